@@ -1,0 +1,97 @@
+"""ctypes binding of libaqlm_hip.so (include/aqlm_hip.h).
+
+The library is built ahead of time by ``aqlm_amd/csrc/Makefile`` (``__graft_entry__.build()``) and lives
+in-tree next to this file.  There is NO fallback: if the shared object is missing or a symbol is absent,
+importing this module raises, and every op that needs it raises with it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaqlm_hip.so")
+ABI_VERSION = 1
+
+F16, BF16 = 0, 1
+E_INVALID, E_UNSUPPORTED = -1, -2
+MAX_GEMV_BATCH = 8
+OP_GEMM_1X16_MFMA = 1
+
+_vp, _ci, _cl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/aqlm_hip.h one to one
+SIGNATURES = {
+    "aqlm_hip_abi_version": (_ci, []),
+    "aqlm_hip_last_error": (ctypes.c_char_p, []),
+    "aqlm_hip_gemv_1x16": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
+    "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
+    "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
+    "aqlm_hip_dequant_1x16": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]),
+    "aqlm_hip_dequant_kx8": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "aqlm_hip_gemm_1x16_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
+    "aqlm_hip_set_tuning": (_ci, [ctypes.c_char_p, _ci]),
+    "aqlm_hip_get_tuning": (_ci, [ctypes.c_char_p, ctypes.POINTER(_ci)]),
+}
+
+
+class AqlmHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X HIP library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C aqlm_amd/csrc`. "
+            "aqlm_amd has no fallback path."
+        )
+    # torch bundles its own libamdhip64.so (same SONAME libamdhip64.so.7); importing torch first makes the
+    # dynamic loader resolve our NEEDED entry to the runtime torch already loaded, so stream handles and device
+    # pointers are shared with torch.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - the C ABI is usable without torch
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.aqlm_hip_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {v}, expected {ABI_VERSION}; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return (lib.aqlm_hip_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map a C-ABI return code to the reference's exception types (cuda_kernel.cpp:9-25, 136-145)."""
+    if rc == 0:
+        return
+    msg = last_error() or what
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise AqlmHipError(f"HIP error {rc}: {msg}")
+
+
+def set_tuning(key: str, value: int) -> None:
+    check(lib.aqlm_hip_set_tuning(key.encode(), int(value)), "set_tuning")
+
+
+def get_tuning(key: str) -> int:
+    v = _ci(0)
+    check(lib.aqlm_hip_get_tuning(key.encode(), ctypes.byref(v)), "get_tuning")
+    return v.value

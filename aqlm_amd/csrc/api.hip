@@ -1,0 +1,65 @@
+// Host-side glue shared by every entry point of libaqlm_hip.so: error reporting, ABI version, tuning knobs.
+#include <stdarg.h>
+#include <string.h>
+
+#include "aqlm_common.h"
+
+namespace aqlm {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_last_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+  return (int)e;
+}
+
+Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+
+static int* tuning_slot(const char* key) {
+  Tuning& t = tuning();
+  if (!key) return nullptr;
+  if (!strcmp(key, "gemv_rows_per_wave")) return &t.gemv_rows_per_wave;
+  if (!strcmp(key, "gemv1x16_aux")) return &t.gemv1x16_aux;
+  if (!strcmp(key, "gemv1x16_prefetch_cb")) return &t.gemv1x16_prefetch_cb;
+  if (!strcmp(key, "gemv1x16_xreg")) return &t.gemv1x16_xreg;
+  if (!strcmp(key, "kx8_replicas")) return &t.kx8_replicas;
+  if (!strcmp(key, "force_generic")) return &t.force_generic;
+  return nullptr;
+}
+
+}  // namespace aqlm
+
+extern "C" int aqlm_hip_abi_version(void) { return AQLM_HIP_ABI_VERSION; }
+
+extern "C" const char* aqlm_hip_last_error(void) { return aqlm::g_err; }
+
+extern "C" int aqlm_hip_set_tuning(const char* key, int value) {
+  int* s = aqlm::tuning_slot(key);
+  if (!s) {
+    aqlm::set_last_error("aqlm_hip_set_tuning: unknown key '%s'", key ? key : "(null)");
+    return AQLM_HIP_E_INVALID;
+  }
+  *s = value;
+  return 0;
+}
+
+extern "C" int aqlm_hip_get_tuning(const char* key, int* value) {
+  int* s = aqlm::tuning_slot(key);
+  if (!s || !value) {
+    aqlm::set_last_error("aqlm_hip_get_tuning: unknown key '%s'", key ? key : "(null)");
+    return AQLM_HIP_E_INVALID;
+  }
+  *value = *s;
+  return 0;
+}

@@ -1,0 +1,103 @@
+// Shared device/host helpers for the gfx950 AQLM kernels.  wave64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/aqlm_hip.h"
+
+namespace aqlm {
+
+constexpr int WAVE = 64;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// buffer cache-policy bits of gfx940+ raw buffer loads (cdna_hip_programming.md T8 / G16)
+constexpr int AUX_DEFAULT = 0;
+constexpr int AUX_SC0 = 1;
+constexpr int AUX_NT = 2;
+constexpr int AUX_SC1 = 16;
+
+// ---------------------------------------------------------------------------------------------
+// element-type traits: fp16 and bf16 share every kernel; arithmetic is v_dot2c_f32_{f16,bf16}
+// with fp32 accumulation (the reference CUDA kernels accumulate each group in half precision,
+// cuda_kernel.cu:69-75; we do not reproduce that rounding).
+// ---------------------------------------------------------------------------------------------
+struct F16 {
+  static constexpr int id = AQLM_HIP_F16;
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+  }
+  static __device__ __forceinline__ float to_float(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ uint16_t from_float(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);  // v_cvt_f16_f32, round-to-nearest-even
+  }
+  // packed add of two f16 pairs (used by dequant to sum codebooks like embedding_bag does in storage dtype)
+  static __device__ __forceinline__ float lo(uint32_t a) { return to_float((uint16_t)(a & 0xffffu)); }
+  static __device__ __forceinline__ float hi(uint32_t a) { return to_float((uint16_t)(a >> 16)); }
+};
+
+struct BF16 {
+  static constexpr int id = AQLM_HIP_BF16;
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+  }
+  static __device__ __forceinline__ float to_float(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+  static __device__ __forceinline__ uint16_t from_float(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                               // round-to-nearest-even
+    return (uint16_t)(u >> 16);
+  }
+  static __device__ __forceinline__ float lo(uint32_t a) { return __uint_as_float(a << 16); }
+  static __device__ __forceinline__ float hi(uint32_t a) { return __uint_as_float(a & 0xffff0000u); }
+};
+
+// <8 halfs, 8 halfs> accumulated into fp32
+template <class T>
+__device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float acc) {
+  acc = T::dot2(w.x, x.x, acc);
+  acc = T::dot2(w.y, x.y, acc);
+  acc = T::dot2(w.z, x.z, acc);
+  acc = T::dot2(w.w, x.w, acc);
+  return acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// compile-time extraction of code #idx from the dwords of one code word
+template <int CODE_BYTES, int N>
+__device__ __forceinline__ uint32_t code_at(const uint32_t (&cw)[N], int idx) {
+  if constexpr (CODE_BYTES == 2) {
+    return (cw[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu;
+  } else {
+    return (cw[idx >> 2] >> ((idx & 3) * 8)) & 0xffu;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+struct Tuning {
+  int gemv_rows_per_wave = 0;    // 0 = heuristic
+  int gemv1x16_aux = AUX_DEFAULT;  // cache policy of the codebook gathers: 0 default, 1 sc0, 2 nt, 16 sc1
+  int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
+  int gemv1x16_xreg = 0;         // reserved
+  int kx8_replicas = 1;          // reserved
+  int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
+};
+Tuning& tuning();
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace aqlm

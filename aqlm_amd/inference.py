@@ -1,0 +1,101 @@
+"""``QuantizedLinear``: the module Hugging Face instantiates for every AQLM-quantized ``nn.Linear``.
+
+Host-side mirror of the reference module (inference_lib/src/aqlm/inference.py:11-142): identical constructor
+signature, parameter names / shapes / dtypes (so checkpoints written by convert_to_hf.py load unchanged,
+including construction on the ``meta`` device by transformers/integrations/aqlm.py:47-57), identical
+gemv-vs-gemm rule, autograd support -- with the kernels behind it replaced by the MI355X ops.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .inference_kernels import get_backward_pass_kernel, get_forward_pass_kernel
+from .utils import get_int_dtype
+
+# rows (batch * seq) at or below which the gemv op is used; the reference's value (inference.py:95-96)
+GEMV_MAX_ROWS = 6
+
+
+class QuantizedLinear(nn.Module):
+    def __init__(
+        self,
+        in_features: int,
+        out_features: int,
+        in_group_size: int,
+        out_group_size: int,
+        num_codebooks: int,
+        nbits_per_codebook: int,
+        bias=True,
+        device=None,
+        dtype=None,
+    ):
+        super().__init__()
+        if in_features % in_group_size or out_features % out_group_size:
+            raise AssertionError("feature counts must be divisible by the group sizes")
+        self.in_features, self.out_features = in_features, out_features
+        self.in_group_size, self.out_group_size = in_group_size, out_group_size
+        self.num_codebooks = num_codebooks
+        self.nbits_per_codebook = nbits_per_codebook
+        self.codebook_size = 2**nbits_per_codebook
+        n_out, n_in = out_features // out_group_size, in_features // in_group_size
+        fkw = {"device": device, "dtype": dtype}
+
+        def frozen(t):
+            return nn.Parameter(t, requires_grad=False)
+
+        # same registration order as the reference (inference.py:39-61): codebooks, codes, scales, bias
+        self.codebooks = frozen(torch.empty((num_codebooks, self.codebook_size, out_group_size, in_group_size), **fkw))
+        self.codes = frozen(torch.empty((n_out, n_in, num_codebooks), device=device, dtype=get_int_dtype(nbits_per_codebook)))
+        self.scales = frozen(torch.empty((n_out, 1, 1, 1), **fkw))
+        if bias:
+            self.bias = frozen(torch.empty(out_features, **fkw))
+        else:
+            self.register_parameter("bias", None)
+
+        self.gemv_op = None
+        self.gemm_op = None
+        self.use_gemv_rule = None
+
+    def extra_repr(self) -> str:
+        return (f"in_features={self.in_features}, out_features={self.out_features}, scheme="
+                f"{self.num_codebooks}x{self.nbits_per_codebook}g{self.in_group_size}, bias={self.bias is not None}")
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if self.gemv_op is None:
+            self.prepare_matmul_op(input)
+        op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
+        return op.apply(input, self.codes, self.codebooks, self.scales, self.bias)
+
+    def prepare_matmul_op(self, input: torch.Tensor):
+        """Resolve the decode (gemv) and batch (gemm) operators once (reference inference.py:77-96).  Unlike the
+        reference there is no CPU branch and therefore no in-place permutation of ``codes``."""
+        self.gemv_op = _get_autograd_matmul_op(
+            get_forward_pass_kernel(self.codebooks, False), get_backward_pass_kernel(self.codebooks, False)
+        )
+        self.gemm_op = _get_autograd_matmul_op(
+            get_forward_pass_kernel(self.codebooks, True), get_backward_pass_kernel(self.codebooks, True)
+        )
+        self.use_gemv_rule = lambda x: math.prod(x.shape[:-1]) <= GEMV_MAX_ROWS
+
+
+def _get_autograd_matmul_op(forward_pass_kernel, backward_pass_kernel):
+    """autograd.Function around a (forward, backward) kernel pair (reference inference.py:99-142): gradient flows
+    to ``input`` only; codes / codebooks / scales / bias are frozen."""
+
+    class _QuantizedMatmul(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, input, codes, codebooks, scales, bias: Optional[torch.Tensor]):
+            ctx.save_for_backward(codes, codebooks, scales)
+            return forward_pass_kernel(input, codes, codebooks, scales, bias)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            codes, codebooks, scales = ctx.saved_tensors
+            grad_input = backward_pass_kernel(grad_output.contiguous(), codes, codebooks, scales, None)
+            return grad_input, None, None, None, None
+
+    return _QuantizedMatmul

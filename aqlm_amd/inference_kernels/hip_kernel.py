@@ -1,0 +1,315 @@
+"""torch.ops.aqlm.* backed by libaqlm_hip.so (MI355X / gfx950).
+
+Host-side mirror of the reference's op registration + host glue
+(inference_lib/src/aqlm/inference_kernels/cuda_kernel.py:13-132 and cuda_kernel.cpp:148-182, 249-354 and the
+2x8 / 1x8 copies): same op names, same schemas, same output shapes, same error conventions -- but each op is a
+thin shim: flatten, allocate the output, call the C ABI (include/aqlm_hip.h) on torch's current stream.
+
+Differences from the reference, all deliberate:
+  * one launch for up to 8 rows instead of a per-row loop; scale+bias fused (no epilogue launches, no clone);
+  * the ``*_matmat_dequant`` ops run a fused dequant-tile -> MFMA kernel for 1x16 (W never reaches HBM); other
+    schemes dequantise with our kernel and call F.linear (hipBLASLt) like the reference;
+  * ``*_dequant_transposed`` applies the scales for every scheme and honours in_group_size (the reference drops
+    the scales for 2x8/1x8 and hard-codes g=8 for 1x16).
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import _native
+from .._native import lib as _lib
+
+HIP_FOLDER = os.path.dirname(os.path.abspath(_native.LIB_PATH))
+CUDA_FOLDER = HIP_FOLDER  # reference name (cuda_kernel.py:6); ROCm reports device type "cuda"
+
+_DT = {torch.float16: _native.F16, torch.bfloat16: _native.BF16}
+
+
+def _dtype_id(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        # message mirrors check_use_bfloat16 (cuda_kernel.cpp:9-25)
+        raise NotImplementedError(
+            f"AQLM HIP kernels only support float16 and bfloat16. Got {t.dtype}. "
+            "Please specify the correct `torch_dtype` when loading the model."
+        ) from None
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _flat_rows(input: torch.Tensor) -> torch.Tensor:
+    x = input.reshape(-1, input.shape[-1])
+    if x.stride(-1) != 1 or (x.shape[0] > 1 and x.stride(0) % 8 != 0) or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+    return x
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------------
+# gemv ops (decode; the hot path)
+# ------------------------------------------------------------------------------------------------------
+def _gemv(input, codes, codebooks, scales, bias, kind):
+    dt = _dtype_id(input)
+    num_codebooks, codebook_size, out_group_size, in_group_size = codebooks.shape
+    if out_group_size != 1:
+        raise NotImplementedError("AQLM HIP kernels require out_group_size == 1")
+    if codebooks.dtype != input.dtype or scales.dtype != input.dtype:
+        raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {codebooks.dtype}")
+    out_features = codes.shape[0]
+    in_features = codes.shape[1] * in_group_size
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _flat_rows(input)
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    B = x.shape[0]
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    stream = _stream_ptr()
+    with torch.cuda.device(input.device):
+        for b0 in range(0, B, _native.MAX_GEMV_BATCH):
+            nb = min(_native.MAX_GEMV_BATCH, B - b0)
+            xp = x.data_ptr() + b0 * x.stride(0) * 2
+            yp = y.data_ptr() + b0 * out_features * 2
+            if kind == "1x16":
+                rc = _lib.aqlm_hip_gemv_1x16(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                             xp, yp, out_features, in_features, in_group_size, nb,
+                                             x.stride(0), out_features, dt, stream)
+            elif kind == "kx8":
+                rc = _lib.aqlm_hip_gemv_kx8(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                            xp, yp, out_features, in_features, num_codebooks, in_group_size, nb,
+                                            x.stride(0), out_features, dt, stream)
+            else:
+                nbits = int(codebook_size).bit_length() - 1
+                rc = _lib.aqlm_hip_gemv_generic(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                                xp, yp, out_features, in_features, num_codebooks, nbits,
+                                                in_group_size, nb, x.stride(0), out_features, dt, stream)
+            if rc:
+                _native.check(rc, "aqlm gemv")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
+def code1x16_matmat(input, codes, codebooks, scales, bias=None):
+    """aqlm::code1x16_matmat (cuda_kernel.py:13-22, cuda_kernel.cpp:148-182)."""
+    if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536:
+        raise NotImplementedError(f"code1x16_matmat needs codebooks [1, 65536, 1, g], got {tuple(codebooks.shape)}")
+    return _gemv(input, codes, codebooks, scales, bias, "1x16")
+
+
+def code2x8_matmat(input, codes, codebooks, scales, bias=None):
+    """aqlm::code2x8_matmat (cuda_kernel.py:58-67, cuda_kernel.cpp:387-421)."""
+    if codebooks.shape[0] != 2 or codebooks.shape[1] != 256:
+        raise NotImplementedError(f"code2x8_matmat needs codebooks [2, 256, 1, g], got {tuple(codebooks.shape)}")
+    return _gemv(input, codes, codebooks, scales, bias, "kx8")
+
+
+def code1x8_matmat(input, codes, codebooks, scales, bias=None):
+    """aqlm::code1x8_matmat (cuda_kernel.py:100-109, cuda_kernel.cpp:552-586)."""
+    if codebooks.shape[0] != 1 or codebooks.shape[1] != 256:
+        raise NotImplementedError(f"code1x8_matmat needs codebooks [1, 256, 1, g], got {tuple(codebooks.shape)}")
+    return _gemv(input, codes, codebooks, scales, bias, "kx8")
+
+
+def codekx8_matmat(input, codes, codebooks, scales, bias=None):
+    """Any K x 8-bit scheme (e.g. 8x8 g32): the HIP replacement for the reference's Triton fallback
+    (kernel_selector.py:91-94, triton_kernel.py:187-205)."""
+    if codebooks.shape[1] != 256:
+        raise NotImplementedError(f"codekx8_matmat needs 256-entry codebooks, got {tuple(codebooks.shape)}")
+    return _gemv(input, codes, codebooks, scales, bias, "kx8")
+
+
+def generic_matmat(input, codes, codebooks, scales, bias=None):
+    """Any scheme with out_group_size == 1 (slow generic kernel)."""
+    return _gemv(input, codes, codebooks, scales, bias, "generic")
+
+
+# ------------------------------------------------------------------------------------------------------
+# dequantisation
+# ------------------------------------------------------------------------------------------------------
+def _dequant(codes, codebooks, scales, kind):
+    dt = _dtype_id(codebooks)
+    num_codebooks, codebook_size, out_group_size, in_group_size = codebooks.shape
+    if out_group_size != 1:
+        raise NotImplementedError("AQLM HIP kernels require out_group_size == 1")
+    out_features = codes.shape[0]
+    in_features = codes.shape[1] * in_group_size
+    codes, codebooks = _c(codes), _c(codebooks)
+    if scales is not None:
+        scales = _c(scales)
+    W = torch.empty((out_features, in_features), dtype=codebooks.dtype, device=codebooks.device)
+    with torch.cuda.device(codebooks.device):
+        if kind == "1x16":
+            rc = _lib.aqlm_hip_dequant_1x16(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
+                                            out_features, in_features, in_group_size, dt, _stream_ptr())
+        else:
+            rc = _lib.aqlm_hip_dequant_kx8(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
+                                           out_features, in_features, num_codebooks, in_group_size, dt, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm dequant")
+    return W
+
+
+def code1x16_dequant(codes, codebooks, scales):
+    """pybind ``code1x16_dequant`` (cuda_kernel.cpp:184-227): scaled weight [out, in]."""
+    return _dequant(codes, codebooks, scales, "1x16")
+
+
+def code2x8_dequant(codes, codebooks, scales):
+    """pybind ``code2x8_dequant`` (cuda_kernel.cpp:423-448)."""
+    return _dequant(codes, codebooks, scales, "kx8")
+
+
+def code1x8_dequant(codes, codebooks, scales):
+    """pybind ``code1x8_dequant`` (cuda_kernel.cpp:588-613)."""
+    return _dequant(codes, codebooks, scales, "kx8")
+
+
+# ------------------------------------------------------------------------------------------------------
+# large-batch ops
+# ------------------------------------------------------------------------------------------------------
+def _fused_mfma_ok(x, in_features):
+    return in_features % 64 == 0
+
+
+def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
+    """aqlm::code1x16_matmat_dequant (cuda_kernel.py:24-35, cuda_kernel.cpp:249-301) -- fused MFMA kernel."""
+    dt = _dtype_id(input)
+    if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536 or codebooks.shape[2] != 1:
+        raise NotImplementedError(f"code1x16_matmat_dequant needs codebooks [1, 65536, 1, g], got {tuple(codebooks.shape)}")
+    in_group_size = codebooks.shape[3]
+    out_features, in_features = codes.shape[0], codes.shape[1] * in_group_size
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _flat_rows(input)
+    B = x.shape[0]
+    if not _fused_mfma_ok(x, in_features):
+        W = _dequant(codes, codebooks, None, "1x16")
+        y = F.linear(x, W)
+        y = y * scales.reshape(1, -1)
+        if bias is not None:
+            y = y + bias
+        return y.reshape(input.shape[:-1] + (out_features,))
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMM_1X16_MFMA, B, out_features, in_features)
+    ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.aqlm_hip_gemm_1x16_mfma(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                          x.data_ptr(), y.data_ptr(), B, out_features, in_features, in_group_size,
+                                          x.stride(0), out_features, dt, ws.data_ptr(), ws.numel() * 4, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm gemm_1x16_mfma")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
+def _matmat_dequant_kx8(input, codes, codebooks, scales, bias):
+    """Reference pipeline for the 8-bit schemes (cuda_kernel.cpp:450-484, 615-649): dequantise (our kernel, scales
+    folded in) then one library GEMM."""
+    _dtype_id(input)
+    W = _dequant(codes, codebooks, scales, "kx8")
+    return F.linear(input, W, bias)
+
+
+def code2x8_matmat_dequant(input, codes, codebooks, scales, bias=None):
+    return _matmat_dequant_kx8(input, codes, codebooks, scales, bias)
+
+
+def code1x8_matmat_dequant(input, codes, codebooks, scales, bias=None):
+    return _matmat_dequant_kx8(input, codes, codebooks, scales, bias)
+
+
+def _matmat_dequant_transposed(input, codes, codebooks, scales, bias, kind):
+    """grad_input = (grad_output * scales) @ W  (+ bias): backward of the linear layer
+    (cuda_kernel.cpp:303-354; generic definition kernel_selector.py:145-161)."""
+    _dtype_id(input)
+    W = _dequant(codes, codebooks, scales, kind)  # scales folded into W rows == scaling grad_output columns
+    out = torch.matmul(input, W)
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def code1x16_matmat_dequant_transposed(input, codes, codebooks, scales, bias=None):
+    return _matmat_dequant_transposed(input, codes, codebooks, scales, bias, "1x16")
+
+
+def code2x8_matmat_dequant_transposed(input, codes, codebooks, scales, bias=None):
+    return _matmat_dequant_transposed(input, codes, codebooks, scales, bias, "kx8")
+
+
+def code1x8_matmat_dequant_transposed(input, codes, codebooks, scales, bias=None):
+    return _matmat_dequant_transposed(input, codes, codebooks, scales, bias, "kx8")
+
+
+# ------------------------------------------------------------------------------------------------------
+# registration: same names + schemas as cuda_kernel.py:13-132 (bias declared optional, which is what the
+# reference's C++ signature std::optional<torch::Tensor> actually accepts)
+# ------------------------------------------------------------------------------------------------------
+_SCHEMA = "(Tensor input, Tensor codes, Tensor codebooks, Tensor scales, Tensor? bias) -> Tensor"
+_LIB = torch.library.Library("aqlm", "DEF")
+
+
+def _fake_forward(input, codes, codebooks, scales, bias=None):
+    return torch.empty(input.shape[:-1] + (codes.shape[0],), device=input.device, dtype=input.dtype)
+
+
+def _fake_transposed(input, codes, codebooks, scales, bias=None):
+    return torch.empty(input.shape[:-1] + (codes.shape[1] * codebooks.shape[3],), device=input.device, dtype=input.dtype)
+
+
+_OPS = {
+    "code1x16_matmat": (code1x16_matmat, _fake_forward),
+    "code1x16_matmat_dequant": (code1x16_matmat_dequant, _fake_forward),
+    "code1x16_matmat_dequant_transposed": (code1x16_matmat_dequant_transposed, _fake_transposed),
+    "code2x8_matmat": (code2x8_matmat, _fake_forward),
+    "code2x8_matmat_dequant": (code2x8_matmat_dequant, _fake_forward),
+    "code2x8_matmat_dequant_transposed": (code2x8_matmat_dequant_transposed, _fake_transposed),
+    "code1x8_matmat": (code1x8_matmat, _fake_forward),
+    "code1x8_matmat_dequant": (code1x8_matmat_dequant, _fake_forward),
+    "code1x8_matmat_dequant_transposed": (code1x8_matmat_dequant_transposed, _fake_transposed),
+    # additions (no reference counterpart: the reference sends these schemes to Triton)
+    "codekx8_matmat": (codekx8_matmat, _fake_forward),
+    "generic_matmat": (generic_matmat, _fake_forward),
+}
+
+for _name, (_impl, _fake) in _OPS.items():
+    _LIB.define(f"{_name}{_SCHEMA}")
+    _LIB.impl(_name, _impl, "CUDA")
+    torch.library.register_fake(f"aqlm::{_name}")(_fake)
+
+# what benchmark/matmul_benchmark.py:6,103 reaches for: CUDA_KERNEL.code1x16_matmat etc. (pybind module in the
+# reference, cuda_kernel.cpp:686-699)
+HIP_KERNEL = SimpleNamespace(
+    code1x16_matmat=code1x16_matmat,
+    code1x16_dequant=code1x16_dequant,
+    code1x16_matmat_dequant=code1x16_matmat_dequant,
+    code1x16_matmat_dequant_transposed=code1x16_matmat_dequant_transposed,
+    code2x8_matmat=code2x8_matmat,
+    code2x8_dequant=code2x8_dequant,
+    code2x8_matmat_dequant=code2x8_matmat_dequant,
+    code2x8_matmat_dequant_transposed=code2x8_matmat_dequant_transposed,
+    code1x8_matmat=code1x8_matmat,
+    code1x8_dequant=code1x8_dequant,
+    code1x8_matmat_dequant=code1x8_matmat_dequant,
+    code1x8_matmat_dequant_transposed=code1x8_matmat_dequant_transposed,
+    codekx8_matmat=codekx8_matmat,
+    generic_matmat=generic_matmat,
+)
+CUDA_KERNEL = HIP_KERNEL

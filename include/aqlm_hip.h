@@ -1,0 +1,131 @@
+/*
+ * aqlm_hip.h -- C ABI of libaqlm_hip.so: the MI355X (gfx950 / CDNA4) implementation of the AQLM
+ * additive-codebook dequant-fused matvec / matmul path.
+ *
+ * This is the drop-in boundary for the ONE hot path of Vahe1994/AQLM that this repository replaces
+ * (SURVEY.md section 8).  Each entry point names the reference interface it replaces; paths are relative
+ * to the reference tree (inference_lib/src/aqlm/inference_kernels/).  INTEGRATION.md shows the binding
+ * a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - raw device pointers, caller-owned, never retained; inputs are never written;
+ *   - stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the null stream), asynchronous,
+ *     no allocation, no synchronisation -> hipGraph-capturable and re-entrant;
+ *   - tensors use the reference's checkpoint layout unchanged:
+ *       codes      [out_features][in_features/in_group_size][num_codebooks]  int8 (nbits<=8) / int16 (nbits<=16)
+ *                  two's-complement containers holding UNSIGNED indices (utils.py:11-31)
+ *       codebooks  [num_codebooks][2**nbits][1][in_group_size]               fp16 / bf16
+ *       scales     [out_features]   (the reference's [out,1,1,1], contiguous)  fp16 / bf16
+ *       bias       [out_features] or NULL
+ *     out_group_size is 1 (as in every reference kernel, kernel_selector.py:27-94);
+ *   - every kernel fuses the epilogue  y = acc * scales[row] + bias[row]  (replaces
+ *     scale_bias_unflatten_output, cuda_kernel.cpp:95-111); accumulation is fp32;
+ *   - dtype: AQLM_HIP_F16 or AQLM_HIP_BF16 for x / y / codebooks / scales / bias alike
+ *     (check_use_bfloat16, cuda_kernel.cpp:9-25);
+ *   - return 0 on success; a positive value is a hipError_t from the launch; negative values are
+ *     AQLM_HIP_E_*.  aqlm_hip_last_error() returns a thread-local human-readable message.
+ */
+#ifndef AQLM_HIP_H_
+#define AQLM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQLM_HIP_ABI_VERSION 1
+
+#define AQLM_HIP_F16 0
+#define AQLM_HIP_BF16 1
+
+#define AQLM_HIP_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, misaligned buffer) */
+#define AQLM_HIP_E_UNSUPPORTED (-2) /* shape / scheme outside what the entry point implements */
+
+#define AQLM_HIP_MAX_GEMV_BATCH 8
+
+/* ABI version of the loaded library (== AQLM_HIP_ABI_VERSION of the header it was built from). */
+int aqlm_hip_abi_version(void);
+
+/* Thread-local message describing the last non-zero return on this thread ("" if none). */
+const char* aqlm_hip_last_error(void);
+
+/*
+ * y[b, :] = (W x[b, :]) * scales + bias   for b < batch (1..AQLM_HIP_MAX_GEMV_BATCH), 1x16 scheme
+ * (one codebook of 65536 entries, in_group_size 8 or 16).  ONE launch for all batch rows: codes and the
+ * gathered codebook vectors are reused across the rows of x.
+ *
+ * Replaces: code1x16_matvec_cuda<bf16,g> + launcher (cuda_kernel.cu:7-95, 476-521), the per-row host loop of
+ *           code1x16_matmat (cuda_kernel.cpp:148-182) and its 3-4 epilogue launches (cuda_kernel.cpp:95-111).
+ * x_row_stride / y_row_stride are in elements.  Requirements: in_features % in_group_size == 0.
+ */
+int aqlm_hip_gemv_1x16(const void* codes_i16, const void* codebook, const void* scales, const void* bias,
+                       const void* x, void* y, int out_features, int in_features, int in_group_size, int batch,
+                       long x_row_stride, long y_row_stride, int dtype, void* stream);
+
+/*
+ * Same contract for K x 8-bit schemes (256-entry codebooks held in LDS): num_codebooks in 1..16, any
+ * in_group_size that is a multiple of 8 (tuned instances: 1x8 g8, 2x8 g8, 8x8 g32; other shapes run a generic kernel).
+ *
+ * Replaces: Code2x8MatVec / CodeKx8MatVec + launchers (cuda_kernel.cu:144-233, 296-390, 555-620, 709-758),
+ *           code2x8_matmat / code1x8_matmat (cuda_kernel.cpp:387-421, 552-586), and the Triton generic gemv the
+ *           reference falls back to for 8x8 etc. (triton_kernel.py:30-205).
+ */
+int aqlm_hip_gemv_kx8(const void* codes_i8, const void* codebooks, const void* scales, const void* bias,
+                      const void* x, void* y, int out_features, int in_features, int num_codebooks,
+                      int in_group_size, int batch, long x_row_stride, long y_row_stride, int dtype, void* stream);
+
+/*
+ * Fully generic gemv (any num_codebooks, nbits <= 16, any in_group_size, codes in 8- or 16-bit containers):
+ * the slow-but-correct path for every scheme without a tuned kernel (the role of triton_kernel.py in the
+ * reference, kernel_selector.py:91-94).
+ */
+int aqlm_hip_gemv_generic(const void* codes, const void* codebooks, const void* scales, const void* bias,
+                          const void* x, void* y, int out_features, int in_features, int num_codebooks, int nbits,
+                          int in_group_size, int batch, long x_row_stride, long y_row_stride, int dtype,
+                          void* stream);
+
+/*
+ * W[out_features][in_features] = sum_c codebooks[c][codes[.., c]]  (* scales[row] if scales != NULL), row-major.
+ * Replaces: Code1x16Dequant / code1x16_dequant_cuda (cuda_kernel.cu:98-142, 523-553), and with scales the
+ *           pybind `code1x16_dequant` (cuda_kernel.cpp:184-227).
+ */
+int aqlm_hip_dequant_1x16(const void* codes_i16, const void* codebook, const void* scales /* nullable */, void* W,
+                          int out_features, int in_features, int in_group_size, int dtype, void* stream);
+
+/*
+ * Replaces: Code2x8Dequant / CodeKx8Dequant (cuda_kernel.cu:235-294, 392-468, 622-707, 760-817) and the pybind
+ *           `code2x8_dequant` / `code1x8_dequant` (cuda_kernel.cpp:423-448, 588-613).  Unlike the reference's
+ *           CodeKx8Dequant there is no read-modify-write of W: all codebooks are summed in registers.
+ */
+int aqlm_hip_dequant_kx8(const void* codes_i8, const void* codebooks, const void* scales /* nullable */, void* W,
+                         int out_features, int in_features, int num_codebooks, int in_group_size, int dtype,
+                         void* stream);
+
+/*
+ * Large-batch path: Y[B][out] = (X[B][in] @ W^T) * scales + bias with W dequantised tile-by-tile into LDS and
+ * contracted on the matrix cores (v_mfma_f32_32x32x16_f16/bf16); W never touches HBM.
+ * Replaces: code1x16_matmat_dequant = Code1x16Dequant + F::linear(cuBLAS) + epilogue (cuda_kernel.cpp:249-301).
+ * X and Y are row-major with the given row strides (elements).  workspace: aqlm_hip_workspace_bytes(...) bytes
+ * (may be 0 -> NULL allowed).
+ */
+int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const void* scales, const void* bias,
+                            const void* X, void* Y, int batch, int out_features, int in_features,
+                            int in_group_size, long x_row_stride, long y_row_stride, int dtype, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+#define AQLM_HIP_OP_GEMM_1X16_MFMA 1
+size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);
+
+/*
+ * Tuning / experiment knobs (process-wide, not part of the reference surface; defaults are the shipped
+ * configuration).  Unknown keys return AQLM_HIP_E_INVALID.  Keys: see aqlm_amd/csrc/tuning.h.
+ */
+int aqlm_hip_set_tuning(const char* key, int value);
+int aqlm_hip_get_tuning(const char* key, int* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQLM_HIP_H_ */

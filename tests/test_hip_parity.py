@@ -1,0 +1,307 @@
+"""GPU parity: the HIP path (through the C ABI) against the pinned oracle and the reference's golden outputs.
+
+Tolerances (BASELINE.json north_star: "fp16 output within 1e-3 rel"):
+  * fp16:  mean|y - y_ref| / mean|y_ref| <= 1e-3 against the fp64 oracle AND against the reference's fp32 run,
+           plus a per-element bound  |y - y64| <= 2e-3 * mean|y64| + 4 * ulp_fp16(|y64|)  to catch localised errors;
+  * bf16:  same with 8e-3 / 1.6e-2 and bf16 ulps (a bf16 output has 8 mantissa bits: rounding alone is ~2e-3 rel;
+           the reference's own bf16 CPU result is 2-3e-3 off, see tests/golden generator log);
+  * integer / layout properties (row permutation, batch consistency, zero input): bit-exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import aqlm_oracle as orc
+from oracle import c_oracle
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hk():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    from aqlm_amd.inference_kernels import hip_kernel
+
+    return hip_kernel
+
+
+DEV = "cuda:0"
+
+
+def tdtype(name):
+    return {"float16": torch.float16, "bfloat16": torch.bfloat16}[name]
+
+
+def to_dev(L, dtype):
+    """numpy layer dict -> torch tensors on the GPU in `dtype` (values are exactly representable)."""
+    f = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dtype).to(DEV)
+    return dict(
+        codes=torch.from_numpy(L["codes"]).to(DEV),
+        codebooks=f(L["codebooks"]),
+        scales=f(L["scales"]),
+        bias=f(L["bias"]),
+        x=f(L["x"]),
+    )
+
+
+def ulp(y, dtype):
+    mant = 10 if dtype == torch.float16 else 7
+    e = np.floor(np.log2(np.maximum(np.abs(y), 2.0**-14)))
+    return 2.0 ** (e - mant)
+
+
+def check_close(y, y64, dtype, what=""):
+    y = np.asarray(y, dtype=np.float64)
+    y64 = np.asarray(y64, dtype=np.float64)
+    assert y.shape == y64.shape, (y.shape, y64.shape)
+    assert np.isfinite(y).all(), f"{what}: non-finite output"
+    mean_tol, el_tol = (1e-3, 2e-3) if dtype == torch.float16 else (8e-3, 1.6e-2)
+    m = np.mean(np.abs(y - y64)) / np.mean(np.abs(y64))
+    assert m <= mean_tol, f"{what}: mean-rel {m:.3e} > {mean_tol}"
+    bound = el_tol * np.mean(np.abs(y64)) + 4 * ulp(y64, dtype)
+    bad = np.abs(y - y64) > bound
+    assert not bad.any(), f"{what}: {bad.sum()} elements outside bound, worst {np.abs(y - y64).max():.4g}"
+    return m
+
+
+def run_forward(hk, K, nbits, g, T, batch_shape=None):
+    x = T["x"] if batch_shape is None else T["x"].reshape(*batch_shape, T["x"].shape[-1])
+    if (K, nbits) == (1, 16):
+        return hk.code1x16_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+    if nbits == 8:
+        return hk.codekx8_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+    return hk.generic_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+
+
+# ------------------------------------------------------------------ golden fixtures (reference outputs)
+GOLDEN = ["c1x16g8_f16", "c1x16g8_f16_nobias", "c1x16g16_f16", "c1x16g8_bf16", "c2x8g8_f16", "c2x8g8_bf16",
+          "c1x8g8_f16", "c8x8g32_f16", "c4x8g16_f16"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_forward_dequant_backward(hk, golden, name):
+    seed, fin, fout, K, nbits, g, batch, bias, ogs = [int(v) for v in golden[f"{name}/cfg"]]
+    dt = tdtype(str(golden[f"{name}/dtype"]))
+    L = orc.make_layer(seed, fin, fout, K, nbits, g, batch=batch, bias=bool(bias),
+                       float_dtype=np.float16 if dt == torch.float16 else "bfloat16")
+    T = to_dev(L, dt)
+    y = run_forward(hk, K, nbits, g, T).float().cpu().numpy()
+    check_close(y, golden[f"{name}/y_ref32"], dt, f"{name} forward vs reference")
+    # generic kernel must agree too
+    yg = hk.generic_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+    check_close(yg, golden[f"{name}/y_ref32"], dt, f"{name} generic vs reference")
+    # dequantised weight
+    W = (hk.code1x16_dequant if nbits == 16 else hk.code2x8_dequant)(T["codes"], T["codebooks"], T["scales"])
+    Wref = golden[f"{name}/W_ref32"]
+    rt = 2.0**-10 if dt == torch.float16 else 2.0**-7
+    np.testing.assert_allclose(W.float().cpu().numpy(), Wref, rtol=rt, atol=1e-6)
+    # backward operator
+    gout = torch.from_numpy(golden[f"{name}/gout"]).to(dt).to(DEV)
+    fn = hk.code1x16_matmat_dequant_transposed if nbits == 16 else hk.code2x8_matmat_dequant_transposed
+    gin = fn(gout, T["codes"], T["codebooks"], T["scales"], None).float().cpu().numpy()
+    gref = orc.dequantize_gemm_transposed(gout.float().cpu().numpy(), L["codes"], L["codebooks"], L["scales"], None)
+    check_close(gin, gref, dt, f"{name} backward vs oracle")
+
+
+# ------------------------------------------------------------------ scheme / shape sweep vs the oracle
+SWEEP = [
+    # K, nbits, g, in, out, batch, bias, dtype
+    (1, 16, 8, 4096, 256, 1, True, "float16"),
+    (1, 16, 8, 4096, 250, 3, False, "float16"),       # out not a multiple of rows-per-block
+    (1, 16, 8, 11008, 96, 1, True, "float16"),        # 1376 groups: 172 units, ragged last iteration
+    (1, 16, 8, 14336, 64, 2, True, "bfloat16"),
+    (1, 16, 8, 520, 64, 1, True, "float16"),          # 65 groups: not a multiple of 8 -> generic route
+    (1, 16, 16, 4096, 128, 5, True, "float16"),
+    (1, 16, 16, 2048, 128, 8, True, "bfloat16"),
+    (2, 8, 8, 4096, 256, 1, True, "float16"),
+    (2, 8, 8, 11008, 100, 7, False, "float16"),
+    (2, 8, 8, 4096, 128, 4, True, "bfloat16"),
+    (1, 8, 8, 4096, 256, 6, True, "float16"),
+    (1, 8, 8, 1000, 64, 1, True, "float16"),          # 125 groups -> generic route
+    (8, 8, 32, 4096, 256, 1, True, "float16"),
+    (8, 8, 32, 4096, 72, 2, True, "bfloat16"),
+    (8, 8, 32, 8192, 64, 3, False, "float16"),
+    (4, 8, 8, 1024, 64, 2, True, "float16"),          # no tuned instance -> generic route via kx8 entry
+    (2, 8, 16, 1024, 64, 1, True, "float16"),
+    (3, 5, 8, 512, 40, 2, True, "float16"),           # odd nbits in int8 containers (generic)
+    (1, 12, 8, 512, 40, 2, True, "float16"),          # 12-bit codes in int16 containers (generic)
+]
+
+
+@pytest.mark.parametrize("K,nbits,g,fin,fout,batch,bias,dt", SWEEP)
+def test_sweep_vs_oracle(hk, K, nbits, g, fin, fout, batch, bias, dt):
+    dtype = tdtype(dt)
+    L = orc.make_layer(1000 + fin + fout + K, fin, fout, K, nbits, g, batch=batch, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = run_forward(hk, K, nbits, g, T).float().cpu().numpy()
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y, y64, dtype, f"{K}x{nbits}g{g} {fin}->{fout} b{batch}")
+
+
+def test_leading_dims_and_noncontiguous_input(hk):
+    L = orc.make_layer(5, 1024, 64, 1, 16, 8, batch=6, bias=True)
+    T = to_dev(L, torch.float16)
+    y = run_forward(hk, 1, 16, 8, T, batch_shape=(2, 3))
+    assert y.shape == (2, 3, 64)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"]).reshape(2, 3, 64)
+    check_close(y.float().cpu().numpy(), y64, torch.float16, "leading dims")
+    wide = torch.zeros(6, 2048, dtype=torch.float16, device=DEV)
+    wide[:, ::2] = T["x"]
+    y2 = hk.code1x16_matmat(wide[:, ::2], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert torch.equal(y2, y.reshape(6, 64))
+
+
+def test_error_conventions(hk):
+    L = orc.make_layer(6, 512, 32, 1, 16, 8, batch=1, bias=False)
+    T = to_dev(L, torch.float16)
+    with pytest.raises(NotImplementedError, match="only support float16 and bfloat16"):
+        hk.code1x16_matmat(T["x"].float(), T["codes"], T["codebooks"].float(), T["scales"].float(), None)
+    with pytest.raises(NotImplementedError):
+        hk.code2x8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], None)  # wrong codebook shape
+    bad_cb = torch.zeros(1, 65536, 1, 4, dtype=torch.float16, device=DEV)
+    with pytest.raises(NotImplementedError, match="8 or 16"):
+        hk.code1x16_matmat(T["x"][:, :256], T["codes"], bad_cb, T["scales"], None)
+    with pytest.raises(ValueError):
+        hk.code1x16_matmat(T["x"][:, :256], T["codes"], T["codebooks"], T["scales"], None)
+
+
+# ------------------------------------------------------------------ full-size (BASELINE shapes) parity + properties
+FULL = [
+    (1, 16, 8, 4096, 4096, "float16"),
+    (1, 16, 8, 4096, 11008, "float16"),
+    (1, 16, 8, 14336, 4096, "bfloat16"),
+    (2, 8, 8, 4096, 11008, "float16"),
+    (8, 8, 32, 4096, 4096, "float16"),
+]
+
+
+@pytest.mark.parametrize("K,nbits,g,fin,fout,dt", FULL)
+def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
+    dtype = tdtype(dt)
+    L = orc.make_layer(77, fin, fout, K, nbits, g, batch=4, bias=True,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = run_forward(hk, K, nbits, g, T)
+    # (1) against the C restatement of dequantize_gemm (pinned through the numpy oracle)
+    ref = c_oracle.DequantGemv(L["codebooks"], L["codes"], L["scales"], L["bias"], nbits, nthreads=0)
+    yh = y.float().cpu().numpy()
+    for b in range(4):
+        check_close(yh[b], ref(L["x"][b]).copy(), dtype, f"full {K}x{nbits}g{g} {fin}->{fout} row {b}")
+    # (2) batch consistency: a row of the batched launch == the same row launched alone (bit-exact)
+    T1 = dict(T, x=T["x"][2:3].contiguous())
+    assert torch.equal(run_forward(hk, K, nbits, g, T1)[0], y[2])
+    # (3) zero input -> exactly the bias
+    Tz = dict(T, x=torch.zeros_like(T["x"][:1]))
+    assert torch.equal(run_forward(hk, K, nbits, g, Tz)[0], T["bias"])
+    # (4) permuting output rows of (codes, scales, bias) permutes y bit-exactly
+    perm = torch.randperm(fout, generator=torch.Generator().manual_seed(3)).to(DEV)
+    Tp = dict(T, codes=T["codes"][perm].contiguous(), scales=T["scales"][perm].contiguous(), bias=T["bias"][perm].contiguous())
+    assert torch.equal(run_forward(hk, K, nbits, g, Tp), y[:, perm])
+    # (5) the dequantised weight reproduces the matvec:  y ~= x @ W^T + bias
+    W = (hk.code1x16_dequant if nbits == 16 else hk.code2x8_dequant)(T["codes"], T["codebooks"], T["scales"])
+    y_w = (T["x"].float() @ W.float().T + T["bias"].float()).cpu().numpy()
+    check_close(yh, y_w, dtype, "gemv vs dequant@x")
+
+
+# ------------------------------------------------------------------ large-batch (MFMA) op
+@pytest.mark.parametrize("g,fin,fout,B,dt", [
+    (8, 512, 128, 32, "float16"),
+    (8, 4096, 4096, 128, "float16"),
+    (8, 4096, 1000, 100, "float16"),     # ragged rows and batch
+    (8, 11008, 256, 7, "bfloat16"),
+    (16, 4096, 512, 128, "float16"),
+    (8, 1024, 384, 300, "float16"),      # batch > 128: column slabs
+    (8, 520, 64, 16, "float16"),         # in % 64 != 0 -> dequant + F.linear route
+])
+def test_matmat_dequant_mfma(hk, g, fin, fout, B, dt):
+    dtype = tdtype(dt)
+    L = orc.make_layer(4242 + B, fin, fout, 1, 16, g, batch=B, bias=True,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+    W64 = orc.dequantize_weight(L["codes_unsigned"], L["codebooks"], L["scales"])
+    y64 = L["x"].astype(np.float64) @ W64.T + L["bias"].astype(np.float64)
+    check_close(y, y64, dtype, f"mfma g{g} {fin}->{fout} B{B}")
+
+
+@pytest.mark.parametrize("K,g", [(2, 8), (1, 8), (8, 32)])
+def test_matmat_dequant_kx8(hk, K, g):
+    L = orc.make_layer(99, 2048, 192, K, 8, g, batch=40, bias=True)
+    T = to_dev(L, torch.float16)
+    y = hk.code2x8_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y, y64, torch.float16, f"{K}x8 dequant+gemm")
+
+
+# ------------------------------------------------------------------ module level: QuantizedLinear + autograd + graphs
+def _module_from(L, K, nbits, g, fin, fout, dtype):
+    from aqlm import QuantizedLinear
+
+    m = QuantizedLinear(fin, fout, g, 1, K, nbits, bias=L["bias"] is not None, device=DEV, dtype=dtype)
+    T = to_dev(L, dtype)
+    with torch.no_grad():
+        m.codes.copy_(T["codes"]); m.codebooks.copy_(T["codebooks"]); m.scales.copy_(T["scales"])
+        if T["bias"] is not None:
+            m.bias.copy_(T["bias"])
+    return m, T
+
+
+@pytest.mark.parametrize("K,nbits,g", [(1, 16, 8), (2, 8, 8), (8, 8, 32)])
+def test_quantized_linear_forward_backward(hk, K, nbits, g):
+    fin, fout = 1024, 192
+    L = orc.make_layer(31, fin, fout, K, nbits, g, batch=12, bias=True)
+    m, T = _module_from(L, K, nbits, g, fin, fout, torch.float16)
+    W64 = orc.dequantize_weight(L["codes_unsigned"], L["codebooks"], L["scales"])
+    for rows in (3, 12):  # gemv rule (<= 6 rows) and gemm rule
+        x = T["x"][:rows].clone().requires_grad_(True)
+        y = m(x)
+        y64 = L["x"][:rows].astype(np.float64) @ W64.T + L["bias"].astype(np.float64)
+        check_close(y.detach().float().cpu().numpy(), y64, torch.float16, f"module fwd rows={rows}")
+        gout = torch.randn(rows, fout, generator=torch.Generator().manual_seed(1)).to(torch.float16).to(DEV)
+        y.backward(gout)
+        gin64 = gout.float().cpu().numpy().astype(np.float64) @ W64
+        check_close(x.grad.float().cpu().numpy(), gin64, torch.float16, f"module bwd rows={rows}")
+
+
+def test_hipgraph_capture_and_side_stream(hk):
+    L = orc.make_layer(8, 4096, 512, 1, 16, 8, batch=1, bias=True)
+    T = to_dev(L, torch.float16)
+    eager = hk.code1x16_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        side = hk.code1x16_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    s.synchronize()
+    assert torch.equal(side, eager)
+    g = torch.cuda.CUDAGraph()
+    static_x = T["x"].clone()
+    with torch.cuda.graph(g):
+        out = hk.code1x16_matmat(static_x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+    static_x.copy_(T["x"])
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    static_x.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], T["bias"])
+
+
+def test_raw_c_abi_strided_rows(hk):
+    """Call the C ABI directly with non-trivial x / y row strides."""
+    from aqlm_amd import _native
+
+    L = orc.make_layer(15, 2048, 128, 2, 8, 8, batch=3, bias=True)
+    T = to_dev(L, torch.float16)
+    xbuf = torch.zeros(3, 4096, dtype=torch.float16, device=DEV)
+    xbuf[:, :2048] = T["x"]
+    ybuf = torch.full((3, 256), 7.0, dtype=torch.float16, device=DEV)
+    rc = _native.lib.aqlm_hip_gemv_kx8(T["codes"].data_ptr(), T["codebooks"].data_ptr(), T["scales"].data_ptr(),
+                                       T["bias"].data_ptr(), xbuf.data_ptr(), ybuf.data_ptr(), 128, 2048, 2, 8, 3,
+                                       4096, 256, _native.F16, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _native.last_error()
+    torch.cuda.synchronize()
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(ybuf[:, :128].float().cpu().numpy(), y64, torch.float16, "raw abi")
+    assert (ybuf[:, 128:] == 7.0).all()

@@ -1,0 +1,134 @@
+"""CPU-only checks of the host-side mirror of the reference interface (module, selector, op schemas, utils)."""
+import importlib.metadata
+
+import numpy as np
+import pytest
+import torch
+
+import aqlm
+import aqlm_amd
+from aqlm_amd import utils
+from oracle import aqlm_oracle as orc
+
+
+def test_dropin_import_paths():
+    from aqlm import QuantizedLinear, optimize_for_training  # noqa: F401
+    from aqlm.inference import QuantizedLinear as Q2
+    from aqlm.inference_kernels import get_backward_pass_kernel, get_forward_pass_kernel  # noqa: F401
+    from aqlm.inference_kernels.kernel_selector import get_forward_pass_kernel as g2  # noqa: F401
+    from aqlm.utils import _dequantize_weight, get_int_dtype, pack_int_data, unpack_int_data  # noqa: F401
+
+    assert Q2 is aqlm_amd.QuantizedLinear
+    # what quantizer_aqlm.py:63-72 probes
+    assert importlib.metadata.version("aqlm") >= "1.0.2"
+
+
+@pytest.mark.parametrize("K,nbits,g,bias", [(1, 16, 8, True), (2, 8, 8, False), (8, 8, 32, True), (1, 16, 16, False)])
+def test_quantized_linear_parameters_match_reference_contract(K, nbits, g, bias):
+    m = aqlm.QuantizedLinear(1024, 256, g, 1, K, nbits, bias=bias, device="meta", dtype=torch.float16)
+    sd = {k: (tuple(v.shape), v.dtype) for k, v in m.state_dict().items()}
+    want = {
+        "codebooks": ((K, 2**nbits, 1, g), torch.float16),
+        "codes": ((256, 1024 // g, K), torch.int8 if nbits <= 8 else torch.int16),
+        "scales": ((256, 1, 1, 1), torch.float16),
+    }
+    if bias:
+        want["bias"] = ((256,), torch.float16)
+    assert sd == want
+    assert list(m.state_dict()) == list(want)  # registration order (reference inference.py:39-61)
+    assert all(not p.requires_grad for p in m.parameters())
+    for attr in ("in_features", "out_features", "in_group_size", "out_group_size", "num_codebooks",
+                 "nbits_per_codebook", "codebook_size"):
+        assert hasattr(m, attr)
+    assert m.codebook_size == 2**nbits and m.gemv_op is None and m.gemm_op is None
+
+
+def test_state_dict_roundtrip_cpu():
+    m = aqlm.QuantizedLinear(256, 64, 8, 1, 2, 8, bias=True, dtype=torch.float16)
+    L = orc.make_layer(3, 256, 64, 2, 8, 8)
+    sd = {"codes": torch.from_numpy(L["codes"]), "codebooks": torch.from_numpy(L["codebooks"]),
+          "scales": torch.from_numpy(L["scales"]), "bias": torch.from_numpy(L["bias"])}
+    m.load_state_dict(sd)
+    assert torch.equal(m.codes, sd["codes"]) and m.codes.dtype == torch.int8
+
+
+def test_no_cpu_fallback():
+    """The product has no CPU path: asking for a kernel for CPU tensors must raise, not silently dequantise."""
+    m = aqlm.QuantizedLinear(256, 64, 8, 1, 1, 16, bias=False, dtype=torch.float16)
+    with pytest.raises(NotImplementedError, match="MI355X"):
+        m(torch.zeros(1, 256, dtype=torch.float16))
+    with pytest.raises(NotImplementedError):
+        aqlm.get_forward_pass_kernel(torch.zeros(2, 256, 1, 8), False)
+    with pytest.raises(NotImplementedError):
+        aqlm.get_backward_pass_kernel(torch.zeros(2, 256, 1, 8), True)
+
+
+def test_selector_table_on_meta_codebooks_is_gpu_only():
+    cb = torch.empty(1, 65536, 1, 8, device="meta", dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        aqlm.get_forward_pass_kernel(cb, False)
+
+
+def test_op_schemas_and_fake_impls():
+    from aqlm_amd.inference_kernels import hip_kernel  # noqa: F401  (registers the ops)
+
+    x = torch.empty(2, 3, 512, device="meta", dtype=torch.bfloat16)
+    codes = torch.empty(96, 64, 1, device="meta", dtype=torch.int16)
+    cb = torch.empty(1, 65536, 1, 8, device="meta", dtype=torch.bfloat16)
+    sc = torch.empty(96, 1, 1, 1, device="meta", dtype=torch.bfloat16)
+    for name in ("code1x16_matmat", "code1x16_matmat_dequant", "code2x8_matmat", "code2x8_matmat_dequant",
+                 "code1x8_matmat", "code1x8_matmat_dequant", "codekx8_matmat", "generic_matmat"):
+        y = getattr(torch.ops.aqlm, name)(x, codes, cb, sc, None)
+        assert y.shape == (2, 3, 96) and y.dtype == torch.bfloat16 and y.device.type == "meta"
+    g = torch.empty(2, 3, 96, device="meta", dtype=torch.bfloat16)
+    for name in ("code1x16_matmat_dequant_transposed", "code2x8_matmat_dequant_transposed",
+                 "code1x8_matmat_dequant_transposed"):
+        assert getattr(torch.ops.aqlm, name)(g, codes, cb, sc, None).shape == (2, 3, 512)
+    schema = str(torch.ops.aqlm.code1x16_matmat.default._schema)
+    assert "Tensor input, Tensor codes, Tensor codebooks, Tensor scales, Tensor? bias" in schema
+    from aqlm.inference_kernels.cuda_kernel import CUDA_KERNEL
+
+    for fn in ("code1x16_matmat", "code2x8_matmat", "code1x16_dequant", "code2x8_dequant", "code1x8_dequant"):
+        assert callable(getattr(CUDA_KERNEL, fn))
+
+
+def test_utils_against_reference_golden(golden):
+    for nbits in (8, 12, 16):
+        vals = torch.from_numpy(golden[f"kat/pack{nbits}_in"])
+        keep = vals.clone()
+        packed = utils.pack_int_data(vals, nbits)
+        assert torch.equal(vals, keep), "pack_int_data must not mutate its argument"
+        np.testing.assert_array_equal(packed.numpy(), golden[f"kat/pack{nbits}_out"])
+        np.testing.assert_array_equal(utils.unpack_int_data(packed, nbits).numpy(), golden[f"kat/unpack{nbits}_out"])
+    for name in ("c2x8g8_f16", "c2x8g8_og2_f32", "c8x8g32_f16"):
+        seed, fin, fout, K, nbits, g, batch, bias, ogs = [int(v) for v in golden[f"{name}/cfg"]]
+        L = orc.make_layer(seed, fin, fout, K, nbits, g, batch=batch, bias=bool(bias), out_group_size=ogs,
+                           float_dtype=np.float32 if "f32" in name else np.float16)
+        W = utils._dequantize_weight(torch.from_numpy(L["codes_unsigned"]), torch.from_numpy(L["codebooks"]).float(),
+                                     torch.from_numpy(L["scales"]).float())
+        np.testing.assert_allclose(W.numpy(), golden[f"{name}/W_ref32"], rtol=1e-5, atol=1e-5)
+
+
+def test_hf_integration_replaces_linears_with_our_module():
+    """transformers/integrations/aqlm.py:27-70 builds our QuantizedLinear on the meta device."""
+    transformers = pytest.importorskip("transformers")
+    try:
+        from transformers import AqlmConfig, LlamaConfig, LlamaForCausalLM
+        from transformers.integrations.aqlm import replace_with_aqlm_linear
+    except Exception as e:  # pragma: no cover
+        pytest.skip(f"transformers AQLM integration not importable: {e}")
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=64)
+    with torch.device("meta"):
+        model = LlamaForCausalLM(cfg)
+    qcfg = AqlmConfig(in_group_size=8, out_group_size=1, num_codebooks=1, nbits_per_codebook=16,
+                      linear_weights_not_to_quantize=["lm_head"])
+    try:
+        out = replace_with_aqlm_linear(model, quantization_config=qcfg, modules_to_not_convert=["lm_head"])
+    except TypeError:
+        out = replace_with_aqlm_linear(model, quantization_config=qcfg, linear_weights_not_to_quantize=["lm_head"])
+    model = out[0] if isinstance(out, tuple) else out
+    q = model.model.layers[0].self_attn.q_proj
+    assert type(q) is aqlm_amd.QuantizedLinear
+    assert q.codes.shape == (128, 16, 1) and q.codes.dtype == torch.int16
+    assert not isinstance(model.lm_head, aqlm_amd.QuantizedLinear)
