@@ -453,9 +453,11 @@ extern "C" int aqlm_hip_gemv_kx8(const void* codes, const void* codebooks, const
   if (K == 1 && G == 8) U = 8;
   else if (K == 2 && G == 8) U = 8;
   else if (K == 8 && G == 32) { U = 1; hint = 16 * 256; }
+  // x tile budget: whatever the 160 KiB of LDS leaves next to the codebooks (8x8 g32: 128 KiB of codebooks)
+  const size_t cb_lds = (size_t)K * 256 * G * 2;
+  const size_t x_budget = std::min<size_t>(kMaxXTileBytes, 160 * 1024 - cb_lds - 2048);
   const bool fast = U != 0 && !tuning().force_generic && (in_groups % U == 0) && aligned16(codes) &&
-                    aligned16(codebooks) && aligned16(x) && (xs % 8 == 0) &&
-                    ((long)in_groups * K) % (U * K) == 0 && x_row_bytes <= (G == 32 ? 16 * 1024 : kMaxXTileBytes);
+                    aligned16(codebooks) && aligned16(x) && (xs % 8 == 0) && x_row_bytes + 256 <= x_budget;
   if (!fast)
     return run_generic(codes, codebooks, scales, bias, x, y, out_features, in_features, K, 8, G, batch, xs, ys, dtype,
                        stream);
@@ -472,12 +474,11 @@ extern "C" int aqlm_hip_gemv_kx8(const void* codes, const void* codebooks, const
   p.prefetch = 0;
   if (U == 8) finish_params<8>(p, in_groups, out_features, hint);
   else finish_params<1>(p, in_groups, out_features, hint);
-  const size_t x_budget = (G == 32) ? 16 * 1024 : kMaxXTileBytes;
   int done = 0;
   while (done < batch) {
     int nb = 0;
     for (int cand : {8, 4, 2, 1})
-      if (cand <= batch - done && (size_t)cand * x_row_bytes <= x_budget) { nb = cand; break; }
+      if (cand <= batch - done && (size_t)cand * (x_row_bytes + 256) <= x_budget) { nb = cand; break; }
     p.x = (const uint16_t*)x + (long)done * xs;
     p.y = (uint16_t*)y + (long)done * ys;
     int e;

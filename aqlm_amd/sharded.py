@@ -1,0 +1,113 @@
+"""Row-/column-sharded QuantizedLinear over several MI355X (one process per GPU, torch.distributed over RCCL/xGMI).
+
+New design -- the reference has no tensor parallelism anywhere; BASELINE.json's north star
+asks for the 70B layer shapes (8192 -> 28672) to be "sharded row-wise across 8 GPUs with an RCCL all-reduce over xGMI".
+
+Two partitions of one layer  y = (W x) * scales + bias :
+
+  * ``"in"``  (row-parallel, the north star's variant): rank r owns the input-group slice
+    ``codes[:, j0:j1, :]`` and consumes ``x[..., j0*g : j1*g]``; codebooks and scales are replicated.  Each rank
+    runs the ordinary gemv on its ``[out, in/R]`` slice with the scales applied (the layer is linear in the slice
+    contributions) and the bias added on rank 0 only; partial outputs are summed with ONE all-reduce of
+    ``batch x out`` elements (56 KiB in fp16 for out = 28672 -- latency-bound on xGMI, not bandwidth-bound).
+  * ``"out"`` (column-parallel): rank r owns ``codes[i0:i1]``, ``scales[i0:i1]``, ``bias[i0:i1]``; x and the
+    codebooks are replicated; outputs are concatenated with an all-gather (or left sharded when the next layer is
+    in-split -- the Megatron pairing).  Bit-identical to the single-GPU result.
+
+The per-shard compute is whatever ``get_forward_pass_kernel`` returns for the shard's codebooks (the HIP ops); tests
+inject a different ``kernel`` to exercise the sharding + collective logic on CPU with the gloo backend.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .inference_kernels import get_forward_pass_kernel
+
+
+def shard_bounds(n: int, world: int, rank: int, multiple: int = 1):
+    """Contiguous, nearly equal split of ``n`` units in chunks of ``multiple`` units: returns [lo, hi)."""
+    blocks = (n + multiple - 1) // multiple
+    base, rem = divmod(blocks, world)
+    lo_b = rank * base + min(rank, rem)
+    hi_b = lo_b + base + (1 if rank < rem else 0)
+    return min(lo_b * multiple, n), min(hi_b * multiple, n)
+
+
+class ShardedQuantizedLinear(nn.Module):
+    """One rank's shard of an AQLM layer.  Build it with :meth:`from_full` (every rank passes the full tensors, or
+    loads only its slice using :func:`shard_bounds`)."""
+
+    def __init__(self, codes, codebooks, scales, bias, *, mode: str, in_group_size: int, in_lo: int, in_hi: int,
+                 out_lo: int, out_hi: int, out_features: int, group=None, gather_output: bool = True,
+                 kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        assert mode in ("in", "out")
+        self.mode = mode
+        self.group = group
+        self.gather_output = gather_output
+        self.in_group_size = in_group_size
+        self.in_lo, self.in_hi, self.out_lo, self.out_hi = in_lo, in_hi, out_lo, out_hi
+        self.out_features = out_features
+        self.reduce_dtype = reduce_dtype
+        self.codes = nn.Parameter(codes, requires_grad=False)
+        self.codebooks = nn.Parameter(codebooks, requires_grad=False)
+        self.scales = nn.Parameter(scales, requires_grad=False)
+        self.bias = nn.Parameter(bias, requires_grad=False) if bias is not None else None
+        self._kernel = kernel
+
+    @classmethod
+    def from_full(cls, codes, codebooks, scales, bias, *, mode: str = "in", group=None, gather_output: bool = True,
+                  kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = None):
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        out_groups, in_groups, _ = codes.shape
+        g = codebooks.shape[3]
+        if mode == "in":
+            # multiples of 8 groups keep each shard on the tuned (16-B code word) kernels
+            j0, j1 = shard_bounds(in_groups, world, rank, multiple=8)
+            c = codes[:, j0:j1, :].contiguous()
+            b = bias if (bias is not None and rank == 0) else None
+            return cls(c, codebooks, scales, b, mode=mode, in_group_size=g, in_lo=j0 * g, in_hi=j1 * g, out_lo=0,
+                       out_hi=out_groups, out_features=out_groups, group=group, gather_output=gather_output,
+                       kernel=kernel, reduce_dtype=reduce_dtype)
+        i0, i1 = shard_bounds(out_groups, world, rank)
+        return cls(codes[i0:i1].contiguous(), codebooks, scales[i0:i1].contiguous(),
+                   None if bias is None else bias[i0:i1].contiguous(), mode=mode, in_group_size=g, in_lo=0,
+                   in_hi=in_groups * g, out_lo=i0, out_hi=i1, out_features=out_groups, group=group,
+                   gather_output=gather_output, kernel=kernel, reduce_dtype=reduce_dtype)
+
+    def _k(self):
+        if self._kernel is None:
+            self._kernel = get_forward_pass_kernel(self.codebooks, False)
+        return self._kernel
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if self.mode == "in":
+            xs = x[..., self.in_lo:self.in_hi]
+            if self.codes.shape[1] == 0:  # more ranks than 8-group blocks: this rank contributes nothing
+                y = torch.zeros(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=x.device)
+            else:
+                y = self._k()(xs, self.codes, self.codebooks, self.scales, self.bias)
+            if world > 1:
+                if self.reduce_dtype is not None and self.reduce_dtype != y.dtype:
+                    acc = y.to(self.reduce_dtype)
+                    dist.all_reduce(acc, group=self.group)
+                    y = acc.to(y.dtype)
+                else:
+                    dist.all_reduce(y, group=self.group)
+            return y
+        y = self._k()(x, self.codes, self.codebooks, self.scales, self.bias)
+        if world == 1 or not self.gather_output:
+            return y
+        sizes = [shard_bounds(self.out_features, world, r)[1] - shard_bounds(self.out_features, world, r)[0]
+                 for r in range(world)]
+        width = max(sizes)  # all_gather needs equal shapes: pad ragged shards, trim after
+        mine = y if y.shape[-1] == width else torch.nn.functional.pad(y, (0, width - y.shape[-1]))
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine.contiguous(), group=self.group)
+        return torch.cat([p[..., :s] for p, s in zip(parts, sizes)], dim=-1)

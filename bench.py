@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the AQLM QuantizedLinear matvec path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "1x16g8 matvec, Llama-3-8B linear shapes (4096->4096/11008), bs=1"):
+one STEP = one decode token's pass, batch 1, through a stack of 32 blocks, each block = one 4096->4096 and one
+4096->11008 1x16g8 QuantizedLinear matvec.  All 64 layers are distinct instances (own codes AND own codebook, like a
+real model), 564 MB of algorithmic bytes per step, so every step streams its weights from HBM (cold: larger than the
+256 MiB Infinity Cache).  The step is captured once in a hipGraph (launch-bound otherwise) and replayed.
+
+value = algorithmic GB/s of the whole job = ranks x bytes-per-step / step time, inputs resident in HBM.
+N > 1 = N independent replicas of the step (one process per GPU, no data-path collective: decode data parallelism),
+"scaling": "weak".  The north star's row-sharded 70B layer + RCCL all-reduce is measured next to it and reported in
+"sharded_70b" (it is an extra, never the headline value).
+
+Extra objects: "roofline" (dominant kernel = the 1x16 gemv; duration from HIP events over the timed region on the
+launch stream, i.e. including inter-launch gaps), "cpu_baseline" (oracle C port of the reference CPU path on the host
+cores, rank 0, N=1 only, bounded sample), "detail" (per-shape cold/warm timings, Llama-3-8B / Llama-2-7B tokens/s,
+other schemes).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
+    """SURVEY.md section 8(d)."""
+    n = fout * (fin // g) * K * (1 if nbits <= 8 else 2) + K * (2**nbits) * g * 2
+    n += batch * fin * 2 + batch * fout * 2 + fout * 2 + (fout * 2 if bias else 0)
+    return n
+
+
+class Layer:
+    """One synthetic QuantizedLinear instance resident in HBM (mirrors benchmark/matmul_benchmark.py:83-97:
+    uniform random codes, randn codebooks, scales = 1, no bias)."""
+
+    def __init__(self, fin, fout, K, nbits, g, seed, device, batch=1):
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.fin, self.fout, self.K, self.nbits, self.g = fin, fout, K, nbits, g
+        cdt = torch.int16 if nbits > 8 else torch.int8
+        lo, hi = (-(2 ** (nbits - 1)), 2 ** (nbits - 1))
+        self.codes = torch.randint(lo, hi, (fout, fin // g, K), generator=gen, device=device, dtype=torch.int32).to(cdt)
+        self.codebooks = torch.randn((K, 2**nbits, 1, g), generator=gen, device=device, dtype=torch.float32).half()
+        self.scales = torch.ones((fout, 1, 1, 1), device=device, dtype=torch.float16)
+        self.x = torch.randn((batch, fin), generator=gen, device=device, dtype=torch.float32).half()
+        self.y = torch.empty((batch, fout), device=device, dtype=torch.float16)
+        self.bytes = algorithmic_bytes(fin, fout, K, nbits, g, batch)
+
+    def launch(self, lib, stream, batch=1):
+        from aqlm_amd import _native
+
+        if self.nbits == 16:
+            rc = lib.aqlm_hip_gemv_1x16(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
+                                        self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, batch,
+                                        self.fin, self.fout, _native.F16, stream)
+        else:
+            rc = lib.aqlm_hip_gemv_kx8(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
+                                       self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.K, self.g, batch,
+                                       self.fin, self.fout, _native.F16, stream)
+        if rc:
+            _native.check(rc)
+
+
+class GraphedPass:
+    """A list of layer launches captured once into a hipGraph on a side stream."""
+
+    def __init__(self, layers, lib, batch=1):
+        self.layers, self.n = layers, len(layers)
+        self.bytes = sum(algorithmic_bytes(l.fin, l.fout, l.K, l.nbits, l.g, batch) for l in layers)
+        self.stream = torch.cuda.Stream()
+        with torch.cuda.stream(self.stream):
+            for l in layers:  # eager warm-up (also sets kernel attributes outside capture)
+                l.launch(lib, self.stream.cuda_stream, batch)
+        self.stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            s = torch.cuda.current_stream().cuda_stream
+            for l in layers:
+                l.launch(lib, s, batch)
+
+    def time_replays(self, reps, warmup=2):
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self.graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            for _ in range(reps):
+                self.graph.replay()
+            e1.record(self.stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps  # ms per replay
+
+
+def cpu_baseline(sample_seconds=12.0):
+    """Oracle C port of what the reference executes on CPU for 1x16 (dequantize + F.linear, kernel_selector.py:99-102;
+    oracle/aqlm_oracle.c aqlm_oracle_dequant_gemv_f32), all host cores, on the two workload shapes, bounded sample."""
+    from oracle import aqlm_oracle as orc
+    from oracle import c_oracle
+
+    threads = c_oracle.max_threads()
+    total_bytes, total_time, per_shape = 0, 0.0, {}
+    lut_info = {}
+    for fin, fout in ((4096, 4096), (4096, 11008)):
+        L = orc.make_layer(0, fin, fout, 1, 16, 8, batch=1, bias=False, float_dtype=np.float32, edge_codes=False)
+        k = c_oracle.DequantGemv(L["codebooks"], L["codes"], L["scales"], None, 16, nthreads=threads)
+        x = L["x"][0]
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 1.5:  # let the OpenMP pool spin up (first parallel regions are 10x slow)
+            k(x)
+        t0, times = time.perf_counter(), []
+        while time.perf_counter() - t0 < sample_seconds / 4:
+            t1 = time.perf_counter()
+            k(x)
+            times.append(time.perf_counter() - t1)
+        dt, n = float(np.median(times)), len(times)
+        b = algorithmic_bytes(fin, fout)
+        per_shape[f"{fin}x{fout}"] = {"ms": dt * 1e3, "GBps": b / dt * 1e-9, "iters": n}
+        total_bytes += b
+        total_time += dt
+        if fout == 4096:  # the numba-LUT restatement with u16 codes, few iterations
+            lk = c_oracle.LutGemv(L["codebooks"], orc.permute_codes_for_lut(L["codes"]), L["scales"], 16, nthreads=threads)
+            lk(x)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                lk(x)
+            lut_info = {"lut_gemv_u16_ms": (time.perf_counter() - t1) / 3 * 1e3}
+    return {
+        "value": total_bytes / total_time * 1e-9,
+        "unit": "GB/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle C dequant-gemv (reference CPU path for 1x16), fp32, one 4096->4096 + one 4096->11008 layer, "
+                  f"~{sample_seconds / 2:.0f} s of repeated calls on {threads} OpenMP threads",
+        "per_shape": per_shape,
+        **lut_info,
+    }
+
+
+def sharded_70b(lib, dev, rank, world, steps):
+    """North-star config 5: Llama-3-70B 8192->28672 1x16g8 layer, split along `in` over `world` ranks, partial outputs
+    summed with an RCCL all-reduce (fp16, 56 KiB).  With world == 1 only the per-shard kernel for /8 is timed."""
+    import torch.distributed as dist
+
+    fin, fout = 8192, 28672
+    parts = world if world > 1 else 8
+    shard_in = fin // parts
+    layers = [Layer(shard_in, fout, 1, 16, 8, 1000 + rank * 100 + i, dev) for i in range(16)]
+    gp = GraphedPass(layers, lib)
+    ms = gp.time_replays(max(4, steps // 2))
+    kernel_us = ms * 1e3 / gp.n
+    out = {"layer": "8192->28672 1x16g8", "parts": parts, "shard_in": shard_in, "kernel_us_per_shard": kernel_us,
+           "shard_algorithmic_bytes": layers[0].bytes, "kernel_GBps_per_gpu": layers[0].bytes / kernel_us * 1e-3}
+    if world > 1:
+        s = torch.cuda.current_stream()
+        y = layers[0].y
+        for _ in range(5):
+            layers[0].launch(lib, s.cuda_stream)
+            dist.all_reduce(y)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        n = 50
+        for i in range(n):
+            layers[i % len(layers)].launch(lib, s.cuda_stream)
+            dist.all_reduce(layers[i % len(layers)].y)
+        torch.cuda.synchronize()
+        dt = torch.tensor([(time.perf_counter() - t0) / n], device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        e2e_us = float(dt.item()) * 1e6
+        full_bytes = algorithmic_bytes(fin, fout)
+        out.update({"end_to_end_us": e2e_us, "allreduce_bytes": fout * 2,
+                    "aggregate_GBps_kernel_only": world * layers[0].bytes / kernel_us * 1e-3,
+                    "aggregate_GBps_end_to_end": full_bytes / e2e_us * 1e-3})
+    else:
+        out["collective"] = "unmeasured (1 GPU)"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-detail", action="store_true", help="skip the untimed per-shape / other-scheme breakdown")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from aqlm_amd import _native  # raises if libaqlm_hip.so is missing
+
+    lib = _native.lib
+
+    # ---- the workload: 32 blocks x {4096->4096, 4096->11008}, all distinct
+    NBLOCKS = 32
+    layers = []
+    for i in range(NBLOCKS):
+        layers.append(Layer(4096, 4096, 1, 16, 8, rank * 10000 + 2 * i, dev))
+        layers.append(Layer(4096, 11008, 1, 16, 8, rank * 10000 + 2 * i + 1, dev))
+    step = GraphedPass(layers, lib)
+    torch.cuda.synchronize()
+
+    # ---- W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides
+    with torch.cuda.stream(step.stream):
+        for _ in range(args.warmup):
+            step.graph.replay()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(step.stream):
+        e0.record(step.stream)
+        for _ in range(args.steps):
+            step.graph.replay()
+        e1.record(step.stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev_ms = e0.elapsed_time(e1)
+    if dist:
+        t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * step.bytes / (ms_per_step * 1e-3) * 1e-9
+
+    # ---- roofline of the dominant kernel (1x16 gemv): HIP events on the launch stream over the timed region
+    launches = args.steps * step.n
+    avg_launch_us = ev_ms * 1e3 / launches
+    bytes_per_launch = step.bytes / step.n
+    achieved = bytes_per_launch / avg_launch_us * 1e-3  # GB/s
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("gemv_1x16_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "aqlm::gemv_kernel<F16,1x16,g8,NB=1>",
+                "avg_launch_us": avg_launch_us, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "launches_timed": launches,
+                "note": "duration = HIP-event time of the timed region / launches (includes ~1 us inter-launch gaps); "
+                        "rocprofv3 kernel-only durations are in profiles/"}
+
+    result = {
+        "metric": "QuantizedLinear 1x16g8 matvec algorithmic GB/s (bs=1, Llama-3-8B shapes 4096->4096/11008)",
+        "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": "decode step = 32 blocks x {4096->4096, 4096->11008} 1x16g8 matvec, bs=1, 64 distinct "
+                               "layers (own codes + codebook), 564 MB algorithmic bytes/step, hipGraph replay",
+                   "scheme": "1x16g8", "batch": 1, "layers_per_step": step.n, "algorithmic_bytes_per_step": step.bytes,
+                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+        "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
+        "roofline": roofline,
+    }
+
+    # ---- untimed breakdown (rank 0 prints; every rank runs the collectives inside)
+    if not args.no_detail:
+        detail = {}
+        reps = max(4, args.steps // 5)
+        for name, idxs in (("1x16g8 4096->4096", range(0, 2 * NBLOCKS, 2)), ("1x16g8 4096->11008", range(1, 2 * NBLOCKS, 2))):
+            sub = [layers[i] for i in idxs]
+            # cold = rotate through 32 distinct instances plus the other shape's traffic in between is NOT present here,
+            # so pad the rotation to > 512 MiB with extra instances of the same shape
+            extra = [Layer(sub[0].fin, sub[0].fout, 1, 16, 8, 5000 + rank * 10000 + i, dev)
+                     for i in range(max(0, int(600e6 / sub[0].bytes) + 1 - len(sub)))]
+            gp = GraphedPass(sub + extra, lib)
+            cold_us = gp.time_replays(reps) * 1e3 / gp.n
+            gw = GraphedPass([sub[0]] * 32, lib)
+            warm_us = gw.time_replays(reps) * 1e3 / gw.n
+            detail[name] = {"cold_us": cold_us, "cold_GBps": sub[0].bytes / cold_us * 1e-3,
+                            "cold_frac_of_8TBps": sub[0].bytes / cold_us * 1e-3 / HBM_PEAK_GBPS,
+                            "warm_us": warm_us, "warm_GBps_cache_resident": sub[0].bytes / warm_us * 1e-3,
+                            "instances": gp.n}
+            del gp, gw, extra
+        # true Llama-3-8B decode token: 32 x [q,o 4096->4096; k,v 4096->1024; gate,up 4096->14336; down 14336->4096]
+        shapes = [(4096, 4096), (4096, 1024), (4096, 1024), (4096, 4096), (4096, 14336), (4096, 14336), (14336, 4096)]
+        tok = [Layer(fi, fo, 1, 16, 8, 7000 + rank * 10000 + 7 * b + j, dev) for b in range(32) for j, (fi, fo) in enumerate(shapes)]
+        gp = GraphedPass(tok, lib)
+        ms = gp.time_replays(reps)
+        detail["llama3_8b_1x16g8_linear_stack"] = {"launches": gp.n, "ms_per_token": ms, "tokens_per_s": 1e3 / ms,
+                                                   "algorithmic_GBps": gp.bytes / ms * 1e-6}
+        del gp, tok
+        for sname, (K, nb, g) in {"2x8g8": (2, 8, 8), "8x8g32": (8, 8, 32)}.items():
+            shapes7 = [(4096, 4096)] * 4 + [(4096, 11008)] * 2 + [(11008, 4096)]
+            tok = [Layer(fi, fo, K, nb, g, 9000 + rank * 10000 + 7 * b + j, dev) for b in range(32) for j, (fi, fo) in enumerate(shapes7)]
+            gp = GraphedPass(tok, lib)
+            ms = gp.time_replays(reps)
+            detail[f"llama2_7b_{sname}_linear_stack"] = {"launches": gp.n, "ms_per_token": ms, "tokens_per_s": 1e3 / ms,
+                                                        "algorithmic_GBps": gp.bytes / ms * 1e-6,
+                                                        "frac_of_8TBps": gp.bytes / ms * 1e-6 / HBM_PEAK_GBPS}
+            del gp, tok
+        result["detail"] = detail
+        result["sharded_70b"] = sharded_70b(lib, dev, rank, world, args.steps)
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline()
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

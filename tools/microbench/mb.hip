@@ -1,0 +1,364 @@
+// Micro-benchmarks that bound the AQLM kernels on MI355X (run on the GPU box; results quoted in DESIGN.md):
+//   mb l2gather   random 16-B gathers from an L2-resident table (the 1x16 codebook access pattern)
+//   mb ldsgather  random ds_read_b128 from an LDS-resident table (the Kx8 codebook access pattern)
+//   mb stream     coalesced non-temporal streaming read (HBM ceiling for the code stream)
+//   mb gemv       libaqlm_hip.so kernels through the C ABI: cold (rotating layers > 512 MiB, hipGraph replay)
+//                 and warm, for tuning-knob variants
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/aqlm_hip.h"
+
+#define CK(x)                                                                          \
+  do {                                                                                 \
+    hipError_t e_ = (x);                                                               \
+    if (e_ != hipSuccess) {                                                            \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                         \
+    }                                                                                  \
+  } while (0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+// ---------------------------------------------------------------- fill kernels
+__global__ void fill_u32(uint32_t* p, size_t n, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = mix((uint32_t)i * 2654435761U + seed);
+}
+// fp16 values uniform in [-1, 1): two per dword
+__global__ void fill_half(uint32_t* p, size_t n, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t h = mix((uint32_t)i * 2654435761U + seed);
+    const _Float16 a = (_Float16)(((int)(h & 0x7ff) - 1024) / 1024.0f);
+    const _Float16 b = (_Float16)(((int)((h >> 11) & 0x7ff) - 1024) / 1024.0f);
+    p[i] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  }
+}
+__global__ void fill_one_half(uint16_t* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = 0x3c00;
+}
+
+// ---------------------------------------------------------------- L2 gather
+template <int AUX, int PIECES, bool FLAT>
+__global__ __launch_bounds__(256) void l2gather(const uint8_t* tab, uint32_t entry_mask, int iters, u32x4* out) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tab, 0, (entry_mask + 1) * 16 * PIECES, 0x00020000);
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t s = gid * 2654435761U;
+  u32x4 acc = {0, 0, 0, 0};
+  for (int it = 0; it < iters; it += 8) {
+    u32x4 v[8 * PIECES];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t off = (mix(s + it + k) & entry_mask) * (16 * PIECES);
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        if constexpr (FLAT) v[k * PIECES + p] = *reinterpret_cast<const u32x4*>(tab + off + p * 16);
+        else v[k * PIECES + p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + p * 16, 0, AUX);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8 * PIECES; ++k) acc ^= v[k];
+  }
+  out[gid] = acc;
+}
+
+// ---------------------------------------------------------------- LDS gather
+template <int MODE>  // 0 random, 1 conflict-free (slot = lane & 15), 2 all lanes same address
+__global__ __launch_bounds__(1024) void ldsgather(uint32_t entry_mask, int iters, u32x4* out) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 tab[];
+  for (uint32_t q = threadIdx.x; q <= entry_mask; q += blockDim.x) tab[q] = u32x4{q, q * 3, q * 5, q * 7};
+  __syncthreads();
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t s = gid * 2654435761U;
+  u32x4 acc = {0, 0, 0, 0};
+  for (int it = 0; it < iters; it += 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t idx = mix(s + it + k) & entry_mask;
+      if (MODE == 1) idx = (idx & ~15u) | (lane & 15u);
+      if (MODE == 2) idx = __builtin_amdgcn_readfirstlane(idx);
+      v[k] = tab[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc ^= v[k];
+  }
+  out[gid] = acc;
+}
+
+// ---------------------------------------------------------------- streaming read
+__global__ __launch_bounds__(256) void stream_read(const u32x4* p, size_t n, u32x4* out) {
+  u32x4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    u32x4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+    u32x4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+__global__ void empty_kernel() {}
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+  void start(hipStream_t s = 0) { CK(hipEventRecord(a, s)); }
+  float stop_ms(hipStream_t s = 0) {
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms;
+  }
+};
+
+static double clock_ghz() {
+  int khz = 0;
+  hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0);
+  return khz / 1e6;
+}
+
+template <int AUX, int PIECES, bool FLAT>
+static void run_l2(const char* name, const uint8_t* tab, size_t table_bytes, int blocks_per_cu, u32x4* out) {
+  const int blocks = 256 * blocks_per_cu, iters = 256;
+  const uint32_t mask = (uint32_t)(table_bytes / (16 * PIECES)) - 1;
+  Timer t;
+  hipLaunchKernelGGL((l2gather<AUX, PIECES, FLAT>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, out);
+  CK(hipDeviceSynchronize());
+  t.start();
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL((l2gather<AUX, PIECES, FLAT>), dim3(blocks), dim3(256), 0, 0, tab, mask, iters, out);
+  const float ms = t.stop_ms() / reps;
+  const double gathers = (double)blocks * 256 * iters;
+  printf("l2gather %-22s table %7zu KiB  %2d blk/CU  %8.1f Ggather/s  %6.2f lane-gathers/clk/CU  useful %6.2f TB/s\n", name,
+         table_bytes >> 10, blocks_per_cu, gathers / ms * 1e-6, gathers / (ms * 1e-3) / 256 / (clock_ghz() * 1e9),
+         gathers * 16 * PIECES / ms * 1e-9);
+}
+
+static void bench_l2() {
+  uint8_t* tab; u32x4* out;
+  const size_t maxb = 64u << 20;
+  CK(hipMalloc(&tab, maxb)); CK(hipMalloc(&out, (size_t)256 * 32 * 256 * 16));
+  hipLaunchKernelGGL(fill_u32, dim3(2048), dim3(256), 0, 0, (uint32_t*)tab, maxb / 4, 1u);
+  CK(hipDeviceSynchronize());
+  printf("# clock %.2f GHz\n", clock_ghz());
+  for (size_t kb : {16, 64, 256, 1024, 2048, 4096, 16384, 65536})
+    run_l2<0, 1, false>("buffer/default", tab, kb << 10, 8, out);
+  for (int bpc : {1, 2, 4, 8}) run_l2<0, 1, false>("buffer/default", tab, 1 << 20, bpc, out);
+  run_l2<2, 1, false>("buffer/nt", tab, 1 << 20, 8, out);
+  run_l2<16, 1, false>("buffer/sc1", tab, 1 << 20, 8, out);
+  run_l2<1, 1, false>("buffer/sc0", tab, 1 << 20, 8, out);
+  run_l2<17, 1, false>("buffer/sc0sc1", tab, 1 << 20, 8, out);
+  run_l2<0, 1, true>("flat/default", tab, 1 << 20, 8, out);
+  run_l2<0, 2, false>("buffer/default 32B", tab, 2 << 20, 8, out);
+  run_l2<0, 4, false>("buffer/default 64B", tab, 4 << 20, 8, out);
+  CK(hipFree(tab)); CK(hipFree(out));
+}
+
+template <int MODE>
+static void run_lds(const char* name, size_t table_bytes, int threads, u32x4* out) {
+  const int blocks = 256, iters = 1024;
+  const uint32_t mask = (uint32_t)(table_bytes / 16) - 1;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldsgather<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes));
+  Timer t;
+  hipLaunchKernelGGL((ldsgather<MODE>), dim3(blocks), dim3(threads), table_bytes, 0, mask, iters, out);
+  CK(hipDeviceSynchronize());
+  t.start();
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((ldsgather<MODE>), dim3(blocks), dim3(threads), table_bytes, 0, mask, iters, out);
+  const float ms = t.stop_ms() / reps;
+  const double gathers = (double)blocks * threads * iters;
+  printf("ldsgather %-14s table %4zu KiB  %4d thr/CU  %8.1f Ggather/s  %6.2f lane-gathers/clk/CU\n", name, table_bytes >> 10,
+         threads, gathers / ms * 1e-6, gathers / (ms * 1e-3) / 256 / (clock_ghz() * 1e9));
+}
+
+static void bench_lds() {
+  u32x4* out;
+  CK(hipMalloc(&out, (size_t)256 * 1024 * 16));
+  for (int thr : {256, 512, 1024}) {
+    run_lds<0>("random", 8 << 10, thr, out);
+    run_lds<1>("conflict-free", 8 << 10, thr, out);
+  }
+  run_lds<2>("broadcast", 8 << 10, 1024, out);
+  run_lds<0>("random", 4 << 10, 1024, out);
+  run_lds<0>("random", 128 << 10, 1024, out);
+  run_lds<1>("conflict-free", 128 << 10, 1024, out);
+  CK(hipFree(out));
+}
+
+static void bench_stream() {
+  const size_t bytes = (size_t)2 << 30;
+  u32x4 *buf, *out;
+  CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, (size_t)256 * 64 * 256 * 16));
+  hipLaunchKernelGGL(fill_u32, dim3(4096), dim3(256), 0, 0, (uint32_t*)buf, bytes / 4, 3u);
+  CK(hipDeviceSynchronize());
+  for (int bpc : {4, 8, 16, 32}) {
+    Timer t;
+    hipLaunchKernelGGL(stream_read, dim3(256 * bpc), dim3(256), 0, 0, buf, bytes / 16, out);
+    CK(hipDeviceSynchronize());
+    t.start();
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(stream_read, dim3(256 * bpc), dim3(256), 0, 0, buf, bytes / 16, out);
+    const float ms = t.stop_ms() / 3;
+    printf("stream nt-read 2 GiB  %2d blk/CU  %.2f TB/s\n", bpc, bytes / ms * 1e-9);
+  }
+  CK(hipFree(buf)); CK(hipFree(out));
+}
+
+// ---------------------------------------------------------------- library kernels through the C ABI
+struct Layer {
+  void *codes, *cb, *scales, *x, *y;
+};
+
+struct Scheme {
+  const char* name;
+  int K, nbits, g;
+};
+
+static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
+  size_t n = (size_t)out * (in / s.g) * s.K * (s.nbits <= 8 ? 1 : 2);
+  n += (size_t)s.K * ((size_t)1 << s.nbits) * s.g * 2;
+  n += (size_t)batch * in * 2 + (size_t)batch * out * 2 + (size_t)out * 2;
+  return n;
+}
+
+static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st) {
+  if (s.nbits == 16)
+    return aqlm_hip_gemv_1x16(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, batch, in, out, AQLM_HIP_F16, st);
+  return aqlm_hip_gemv_kx8(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.K, s.g, batch, in, out, AQLM_HIP_F16, st);
+}
+
+// returns mean microseconds per launch over `reps` graph replays of `layers.size()` launches
+static double time_graph(const Scheme& s, const std::vector<Layer>& layers, int in, int out, int batch, int reps) {
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  for (const auto& L : layers)
+    if (int rc = launch_layer(s, L, in, out, batch, st)) { fprintf(stderr, "launch failed rc=%d: %s\n", rc, aqlm_hip_last_error()); exit(3); }
+  CK(hipStreamSynchronize(st));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (const auto& L : layers) launch_layer(s, L, in, out, batch, st);
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(ge, st));
+  CK(hipStreamSynchronize(st));
+  Timer t;
+  t.start(st);
+  for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st));
+  const float ms = t.stop_ms(st);
+  CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(st));
+  return ms * 1e3 / ((double)reps * layers.size());
+}
+
+static double time_empty_graph(int n, int reps) {
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, st);
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+  Timer t; t.start(st);
+  for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st));
+  const float ms = t.stop_ms(st);
+  CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(st));
+  return ms * 1e3 / ((double)reps * n);
+}
+
+static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batch, int n) {
+  std::vector<Layer> v(n);
+  const size_t code_bytes = (size_t)out * (in / s.g) * s.K * (s.nbits <= 8 ? 1 : 2);
+  const size_t cb_bytes = (size_t)s.K * ((size_t)1 << s.nbits) * s.g * 2;
+  for (int i = 0; i < n; ++i) {
+    Layer& L = v[i];
+    CK(hipMalloc(&L.codes, code_bytes)); CK(hipMalloc(&L.cb, cb_bytes)); CK(hipMalloc(&L.scales, (size_t)out * 2));
+    CK(hipMalloc(&L.x, (size_t)batch * in * 2)); CK(hipMalloc(&L.y, (size_t)batch * out * 2));
+    hipLaunchKernelGGL(fill_u32, dim3(1024), dim3(256), 0, 0, (uint32_t*)L.codes, code_bytes / 4, 17u * i + 1);
+    hipLaunchKernelGGL(fill_half, dim3(256), dim3(256), 0, 0, (uint32_t*)L.cb, cb_bytes / 4, 31u * i + 2);
+    hipLaunchKernelGGL(fill_half, dim3(64), dim3(256), 0, 0, (uint32_t*)L.x, (size_t)batch * in / 2, 7u * i + 3);
+    hipLaunchKernelGGL(fill_one_half, dim3(64), dim3(256), 0, 0, (uint16_t*)L.scales, (size_t)out);
+  }
+  CK(hipDeviceSynchronize());
+  return v;
+}
+
+static void free_layers(std::vector<Layer>& v) {
+  for (auto& L : v) { hipFree(L.codes); hipFree(L.cb); hipFree(L.scales); hipFree(L.x); hipFree(L.y); }
+}
+
+static void bench_gemv(int argc, char** argv) {
+  const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
+  struct Case { Scheme s; int in, out; };
+  std::vector<Case> cases = {{S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
+                             {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
+                             {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}};
+  const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+  const double gap = time_empty_graph(128, 20);
+  printf("# empty-kernel graph: %.2f us per launch (launch gap floor)\n", gap);
+  printf("%-9s %6s %6s %2s %-26s %9s %9s %8s %8s\n", "scheme", "in", "out", "B", "variant", "cold_us", "warm_us", "coldGB/s", "%8TB/s");
+  for (const auto& c : cases) {
+    const size_t ab1 = algo_bytes(c.in, c.out, c.s, 1);
+    int n = (int)((600u << 20) / ab1) + 1;
+    if (n > 160) n = 160;
+    if (n < 8) n = 8;
+    auto layers = make_layers(c.s, c.in, c.out, 8, n);
+    std::vector<Layer> one(layers.begin(), layers.begin() + 1);
+    std::vector<Layer> warm(16, one[0]);
+    struct Var { const char* name; const char* key; int val; };
+    std::vector<std::vector<Var>> variants;
+    variants.push_back({});
+    if (c.s.nbits == 16 && !quick) {
+      variants.push_back({{"aux=nt", "gemv1x16_aux", 2}});
+      variants.push_back({{"aux=sc1", "gemv1x16_aux", 16}});
+      variants.push_back({{"prefetch_cb", "gemv1x16_prefetch_cb", 1}});
+      variants.push_back({{"rpw=2", "gemv_rows_per_wave", 2}});
+      variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
+      variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
+      variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
+    } else if (!quick) {
+      variants.push_back({{"rpw=2", "gemv_rows_per_wave", 2}});
+      variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
+      variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
+    }
+    for (const auto& var : variants) {
+      std::string vn = var.empty() ? "default" : "";
+      for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
+      for (int batch : {1, 2, 4, 8}) {
+        if (batch > 1 && !var.empty()) continue;
+        const size_t ab = algo_bytes(c.in, c.out, c.s, batch);
+        const double cold = time_graph(c.s, layers, c.in, c.out, batch, 4);
+        const double w = time_graph(c.s, warm, c.in, c.out, batch, 20);
+        printf("%-9s %6d %6d %2d %-26s %9.2f %9.2f %8.0f %8.1f\n", c.s.name, c.in, c.out, batch, vn.c_str(), cold, w, ab / cold * 1e-3,
+               ab / cold * 1e-3 / 80.0);
+        fflush(stdout);
+      }
+      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, 0);
+    }
+    free_layers(layers);
+  }
+}
+
+int main(int argc, char** argv) {
+  const char* what = argc > 1 ? argv[1] : "all";
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  printf("# device %s  CUs %d  clock %.0f MHz  L2 %d KiB\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1e3, prop.l2CacheSize >> 10);
+  if (!strcmp(what, "l2gather") || !strcmp(what, "all")) bench_l2();
+  if (!strcmp(what, "ldsgather") || !strcmp(what, "all")) bench_lds();
+  if (!strcmp(what, "stream") || !strcmp(what, "all")) bench_stream();
+  if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
+  return 0;
+}
