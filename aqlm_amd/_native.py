@@ -17,6 +17,7 @@ F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
 MAX_GEMV_BATCH = 8
 OP_GEMM_1X16_MFMA = 1
+OP_GEMV_1X16_LDS = 2
 
 _vp, _ci, _cl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 
@@ -26,6 +27,7 @@ SIGNATURES = {
     "aqlm_hip_last_error": (ctypes.c_char_p, []),
     "aqlm_hip_gemv_1x16": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
+    "aqlm_hip_gemv_1x16_lds": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_dequant_1x16": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_dequant_kx8": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]),

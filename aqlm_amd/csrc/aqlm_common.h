@@ -94,6 +94,7 @@ struct Tuning {
   int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
   int gemv1x16_xreg = 0;         // reserved
   int kx8_replicas = 1;          // reserved
+  int lds_variant = 0;           // experiment switch of the slice-scan kernel
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
 };
 Tuning& tuning();

@@ -104,10 +104,43 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
     return y.reshape(input.shape[:-1] + (out_features,))
 
 
+# out_features at and above which the slice-scan (LDS-resident codebook) kernel replaces the direct L2-gather
+# kernel for a single-row 1x16 g8 matvec; 0 disables it.  Set from measurements.
+LDS_GEMV_MIN_OUT = 0
+
+
+def _gemv_1x16_lds(input, codes, codebooks, scales, bias):
+    """Single-row 1x16 g8 matvec through aqlm_hip_gemv_1x16_lds (codebook slices in LDS + fp32 partial workspace)."""
+    dt = _dtype_id(input)
+    out_features, in_features = codes.shape[0], codes.shape[1] * 8
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _flat_rows(input)
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
+    ws = torch.empty((8 * out_features,), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.aqlm_hip_gemv_1x16_lds(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                         x.data_ptr(), y.data_ptr(), out_features, in_features, 8, dt,
+                                         ws.data_ptr(), ws.numel() * 4, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm gemv_1x16_lds")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
+def _lds_gemv_applicable(input, codes, codebooks):
+    return (codebooks.shape[3] == 8 and input.numel() == input.shape[-1] and input.shape[-1] % 64 == 0
+            and input.shape[-1] <= 14336 and input.dtype == codebooks.dtype)
+
+
 def code1x16_matmat(input, codes, codebooks, scales, bias=None):
     """aqlm::code1x16_matmat (cuda_kernel.py:13-22, cuda_kernel.cpp:148-182)."""
     if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536:
         raise NotImplementedError(f"code1x16_matmat needs codebooks [1, 65536, 1, g], got {tuple(codebooks.shape)}")
+    if LDS_GEMV_MIN_OUT and codes.shape[0] >= LDS_GEMV_MIN_OUT and _lds_gemv_applicable(input, codes, codebooks):
+        return _gemv_1x16_lds(input, codes, codebooks, scales, bias)
     return _gemv(input, codes, codebooks, scales, bias, "1x16")
 
 

@@ -115,12 +115,25 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
                             int in_group_size, long x_row_stride, long y_row_stride, int dtype, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/*
+ * Slice-scan variant of the 1x16 g8 matvec (batch 1): the codebook lives in LDS as 8 per-CU slices, every CU scans the
+ * code rows of its row-group and gathers only the codes of its slice from LDS; fp32 partials go through `workspace`
+ * (aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_LDS, 1, out, in) bytes) and a finalize kernel applies scale + bias.
+ * Same result contract as aqlm_hip_gemv_1x16 (which it replaces for large layers; same reference lines).  Returns
+ * AQLM_HIP_E_UNSUPPORTED for shapes it does not cover (in_group_size != 8, in_features % 64 != 0 or > 14336) --
+ * callers then use aqlm_hip_gemv_1x16.
+ */
+int aqlm_hip_gemv_1x16_lds(const void* codes_i16, const void* codebook, const void* scales, const void* bias,
+                           const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
+#define AQLM_HIP_OP_GEMV_1X16_LDS 2
 size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);
 
 /*
  * Tuning / experiment knobs (process-wide, not part of the reference surface; defaults are the shipped
- * configuration).  Unknown keys return AQLM_HIP_E_INVALID.  Keys: see aqlm_amd/csrc/tuning.h.
+ * configuration).  Unknown keys return AQLM_HIP_E_INVALID.  Keys: struct Tuning in aqlm_amd/csrc/aqlm_common.h.
  */
 int aqlm_hip_set_tuning(const char* key, int value);
 int aqlm_hip_get_tuning(const char* key, int* value);

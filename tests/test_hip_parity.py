@@ -307,3 +307,38 @@ def test_raw_c_abi_strided_rows(hk):
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
     check_close(ybuf[:, :128].float().cpu().numpy(), y64, torch.float16, "raw abi")
     assert (ybuf[:, 128:] == 7.0).all()
+
+
+# ------------------------------------------------------------------ slice-scan (LDS-resident codebook) 1x16 kernel
+@pytest.mark.parametrize("fin,fout,dt,bias", [
+    (4096, 4096, "float16", True),
+    (4096, 1000, "float16", False),     # ragged groups (rows_per_group not dividing out)
+    (4096, 37, "bfloat16", True),       # fewer rows than row-groups
+    (8192, 512, "float16", True),       # 2 iterations per row
+    (11008, 640, "float16", True),      # 3 iterations, ragged last one
+    (14336, 1024, "bfloat16", True),    # 4 iterations
+    (64, 256, "float16", True),         # one unit per row
+])
+def test_gemv_1x16_lds_variant(hk, fin, fout, dt, bias):
+    dtype = tdtype(dt)
+    L = orc.make_layer(900 + fin + fout, fin, fout, 1, 16, 8, batch=1, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = hk._gemv_1x16_lds(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, f"lds 1x16g8 {fin}->{fout}")
+    # all eight code slices must be exercised: force every code of row 0 into one slice at a time
+    for s in (0, 3, 7):
+        cu = L["codes_unsigned"].copy()
+        cu[0, :, 0] = (cu[0, :, 0] & 0x1FFF) | (s << 13)
+        L2 = dict(L, codes=orc.pack_int_data(cu, 16), codes_unsigned=cu)
+        T2 = to_dev(L2, dtype)
+        y2 = hk._gemv_1x16_lds(T2["x"], T2["codes"], T2["codebooks"], T2["scales"], T2["bias"])
+        y64b = orc.dequantize_gemm(L2["x"], L2["codes"], L2["codebooks"], L2["scales"], L2["bias"])
+        check_close(y2.float().cpu().numpy(), y64b, dtype, f"lds slice {s}")
+    # zero input -> bias exactly; and agreement with the direct kernel to fp16 rounding
+    if bias:
+        yz = hk._gemv_1x16_lds(torch.zeros_like(T["x"]), T["codes"], T["codebooks"], T["scales"], T["bias"])
+        assert torch.equal(yz[0], T["bias"])
+    yd = hk._gemv(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "1x16")
+    check_close(y.float().cpu().numpy(), yd.float().cpu().numpy().astype(np.float64), dtype, "lds vs direct")

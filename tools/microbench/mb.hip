@@ -226,7 +226,10 @@ struct Layer {
 struct Scheme {
   const char* name;
   int K, nbits, g;
+  bool lds = false;  // route 1x16 through aqlm_hip_gemv_1x16_lds
 };
+static void* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
 
 static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
   size_t n = (size_t)out * (in / s.g) * s.K * (s.nbits <= 8 ? 1 : 2);
@@ -236,6 +239,8 @@ static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
 }
 
 static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st) {
+  if (s.nbits == 16 && s.lds)
+    return aqlm_hip_gemv_1x16_lds(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16)
     return aqlm_hip_gemv_1x16(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, batch, in, out, AQLM_HIP_F16, st);
   return aqlm_hip_gemv_kx8(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.K, s.g, batch, in, out, AQLM_HIP_F16, st);
@@ -300,9 +305,13 @@ static void free_layers(std::vector<Layer>& v) {
 }
 
 static void bench_gemv(int argc, char** argv) {
+  g_ws_bytes = (size_t)8 * 32768 * 4;
+  CK(hipMalloc(&g_ws, g_ws_bytes));
+  const Scheme S1x16L{"1x16g8L", 1, 16, 8, true};
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
-  std::vector<Case> cases = {{S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
+  std::vector<Case> cases = {{S1x16L, 4096, 4096}, {S1x16L, 4096, 11008}, {S1x16L, 4096, 14336}, {S1x16L, 14336, 4096}, {S1x16L, 4096, 1024}, {S1x16L, 8192, 28672},
+                             {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
                              {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
                              {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}};
   const bool quick = argc > 2 && !strcmp(argv[2], "quick");
@@ -320,7 +329,7 @@ static void bench_gemv(int argc, char** argv) {
     struct Var { const char* name; const char* key; int val; };
     std::vector<std::vector<Var>> variants;
     variants.push_back({});
-    if (c.s.nbits == 16 && !quick) {
+    if (c.s.nbits == 16 && !quick && !c.s.lds) {
       variants.push_back({{"aux=nt", "gemv1x16_aux", 2}});
       variants.push_back({{"aux=sc1", "gemv1x16_aux", 16}});
       variants.push_back({{"prefetch_cb", "gemv1x16_prefetch_cb", 1}});
@@ -328,7 +337,11 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
-    } else if (!quick) {
+    } else if (c.s.lds) {
+      variants.push_back({{"var=1(nosched)", "lds_variant", 1}});
+      variants.push_back({{"var=2(direct store)", "lds_variant", 2}});
+      variants.push_back({{"var=3", "lds_variant", 3}});
+    } else if (!quick && !c.s.lds) {
       variants.push_back({{"rpw=2", "gemv_rows_per_wave", 2}});
       variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
@@ -337,7 +350,7 @@ static void bench_gemv(int argc, char** argv) {
       std::string vn = var.empty() ? "default" : "";
       for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
       for (int batch : {1, 2, 4, 8}) {
-        if (batch > 1 && !var.empty()) continue;
+        if (batch > 1 && (!var.empty() || c.s.lds || quick)) continue;
         const size_t ab = algo_bytes(c.in, c.out, c.s, batch);
         const double cold = time_graph(c.s, layers, c.in, c.out, batch, 4);
         const double w = time_graph(c.s, warm, c.in, c.out, batch, 20);
