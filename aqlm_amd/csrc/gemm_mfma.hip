@@ -245,7 +245,7 @@ using namespace aqlm;
 
 extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features) {
   if (batch <= 0 || out_features <= 0 || in_features <= 0) return 0;
-  if (op == AQLM_HIP_OP_GEMV_1X16_LDS) return (size_t)8 * out_features * sizeof(float);
+  if (op == AQLM_HIP_OP_GEMV_1X16_LDS || op == AQLM_HIP_OP_GEMV_1X16_PACKED) return (size_t)8 * out_features * sizeof(float);
   if (op != AQLM_HIP_OP_GEMM_1X16_MFMA) return 0;
   const GemmPlan g = plan_gemm(batch, out_features, in_features);
   return (size_t)g.ksplit * out_features * g.Bpad * sizeof(float);

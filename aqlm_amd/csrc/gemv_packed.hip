@@ -1,0 +1,432 @@
+// 1x16 g8 matvec on slice-bucketed ("prepacked") codes, gfx950.
+//
+// Why a load-time repack: on MI355X a random 16-B codebook gather that hits L2 costs a whole 128-B line of the CU's
+// L1-fill path (0.43 lane-gathers/clk/CU measured, profiles/r01_call1_mb_l2gather.log), which pins the direct kernel
+// (gemv.hip) at ~5.5 % of the HBM roofline.  LDS gathers are >10x cheaper but only 160 KiB fit per CU, so the
+// codebook has to be cut into 8 slices of 8192 entries with one slice per CU -- and then every CU must find "its"
+// codes.  Scanning the canonical [out][in/8] code matrix for them (gemv_lds.hip) spends ~95 vector instructions per
+// 512 codes to use 64.  Bucketing the codes by slice ONCE, when the layer is loaded, removes the scan.  (The
+// reference also re-lays codes out at load time for its CPU kernel, inference.py:78-83.)
+//
+// Packed format v2 (built by aqlm_hip_prepack_1x16, checked bit-for-bit against a numpy model in tests/):
+//   rows are split into NG = 32 row-groups of RG rows; codes into S = 8 slices by (code >> 13);
+//   stream (g, s) = for each row of group g, in order: that row's codes of slice s in ascending input-group order j,
+//   each as a 24-bit entry  j << 13 | (code & 0x1fff), stored in two planes: lo16[] (low 16 bits) and hi8[] (j >> 3);
+//   every (row, slice) bucket is padded to a multiple of 4 entries with null entries (j = in_groups, whose x is a
+//   zero vector in LDS), so a lane fetches 4 consecutive entries with one aligned 8-B + one aligned 4-B load;
+//   rowoff[(g*S + s)*(RG+1) + r] = global index of the first entry of row r of stream (g, s); slot RG closes the
+//   stream.  ~3.07 bytes per code + 4 bytes per (row, slice): 1.55x the canonical 2 bytes per code.
+//
+// Kernel: grid = 256 workgroups = 32 groups x 8 slices (the 8 slices of a group share bid % 8, observed = the XCD,
+// for speed only).  Workgroup (g, s): slice s of the codebook and x go to LDS; each quarter-wave (16 lanes) owns one
+// row of the group at a time; a lane takes 4 consecutive entries of that row's bucket per step (the typical 64-entry
+// bucket is one step): per entry 2 ds_read_b128 (codebook entry, x[j]) + 4 v_dot2c.  Entry loads run PD rows ahead.  fp32 partials [slice][row] -> workspace -> finalize kernel
+// (adds the 8 slices, scale + bias, one rounding).  Every lane does useful work (no scan, no 8x re-read of codes).
+#include <algorithm>
+
+#include "aqlm_common.h"
+
+namespace aqlm {
+
+constexpr int PK_S = 8;        // slices
+constexpr int PK_NG = 32;      // row groups  (PK_S * PK_NG == 256 workgroups == CUs)
+constexpr int PK_SLICE_ENTRIES = 8192;
+constexpr int PK_PAD = 128;    // entries of slack behind the planes (prefetch may run past the end)
+
+struct PackedLayout {
+  int M, in_groups, RG;
+  size_t n_rowoff;   // NG * S * (RG + 1)
+  size_t entries;    // capacity: M * in_groups real entries + up to 3 null entries per (row, slice)
+  size_t off_rowoff, off_lo16, off_hi8, total;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static bool packed_layout(int out_features, int in_features, int g, PackedLayout& L) {
+  if (g != 8 || out_features <= 0 || in_features <= 0 || in_features % 64 != 0 || in_features > 16320) return false;
+  L.M = out_features;
+  L.in_groups = in_features / 8;
+  L.RG = ((out_features + PK_NG - 1) / PK_NG + 3) / 4 * 4;
+  L.n_rowoff = (size_t)PK_NG * PK_S * (L.RG + 1);
+  L.entries = (size_t)out_features * L.in_groups + (size_t)3 * PK_S * out_features;
+  if (L.entries + PK_PAD >= ((size_t)1 << 31)) return false;
+  L.off_rowoff = 256;  // header
+  L.off_lo16 = align_up(L.off_rowoff + L.n_rowoff * 4, 256);
+  L.off_hi8 = align_up(L.off_lo16 + (L.entries + PK_PAD) * 2, 256);
+  L.total = align_up(L.off_hi8 + (L.entries + PK_PAD), 256);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ prepack
+// K1: per (row, slice) counts -> rowoff[] (as counts).  One wave per row.
+__global__ __launch_bounds__(256) void prepack_count_kernel(const uint16_t* codes, uint32_t* rowoff, int M, int in_groups,
+                                                            int RG) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  uint32_t cnt[PK_S];
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s) cnt[s] = 0;
+  for (int j = lane; j < in_groups; j += 64) {
+    const uint32_t sl = codes[(size_t)row * in_groups + j] >> 13;
+#pragma unroll
+    for (int s = 0; s < PK_S; ++s) cnt[s] += (sl == (uint32_t)s);
+  }
+  const int g = row / RG, r = row - g * RG;
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s) {
+    uint32_t v = cnt[s];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    if (lane == 0) rowoff[((size_t)g * PK_S + s) * (RG + 1) + r] = (v + 3u) & ~3u;  // padded to 4 entries
+  }
+}
+
+// K2: in-place exclusive prefix sum over the flat rowoff array (single block; load-time code, not a hot path).
+__global__ __launch_bounds__(1024) void prepack_scan_kernel(uint32_t* rowoff, size_t n) {
+  __shared__ uint32_t sums[1024];
+  const int t = threadIdx.x;
+  const size_t chunk = (n + 1023) / 1024;
+  const size_t lo = std::min(n, (size_t)t * chunk), hi = std::min(n, lo + chunk);
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; ++i) s += rowoff[i];
+  sums[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const uint32_t v = sums[i];
+      sums[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  uint32_t run = sums[t];
+  for (size_t i = lo; i < hi; ++i) {
+    const uint32_t v = rowoff[i];
+    rowoff[i] = run;
+    run += v;
+  }
+}
+
+// K3: scatter the entries.  One wave per row; ascending j within each (row, slice) bucket.
+__global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* codes, const uint32_t* rowoff, uint16_t* lo16,
+                                                              uint8_t* hi8, int M, int in_groups, int RG) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int g = row / RG, r = row - g * RG;
+  uint32_t base[PK_S];
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s) base[s] = rowoff[((size_t)g * PK_S + s) * (RG + 1) + r];
+  for (int j0 = 0; j0 < in_groups; j0 += 64) {
+    const int j = j0 + lane;
+    const bool ok = j < in_groups;
+    const uint32_t code = ok ? codes[(size_t)row * in_groups + j] : 0u;
+    const uint32_t sl = ok ? (code >> 13) : 0xffffffffu;
+#pragma unroll
+    for (int s = 0; s < PK_S; ++s) {
+      const bool mine = sl == (uint32_t)s;
+      const unsigned long long mask = __ballot(mine);
+      const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
+      if (mine) {
+        const uint32_t e = ((uint32_t)j << 13) | (code & 0x1fffu);
+        lo16[base[s] + before] = (uint16_t)(e & 0xffffu);
+        hi8[base[s] + before] = (uint8_t)(e >> 16);
+      }
+      base[s] += __popcll(mask);
+    }
+  }
+  // pad every bucket to a multiple of 4 entries with null entries: j = in_groups (x[in_groups] is zero in LDS)
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s) {
+    const uint32_t pad = (0u - base[s]) & 3u;  // bucket starts are multiples of 4
+    if ((uint32_t)lane < pad) {
+      const uint32_t e = (uint32_t)in_groups << 13;
+      lo16[base[s] + lane] = (uint16_t)(e & 0xffffu);
+      hi8[base[s] + lane] = (uint8_t)(e >> 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gemv
+struct PackedGemvParams {
+  const uint32_t* rowoff;
+  const uint16_t* lo16;
+  const uint8_t* hi8;
+  const uint8_t* codebook;
+  const uint16_t* x;
+  float* partial;  // [S][M]
+  int M, in_groups, RG;
+  uint32_t lo16_bytes, hi8_bytes;
+};
+
+// one 24-bit entry -> fp32 contribution; lo = dword holding the entry's 16 low bits at bit LOSH, hi = dword holding
+// its high byte at bit HISH
+template <class T, int LOSH, int HISH>
+__device__ __forceinline__ float packed_entry(uint32_t lo, uint32_t hi, const unsigned char* cb_bytes,
+                                              const unsigned char* x_bytes, float acc) {
+  const uint32_t cb_off = (LOSH == 0) ? ((lo << 4) & 0x1FFF0u) : ((lo >> 12) & 0x1FFF0u);          // (code & 0x1fff) * 16
+  const uint32_t jhi = (HISH >= 7) ? ((hi >> (HISH - 7)) & 0x7F80u) : ((hi << (7 - HISH)) & 0x7F80u);  // (j >> 3) * 128
+  const uint32_t x_off = ((lo >> (LOSH + 9)) & 0x70u) | jhi;                                           // j * 16
+  const u32x4 e = *reinterpret_cast<const u32x4*>(cb_bytes + cb_off);
+  const u32x4 xv = *reinterpret_cast<const u32x4*>(x_bytes + x_off);
+  return dot8<T>(e, xv, acc);
+}
+
+template <class T, int NWAVES, int PD, int VAR>
+__global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
+  constexpr int NT = NWAVES * 64;
+  constexpr int STRIDE = NWAVES * 4;  // rows between two consecutive rows of one quarter-wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* const cbl = reinterpret_cast<u32x4*>(smem_raw);   // [8192] codebook slice
+  u32x4* const xl = cbl + PK_SLICE_ENTRIES;                  // [in_groups + 1] x, 16 B per input group, then zeros
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, quarter = lane >> 4;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int slice = local & 7;
+  const int group = xcd * 4 + (local >> 3);
+  const int row_begin = group * p.RG;
+  int nrows = p.M - row_begin;
+  nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
+  const uint32_t* const ro = p.rowoff + ((size_t)group * PK_S + slice) * (p.RG + 1);
+
+  __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.lo16, 0, p.lo16_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.hi8, 0, p.hi8_bytes, 0x00020000);
+
+  // Software pipeline over this quarter-wave's rows r0, r0+STRIDE, ...: bucket bounds run 2*PD rows ahead (ring of
+  // 2*PD slots), the first two 4-entry chunks of each lane PD rows ahead (ring of PD slots).  Rings are indexed with
+  // compile-time slots only (main loop unrolled 2*PD times) and never copied, so no in-flight register is touched
+  // before its row is consumed.  Everything below is issued before the LDS fill (HBM latency overlaps it).
+  constexpr int NB2 = 2 * PD;
+  const int r0 = wave * 4 + quarter;
+  uint32_t bst[NB2], ben[NB2];
+  u32x2 lo_q[PD], lo_q2[PD];            // chunk l16 and chunk l16 + 16 (buckets of 65..128 entries) of each row
+  uint32_t hi_q[PD], hi_q2[PD];
+  // Every load below is UNCONDITIONAL (rows past the end are clamped to the closing rowoff slot = an empty bucket;
+  // chunks past a bucket's end read neighbouring entries or, past the planes, zeros from the bounds-checked buffer
+  // descriptor, and are never consumed).  Loads inside divergent branches make hipcc's s_waitcnt bookkeeping fall
+  // back to vmcnt(0) at every use, which serialises the whole prefetch pipeline (measured: 0.85 us per step).
+  auto bounds = [&](int r, uint32_t& st, uint32_t& en) {
+    const int a = r < p.RG ? r : p.RG, b = r + 1 < p.RG ? r + 1 : p.RG;
+    st = ro[a];
+    en = ro[b];
+  };
+  auto fetch = [&](uint32_t st, int chunk, u32x2& lo, uint32_t& hi) {
+    const uint32_t idx = st + 4u * (uint32_t)chunk;
+    lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_lo, idx * 2, 0, 0));
+    hi = __builtin_amdgcn_raw_buffer_load_b32(rs_hi, idx, 0, 0);
+  };
+#pragma unroll
+  for (int k = 0; k < NB2; ++k) bounds(r0 + k * STRIDE, bst[k], ben[k]);
+#pragma unroll
+  for (int k = 0; k < PD; ++k) {
+    fetch(bst[k], l16, lo_q[k], hi_q[k]);
+    fetch(bst[k], l16 + 16, lo_q2[k], hi_q2[k]);
+  }
+
+  for (int q = tid; q < p.in_groups; q += NT) xl[q] = *reinterpret_cast<const u32x4*>(p.x + (size_t)q * 8);
+  if (tid == 0) xl[p.in_groups] = u32x4{0u, 0u, 0u, 0u};
+  if constexpr (!(VAR & 4)) {
+    // all loads of the 128 KiB slice are issued before the first LDS write (one memory round trip, not eight)
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebook) + (size_t)slice * PK_SLICE_ENTRIES;
+    constexpr int PER = PK_SLICE_ENTRIES / NT;
+    static_assert(PK_SLICE_ENTRIES % NT == 0, "slice must split evenly over the workgroup");
+    u32x4 stage[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) stage[k] = src[tid + k * NT];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) cbl[tid + k * NT] = stage[k];
+  }
+  __syncthreads();
+
+  const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
+  const unsigned char* const x_bytes = reinterpret_cast<const unsigned char*>(xl);
+  auto consume = [&](const u32x2& lo, uint32_t hi, float acc) -> float {
+    if constexpr (VAR & 1) {  // ablation: no LDS gathers
+      const u32x4 fake = {lo.x, lo.y, hi, lo.x ^ hi};
+      return dot8<T>(fake, fake, acc);
+    }
+    acc = packed_entry<T, 0, 0>(lo.x, hi, cb_bytes, x_bytes, acc);
+    acc = packed_entry<T, 16, 8>(lo.x, hi, cb_bytes, x_bytes, acc);
+    acc = packed_entry<T, 0, 16>(lo.y, hi, cb_bytes, x_bytes, acc);
+    acc = packed_entry<T, 16, 24>(lo.y, hi, cb_bytes, x_bytes, acc);
+    return acc;
+  };
+
+  int r = r0;
+  while (__any(r < nrows)) {
+#pragma unroll
+    for (int s6 = 0; s6 < NB2; ++s6) {  // no early exit: a single back-edge keeps every in-flight load in place
+      constexpr int dummy = 0; (void)dummy;
+      const int es = s6 % PD;
+      const uint32_t st = bst[s6], en = ben[s6];
+      const u32x2 lo = lo_q[es], lo2 = lo_q2[es];
+      const uint32_t hi = hi_q[es], hi2 = hi_q2[es];
+      // refill: entries of row r + PD*STRIDE (its bounds sit PD slots further in the ring), bounds of row r + 2*PD*STRIDE
+      fetch(bst[(s6 + PD) % NB2], l16, lo_q[es], hi_q[es]);
+      fetch(bst[(s6 + PD) % NB2], l16 + 16, lo_q2[es], hi_q2[es]);
+      bounds(r + NB2 * STRIDE, bst[s6], ben[s6]);
+
+      const int nchunks = (int)((en - st) >> 2);
+      float acc = 0.f;
+      if (l16 < nchunks) acc = consume(lo, hi, acc);
+      if (l16 + 16 < nchunks) acc = consume(lo2, hi2, acc);
+      for (int c = l16 + 32; __any(c < nchunks); c += 16) {  // buckets longer than 128 entries (rare): blocking loads
+        u32x2 lo3; uint32_t hi3;
+        fetch(st, c, lo3, hi3);
+        if (c < nchunks) acc = consume(lo3, hi3, acc);
+      }
+      if constexpr (!(VAR & 2)) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+      }
+      if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + r] = acc;
+      r += STRIDE;
+    }
+  }
+}
+
+struct PackedFinalizeParams {
+  const float* partial;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  int M;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const PackedFinalizeParams p) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.M) return;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < PK_S; ++k) s += p.partial[(size_t)k * p.M + row];
+  const float scale = T::to_float(p.scales[row]);
+  const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+  p.y[row] = T::from_float(s * scale + bias);
+}
+
+}  // namespace aqlm
+
+using namespace aqlm;
+
+extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size) {
+  PackedLayout L;
+  return packed_layout(out_features, in_features, in_group_size, L) ? L.total : 0;
+}
+
+extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
+                                     void* packed, size_t packed_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PackedLayout L;
+  if (!codes || !packed) {
+    set_last_error("aqlm_hip_prepack_1x16: null pointer argument");
+    return AQLM_HIP_E_INVALID;
+  }
+  if (!packed_layout(out_features, in_features, in_group_size, L)) {
+    set_last_error("aqlm_hip_prepack_1x16: unsupported shape (needs g=8, in %% 64 == 0, in <= 16320; got g=%d in=%d)",
+                   in_group_size, in_features);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (packed_bytes < L.total || !aligned16(packed)) {
+    set_last_error("aqlm_hip_prepack_1x16: packed buffer needs %zu bytes (16-B aligned), got %zu", L.total, packed_bytes);
+    return AQLM_HIP_E_INVALID;
+  }
+  uint8_t* base = (uint8_t*)packed;
+  // header (informational; the kernels take the layout from the shapes)
+  const uint32_t hdr[16] = {0x31505141u, 2u, (uint32_t)L.M, (uint32_t)L.in_groups, 8u, (uint32_t)PK_S, (uint32_t)PK_NG,
+                            (uint32_t)L.RG, (uint32_t)L.entries, (uint32_t)L.off_rowoff, (uint32_t)L.off_lo16,
+                            (uint32_t)L.off_hi8, (uint32_t)(L.total & 0xffffffffu), (uint32_t)(L.total >> 32), 0u, 0u};
+  if (int e = check_hip(hipMemsetAsync(base, 0, L.off_lo16, stream), "prepack memset")) return e;
+  if (int e = check_hip(hipMemcpyAsync(base, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream), "prepack header")) return e;
+  if (int e = check_hip(hipStreamSynchronize(stream), "prepack header sync")) return e;  // hdr is on the stack
+  uint32_t* rowoff = (uint32_t*)(base + L.off_rowoff);
+  uint16_t* lo16 = (uint16_t*)(base + L.off_lo16);
+  uint8_t* hi8 = base + L.off_hi8;
+  if (int e = check_hip(hipMemsetAsync(lo16, 0, L.total - L.off_lo16, stream), "prepack memset planes")) return e;
+  const int blocks = (L.M + 3) / 4;
+  hipLaunchKernelGGL(prepack_count_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, L.M,
+                     L.in_groups, L.RG);
+  hipLaunchKernelGGL(prepack_scan_kernel, dim3(1), dim3(1024), 0, stream, rowoff, L.n_rowoff);
+  hipLaunchKernelGGL(prepack_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, lo16,
+                     hi8, L.M, L.in_groups, L.RG);
+  return check_hip(hipGetLastError(), "prepack launch");
+}
+
+extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codebook, const void* scales, const void* bias,
+                                         const void* x, void* y, int out_features, int in_features, int in_group_size,
+                                         int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!packed || !codebook || !scales || !x || !y) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: null pointer argument");
+    return AQLM_HIP_E_INVALID;
+  }
+  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)", dtype);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  PackedLayout L;
+  if (!packed_layout(out_features, in_features, in_group_size, L) || !aligned16(packed) || !aligned16(codebook) ||
+      !aligned16(x)) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: unsupported shape or misaligned buffer (g=%d in=%d)", in_group_size,
+                   in_features);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  const size_t need = (size_t)PK_S * out_features * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return AQLM_HIP_E_INVALID;
+  }
+  const uint8_t* base = (const uint8_t*)packed;
+  PackedGemvParams p{};
+  p.rowoff = (const uint32_t*)(base + L.off_rowoff);
+  p.lo16 = (const uint16_t*)(base + L.off_lo16);
+  p.hi8 = base + L.off_hi8;
+  p.codebook = (const uint8_t*)codebook;
+  p.x = (const uint16_t*)x;
+  p.partial = (float*)workspace;
+  p.M = L.M;
+  p.in_groups = L.in_groups;
+  p.RG = L.RG;
+  p.lo16_bytes = (uint32_t)((L.entries + PK_PAD) * 2);
+  p.hi8_bytes = (uint32_t)(L.entries + PK_PAD);
+  const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 1) * 16;
+  constexpr int NW = 16;
+  auto launch = [&](auto kern) -> int {
+    static thread_local size_t granted = 0;
+    if (granted < lds) {
+      if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+        return e;
+      granted = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
+  };
+  int e;
+  if (dtype == AQLM_HIP_BF16) e = launch(gemv_1x16_packed_kernel<BF16, NW, 3, 0>);
+  else switch (tuning().lds_variant & 7) {  // ablation switches (experiments only; results are wrong for != 0)
+    case 1: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 1>); break;
+    case 2: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 2>); break;
+    case 3: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 3>); break;
+    case 4: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 4>); break;
+    case 7: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 7>); break;
+    default: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 0>); break;
+  }
+  if (e) return e;
+  PackedFinalizeParams f{};
+  f.partial = (const float*)workspace;
+  f.scales = (const uint16_t*)scales;
+  f.bias = (const uint16_t*)bias;
+  f.y = (uint16_t*)y;
+  f.M = out_features;
+  if (dtype == AQLM_HIP_F16)
+    hipLaunchKernelGGL(gemv_1x16_packed_finalize<F16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
+  else
+    hipLaunchKernelGGL(gemv_1x16_packed_finalize<BF16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
+  return check_hip(hipGetLastError(), "gemv_1x16_packed_finalize launch");
+}

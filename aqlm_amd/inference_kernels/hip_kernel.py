@@ -130,6 +130,45 @@ def _gemv_1x16_lds(input, codes, codebooks, scales, bias):
     return y.reshape(input.shape[:-1] + (out_features,))
 
 
+def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8) -> Optional[torch.Tensor]:
+    """Repack 1x16 g8 codes [out, in/8, 1] (int16) into the slice-bucketed buffer of aqlm_hip_gemv_1x16_packed.
+    Returns None when the packed path does not cover the shape.  One-off, at load / first use (the counterpart of the
+    reference's load-time code permutation for its CPU kernel, inference.py:78-83)."""
+    out_features, in_features = codes.shape[0], codes.shape[1] * in_group_size
+    nbytes = _lib.aqlm_hip_prepack_1x16_bytes(out_features, in_features, in_group_size)
+    if nbytes == 0:
+        return None
+    codes = _c(codes)
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=codes.device)
+    with torch.cuda.device(codes.device):
+        rc = _lib.aqlm_hip_prepack_1x16(codes.data_ptr(), out_features, in_features, in_group_size, packed.data_ptr(),
+                                        nbytes, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm prepack_1x16")
+    return packed
+
+
+def code1x16_matmat_packed(input, packed, codebooks, scales, bias, out_features: int):
+    """Single-row 1x16 g8 matvec on prepacked codes (aqlm_hip_gemv_1x16_packed)."""
+    dt = _dtype_id(input)
+    in_features = input.shape[-1]
+    if input.numel() != in_features:
+        raise ValueError("the packed kernel handles exactly one input row")
+    x = _flat_rows(input)
+    codebooks, scales = _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
+    ws = torch.empty((8 * out_features,), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.aqlm_hip_gemv_1x16_packed(packed.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                            x.data_ptr(), y.data_ptr(), out_features, in_features, 8, dt,
+                                            ws.data_ptr(), ws.numel() * 4, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm gemv_1x16_packed")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
 def _lds_gemv_applicable(input, codes, codebooks):
     return (codebooks.shape[3] == 8 and input.numel() == input.shape[-1] and input.shape[-1] % 64 == 0
             and input.shape[-1] <= 14336 and input.dtype == codebooks.dtype)

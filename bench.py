@@ -34,6 +34,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# 1x16 g8 layers with at least this many output rows run the prepacked (slice-bucketed) decode kernel, like
+# aqlm_amd.inference.PREPACK_MIN_OUT_FEATURES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
+PACK_MIN_OUT = 8192
 
 
 def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
@@ -58,11 +61,34 @@ class Layer:
         self.x = torch.randn((batch, fin), generator=gen, device=device, dtype=torch.float32).half()
         self.y = torch.empty((batch, fout), device=device, dtype=torch.float16)
         self.bytes = algorithmic_bytes(fin, fout, K, nbits, g, batch)
+        self.packed = None
+        if PACK_MIN_OUT and (K, nbits, g) == (1, 16, 8) and fout >= PACK_MIN_OUT:
+            from aqlm_amd import _native
+
+            self.prepack(_native.lib)
+
+    def prepack(self, lib):
+        """One-off load-time repack for the slice-bucketed decode kernel (layers with >= PACK_MIN_OUT rows)."""
+        from aqlm_amd import _native
+
+        nbytes = lib.aqlm_hip_prepack_1x16_bytes(self.fout, self.fin, self.g)
+        if not nbytes:
+            return
+        self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=self.codes.device)
+        self.ws = torch.empty((8 * self.fout,), dtype=torch.float32, device=self.codes.device)
+        rc = lib.aqlm_hip_prepack_1x16(self.codes.data_ptr(), self.fout, self.fin, self.g, self.packed.data_ptr(), nbytes,
+                                       torch.cuda.current_stream().cuda_stream)
+        if rc:
+            _native.check(rc)
 
     def launch(self, lib, stream, batch=1):
         from aqlm_amd import _native
 
-        if self.nbits == 16:
+        if batch == 1 and getattr(self, "packed", None) is not None:
+            rc = lib.aqlm_hip_gemv_1x16_packed(self.packed.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(),
+                                               None, self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g,
+                                               _native.F16, self.ws.data_ptr(), self.ws.numel() * 4, stream)
+        elif self.nbits == 16:
             rc = lib.aqlm_hip_gemv_1x16(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                         self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, batch,
                                         self.fin, self.fout, _native.F16, stream)
@@ -196,7 +222,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-detail", action="store_true", help="skip the untimed per-shape / other-scheme breakdown")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-packed", action="store_true", help="direct L2-gather kernel for every layer (no prepacked path)")
     args = ap.parse_args()
+    global PACK_MIN_OUT
+    if args.no_packed:
+        PACK_MIN_OUT = 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -267,11 +297,14 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "aqlm::gemv_kernel<F16,1x16,g8,NB=1>",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "kernel": ("aqlm::gemv_kernel<F16,1x16,g8> (4096-row layers) + aqlm::gemv_1x16_packed_kernel<F16> "
+                           "(11008-row layers, prepacked codes)") if PACK_MIN_OUT else "aqlm::gemv_kernel<F16,1x16,g8,NB=1>",
                 "avg_launch_us": avg_launch_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "launches_timed": launches,
-                "note": "duration = HIP-event time of the timed region / launches (includes ~1 us inter-launch gaps); "
-                        "rocprofv3 kernel-only durations are in profiles/"}
+                "note": "one launch = one matvec (packed path: main + finalize kernel); duration = HIP-event time of the "
+                        "timed region / matvecs; achieved uses ALGORITHMIC bytes (2 B per code) even where the prepacked "
+                        "path really reads ~3.1 B per code; rocprofv3 per-kernel durations are in profiles/"}
 
     result = {
         "metric": "QuantizedLinear 1x16g8 matvec algorithmic GB/s (bs=1, Llama-3-8B shapes 4096->4096/11008)",
@@ -281,6 +314,8 @@ def main():
         "config": {"workload": "decode step = 32 blocks x {4096->4096, 4096->11008} 1x16g8 matvec, bs=1, 64 distinct "
                                "layers (own codes + codebook), 564 MB algorithmic bytes/step, hipGraph replay",
                    "scheme": "1x16g8", "batch": 1, "layers_per_step": step.n, "algorithmic_bytes_per_step": step.bytes,
+                   "kernels": ("direct L2-gather gemv for out<8192, prepacked slice-bucketed gemv for out>=8192"
+                               if PACK_MIN_OUT else "direct L2-gather gemv"),
                    "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
         "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
         "roofline": roofline,

@@ -127,8 +127,30 @@ int aqlm_hip_gemv_1x16_lds(const void* codes_i16, const void* codebook, const vo
                            const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Load-time repack of 1x16 g8 codes into the slice-bucketed format consumed by aqlm_hip_gemv_1x16_packed
+ * (layout documented in aqlm_amd/csrc/gemv_packed.hip and DESIGN.md; 3 bytes per code + 4 bytes per (row, slice)).
+ * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
+ * (inference.py:78-83).  aqlm_hip_prepack_1x16_bytes returns 0 for shapes the packed path does not cover
+ * (in_group_size != 8, in_features % 64 != 0, in_features > 16320).  aqlm_hip_prepack_1x16 synchronises `stream`
+ * once (it is not meant to be graph-captured).
+ */
+size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size);
+int aqlm_hip_prepack_1x16(const void* codes_i16, int out_features, int in_features, int in_group_size, void* packed,
+                          size_t packed_bytes, void* stream);
+
+/*
+ * Batch-1 1x16 g8 matvec on prepacked codes: every CU keeps one 128 KiB slice of the codebook in LDS and walks only
+ * the codes of that slice.  Same result contract as aqlm_hip_gemv_1x16.  workspace:
+ * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, 1, out, in) bytes of fp32 partials.
+ */
+int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codebook, const void* scales, const void* bias,
+                              const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_LDS 2
+#define AQLM_HIP_OP_GEMV_1X16_PACKED 3
 size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);
 
 /*

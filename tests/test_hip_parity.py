@@ -342,3 +342,84 @@ def test_gemv_1x16_lds_variant(hk, fin, fout, dt, bias):
         assert torch.equal(yz[0], T["bias"])
     yd = hk._gemv(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "1x16")
     check_close(y.float().cpu().numpy(), yd.float().cpu().numpy().astype(np.float64), dtype, "lds vs direct")
+
+
+# ------------------------------------------------------------------ prepacked (slice-bucketed) 1x16 path
+@pytest.mark.parametrize("fin,fout", [(512, 96), (4096, 300), (11008, 64), (64, 40)])
+def test_prepack_is_bit_exact(hk, fin, fout):
+    """The packed buffer must equal the numpy model of the format bit for bit (integer / byte work)."""
+    from tests import packed_model as pm
+
+    L = orc.make_layer(321 + fin, fin, fout, 1, 16, 8, batch=1, bias=False)
+    codes = torch.from_numpy(L["codes"]).to(DEV)
+    packed = hk.prepack_1x16(codes)
+    assert packed is not None
+    rowoff, lo16, hi8, lay = pm.pack(L["codes_unsigned"][:, :, 0])
+    assert packed.numel() == lay["total"]
+    raw = packed.cpu().numpy()
+    got_rowoff = raw[lay["off_rowoff"]:lay["off_rowoff"] + lay["n_rowoff"] * 4].view(np.uint32)
+    got_lo = raw[lay["off_lo16"]:lay["off_lo16"] + lay["entries"] * 2].view(np.uint16)
+    got_hi = raw[lay["off_hi8"]:lay["off_hi8"] + lay["entries"]]
+    np.testing.assert_array_equal(got_rowoff, rowoff)
+    np.testing.assert_array_equal(got_lo, lo16)
+    np.testing.assert_array_equal(got_hi, hi8)
+    hdr = raw[:64].view(np.uint32)
+    assert hdr[0] == 0x31505141 and hdr[1] == 2 and hdr[2] == fout and hdr[3] == fin // 8 and hdr[7] == lay["RG"]
+    # lossless: the entries reproduce the original codes
+    RG = lay["RG"]
+    ro = rowoff.reshape(pm.NG, pm.S, RG + 1)
+    rec = np.full((fout, fin // 8), -1, dtype=np.int64)
+    for r in range(fout):
+        for s in range(pm.S):
+            b, e = int(ro[r // RG, s, r % RG]), int(ro[r // RG, s, r % RG + 1])
+            ent = got_lo[b:e].astype(np.int64) | (got_hi[b:e].astype(np.int64) << 16)
+            ent = ent[(ent >> 13) < fin // 8]  # drop the null padding entries
+            rec[r, ent >> 13] = (s << 13) | (ent & 0x1FFF)
+    np.testing.assert_array_equal(rec, L["codes_unsigned"][:, :, 0])
+    assert hk.prepack_1x16(torch.zeros(8, 65, 1, dtype=torch.int16, device=DEV)) is None  # 520 features: unsupported
+
+
+@pytest.mark.parametrize("fin,fout,dt,bias", [
+    (4096, 4096, "float16", True),
+    (4096, 1000, "float16", False),
+    (4096, 37, "bfloat16", True),
+    (8192, 512, "float16", True),
+    (11008, 640, "float16", True),
+    (14336, 1024, "bfloat16", True),
+    (64, 256, "float16", True),
+])
+def test_gemv_1x16_packed(hk, fin, fout, dt, bias):
+    dtype = tdtype(dt)
+    L = orc.make_layer(700 + fin + fout, fin, fout, 1, 16, 8, batch=1, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    # skew the slice populations so that some (row, slice) buckets are empty and others exceed 64 / 128 entries
+    cu = L["codes_unsigned"].copy()
+    cu[1, :, 0] = cu[1, :, 0] & 0x1FFF            # row 1: everything in slice 0
+    cu[2, ::2, 0] = (cu[2, ::2, 0] & 0x1FFF) | (5 << 13)
+    L = dict(L, codes=orc.pack_int_data(cu, 16), codes_unsigned=cu)
+    T = to_dev(L, dtype)
+    packed = hk.prepack_1x16(T["codes"])
+    y = hk.code1x16_matmat_packed(T["x"], packed, T["codebooks"], T["scales"], T["bias"], fout)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, f"packed 1x16g8 {fin}->{fout}")
+    if bias:
+        yz = hk.code1x16_matmat_packed(torch.zeros_like(T["x"]), packed, T["codebooks"], T["scales"], T["bias"], fout)
+        assert torch.equal(yz[0], T["bias"])
+    # determinism: two runs are bit-identical (no atomics in the accumulation order)
+    y2 = hk.code1x16_matmat_packed(T["x"], packed, T["codebooks"], T["scales"], T["bias"], fout)
+    assert torch.equal(y, y2)
+
+
+def test_quantized_linear_uses_prepacked_path_for_large_layers(hk):
+    import aqlm_amd.inference as inf
+
+    fin, fout = 1024, 8192
+    L = orc.make_layer(55, fin, fout, 1, 16, 8, batch=2, bias=True)
+    m, T = _module_from(L, 1, 16, 8, fin, fout, torch.float16)
+    y1 = m(T["x"][:1])                      # single row -> prepacked kernel
+    assert m._packed_codes is not None and fout >= inf.PREPACK_MIN_OUT_FEATURES
+    y2 = m(T["x"])                          # two rows -> direct kernel
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y1.float().cpu().numpy(), y64[:1], torch.float16, "module packed path")
+    check_close(y2.float().cpu().numpy(), y64, torch.float16, "module direct path")
+    assert "_packed_codes" not in m.state_dict()

@@ -221,12 +221,14 @@ static void bench_stream() {
 // ---------------------------------------------------------------- library kernels through the C ABI
 struct Layer {
   void *codes, *cb, *scales, *x, *y;
+  void* packed = nullptr;
 };
 
 struct Scheme {
   const char* name;
   int K, nbits, g;
   bool lds = false;  // route 1x16 through aqlm_hip_gemv_1x16_lds
+  bool packed = false;  // route 1x16 through aqlm_hip_gemv_1x16_packed
 };
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -239,6 +241,8 @@ static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
 }
 
 static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st) {
+  if (s.nbits == 16 && s.packed)
+    return aqlm_hip_gemv_1x16_packed(L.packed, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16 && s.lds)
     return aqlm_hip_gemv_1x16_lds(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16)
@@ -297,28 +301,42 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     hipLaunchKernelGGL(fill_one_half, dim3(64), dim3(256), 0, 0, (uint16_t*)L.scales, (size_t)out);
   }
   CK(hipDeviceSynchronize());
+  if (s.packed) {
+    const size_t pb = aqlm_hip_prepack_1x16_bytes(out, in, s.g);
+    for (auto& L : v) {
+      CK(hipMalloc(&L.packed, pb));
+      if (int rc = aqlm_hip_prepack_1x16(L.codes, out, in, s.g, L.packed, pb, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+    }
+    CK(hipDeviceSynchronize());
+  }
   return v;
 }
 
 static void free_layers(std::vector<Layer>& v) {
-  for (auto& L : v) { hipFree(L.codes); hipFree(L.cb); hipFree(L.scales); hipFree(L.x); hipFree(L.y); }
+  for (auto& L : v) { hipFree(L.codes); hipFree(L.cb); hipFree(L.scales); hipFree(L.x); hipFree(L.y); if (L.packed) hipFree(L.packed); }
 }
 
 static void bench_gemv(int argc, char** argv) {
   g_ws_bytes = (size_t)8 * 32768 * 4;
   CK(hipMalloc(&g_ws, g_ws_bytes));
   const Scheme S1x16L{"1x16g8L", 1, 16, 8, true};
+  const Scheme S1x16P{"1x16g8P", 1, 16, 8, false, true};
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
-  std::vector<Case> cases = {{S1x16L, 4096, 4096}, {S1x16L, 4096, 11008}, {S1x16L, 4096, 14336}, {S1x16L, 14336, 4096}, {S1x16L, 4096, 1024}, {S1x16L, 8192, 28672},
+  std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672},
+                             {S1x16L, 4096, 4096}, {S1x16L, 4096, 11008}, {S1x16L, 4096, 14336}, {S1x16L, 14336, 4096}, {S1x16L, 4096, 1024}, {S1x16L, 8192, 28672},
                              {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
                              {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
                              {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}};
   const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+  const char* only = argc > 3 ? argv[3] : nullptr;  // run only schemes whose name contains this
+  const int only_out = argc > 4 ? atoi(argv[4]) : 0;
   const double gap = time_empty_graph(128, 20);
   printf("# empty-kernel graph: %.2f us per launch (launch gap floor)\n", gap);
   printf("%-9s %6s %6s %2s %-26s %9s %9s %8s %8s\n", "scheme", "in", "out", "B", "variant", "cold_us", "warm_us", "coldGB/s", "%8TB/s");
   for (const auto& c : cases) {
+    if (only && !strstr(c.s.name, only)) continue;
+    if (only_out && c.out != only_out) continue;
     const size_t ab1 = algo_bytes(c.in, c.out, c.s, 1);
     int n = (int)((600u << 20) / ab1) + 1;
     if (n > 160) n = 160;
@@ -329,7 +347,7 @@ static void bench_gemv(int argc, char** argv) {
     struct Var { const char* name; const char* key; int val; };
     std::vector<std::vector<Var>> variants;
     variants.push_back({});
-    if (c.s.nbits == 16 && !quick && !c.s.lds) {
+    if (c.s.nbits == 16 && !quick && !c.s.lds && !c.s.packed) {
       variants.push_back({{"aux=nt", "gemv1x16_aux", 2}});
       variants.push_back({{"aux=sc1", "gemv1x16_aux", 16}});
       variants.push_back({{"prefetch_cb", "gemv1x16_prefetch_cb", 1}});
@@ -337,6 +355,12 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
+    } else if (c.s.packed) {
+      variants.push_back({{"abl=1(no lds gather)", "lds_variant", 1}});
+      variants.push_back({{"abl=2(no reduce)", "lds_variant", 2}});
+      variants.push_back({{"abl=3", "lds_variant", 3}});
+      variants.push_back({{"abl=4(no cb fill)", "lds_variant", 4}});
+      variants.push_back({{"abl=7(skeleton)", "lds_variant", 7}});
     } else if (c.s.lds) {
       variants.push_back({{"var=1(nosched)", "lds_variant", 1}});
       variants.push_back({{"var=2(direct store)", "lds_variant", 2}});
@@ -350,7 +374,7 @@ static void bench_gemv(int argc, char** argv) {
       std::string vn = var.empty() ? "default" : "";
       for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
       for (int batch : {1, 2, 4, 8}) {
-        if (batch > 1 && (!var.empty() || c.s.lds || quick)) continue;
+        if (batch > 1 && (!var.empty() || c.s.lds || c.s.packed || quick)) continue;
         const size_t ab = algo_bytes(c.in, c.out, c.s, batch);
         const double cold = time_graph(c.s, layers, c.in, c.out, batch, 4);
         const double w = time_graph(c.s, warm, c.in, c.out, batch, 20);
