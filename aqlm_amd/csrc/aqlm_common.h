@@ -95,6 +95,7 @@ struct Tuning {
   int gemv1x16_xreg = 0;         // reserved
   int kx8_replicas = 1;          // reserved
   int lds_variant = 0;           // experiment switch of the slice-scan kernel
+  int gemm_splitk_free = 0;      // 1: large-batch 1x16 op uses the split-K-free 16x16x32 kernel when in % 256 == 0
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
 };
 Tuning& tuning();

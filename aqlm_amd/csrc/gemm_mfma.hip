@@ -121,24 +121,8 @@ __global__ __launch_bounds__(256) void gemm_1x16_mfma_kernel(const GemmParams p)
     }
   };
 
-  uint32_t cw_next[CWN];
-  load_x(0);
-  load_codes(0, cw_next);
-  store_x(0);
-  __syncthreads();
-
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
-    uint32_t cw[CWN];
-#pragma unroll
-    for (int k = 0; k < CWN; ++k) cw[k] = cw_next[k];
-    const bool more = ch + 1 < nchunks;
-    if (more) {
-      load_x(ch + 1);
-      load_codes(ch + 1, cw_next);
-    }
-    // 4 k-steps of 16: one gather per lane per step; entry == MFMA A fragment
-    u32x4 afrag[4];
+  // gathers: one 16-B entry per lane per 16-deep k step = 4 per 64-deep chunk; entry == MFMA A fragment
+  auto gather = [&](const uint32_t (&cw)[CWN], u32x4 (&af)[4]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       uint32_t code, piece;
@@ -149,18 +133,44 @@ __global__ __launch_bounds__(256) void gemm_1x16_mfma_kernel(const GemmParams p)
         code = (cw[kk >> 1] >> (16 * (kk & 1))) & 0xffffu;  // code index kk, lane-half picks the 16-B half
         piece = half;
       }
-      afrag[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, code * (uint32_t)(G * 2) + piece * 16, 0, 0);
+      af[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, code * (uint32_t)(G * 2) + piece * 16, 0, 0);
+    }
+  };
+
+  // Software pipeline: codes run two chunks ahead, codebook gathers one chunk ahead of the MFMAs that consume them.
+  // The loop is unrolled by two with ping-pong roles (A/B) so that no register with a load in flight is ever copied
+  // (a copy forces hipcc to wait for the load it was just issued for: measured 3.3 us per chunk).
+  uint32_t cw_a[CWN], cw_b[CWN];
+  u32x4 af_a[4], af_b[4];
+  load_x(0);
+  load_codes(0, cw_a);
+  if (nchunks > 1) load_codes(1, cw_b);
+  gather(cw_a, af_a);
+  store_x(0);
+  __syncthreads();
+
+  auto step = [&](int ch, uint32_t (&cw_free)[CWN], const uint32_t (&cw_next)[CWN], const u32x4 (&af_cur)[4], u32x4 (&af_nxt)[4]) {
+    const int buf = ch & 1;
+    const bool more = ch + 1 < nchunks;
+    if (more) {
+      load_x(ch + 1);
+      gather(cw_next, af_nxt);                             // chunk ch+1's entries fly during this chunk's MFMAs
+      if (ch + 2 < nchunks) load_codes(ch + 2, cw_free);   // cw_free's gathers were issued one step ago
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
       for (int t = 0; t < NBT; ++t) {
         const u32x4 bfrag = xl[buf][xswz(t * 32 + (lane & 31), kk * 2 + half)];
-        acc[t] = mfma32<T>(afrag[kk], bfrag, acc[t]);
+        acc[t] = mfma32<T>(af_cur[kk], bfrag, acc[t]);
       }
     }
     if (more) store_x(buf ^ 1);
     __syncthreads();
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    step(ch, cw_a, cw_b, af_a, af_b);
+    if (ch + 1 < nchunks) step(ch + 1, cw_b, cw_a, af_b, af_a);
   }
 
   // fp32 partials: C layout col = lane&31 (batch), row = (r&3) + 8*(r>>2) + 4*half
@@ -193,8 +203,14 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const FinalizeParams
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + ty + i * 8, b = b0 + tx;
     float s = 0.f;
-    if (m < p.M && b < p.Bpad)
-      for (int k = 0; k < p.ksplit; ++k) s += p.partial[((long)k * p.M + m) * p.Bpad + b];
+    if (m < p.M && b < p.Bpad) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = k < p.ksplit ? p.partial[((long)k * p.M + m) * p.Bpad + b] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+      for (int k = 8; k < p.ksplit; ++k) s += p.partial[((long)k * p.M + m) * p.Bpad + b];
+    }
     tile[ty + i * 8][tx] = s;
   }
   __syncthreads();
@@ -207,6 +223,170 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const FinalizeParams
       p.Y[(long)b * p.ys + m] = T::from_float(tile[tx][ty + i * 8] * scale + bias);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-K-free variant (experimental, opt-in through the `gemm_splitk_free` tuning knob; measured SLOWER than the
+// split-K kernel on MI355X at 4096x4096: 41 vs 30 us at B = 128 -- each block re-streams all of X through L2 and a
+// 4-wave block cannot hide that latency): one block = 16 output rows x the whole K x all batch
+// columns.  The 4 waves split K four ways, each streams ITS quarter of X through a wave-private LDS image (no block
+// barrier in the main loop) and accumulates 16 x Bpad in registers with v_mfma_f32_16x16x32; at the end the 4
+// accumulators are added through LDS and the block writes Y directly (scale, bias, one rounding): no fp32 partials
+// in HBM, no second kernel.  A operand of lane l = 8 consecutive k of row l%16, k-group l/16 = one codebook entry.
+// Cost model per CU (M = 4096: one block per CU): 8192 gathered 128-B lines + B*K*2 bytes of X through the 64 B/clk
+// L1-fill path -> ~8 us + 6.8 us at B = 128.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class T>
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<F16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<BF16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+struct Gemm16Params {
+  const uint8_t* codes;
+  const uint8_t* codebook;
+  const uint16_t* X;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* Y;
+  int M, K, B, in_groups;
+  long xs, ys;
+  int cb_bytes;
+};
+
+template <class T, int G, int NBT>  // NBT = 16-column batch tiles (Bpad = 16 * NBT <= 128)
+__global__ __launch_bounds__(256) void gemm_1x16_mfma16_kernel(const Gemm16Params p) {
+  constexpr int BPAD = NBT * 16;
+  constexpr int PIECES = BPAD * 8;             // 16-B pieces of one 64-deep X chunk
+  constexpr int PER_LANE = PIECES / 64;        // = 2 * NBT
+  constexpr int CWN = (64 / G) / 2;            // dwords of codes per row per chunk: 4 (g8) / 2 (g16)
+  __shared__ __attribute__((aligned(16))) u32x4 xl_all[4][PIECES];   // wave-private X chunk images (<= 64 KiB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  u32x4* const xl = xl_all[wave];
+  const int arow = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  int my_row = row0 + arow;
+  if (my_row >= p.M) my_row = p.M - 1;  // clamp: computed, never stored
+  const int kq = p.K >> 2;               // this wave's K range
+  const int k_begin = wave * kq;
+  const int nchunks = kq >> 6;
+
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.codebook, 0, p.cb_bytes, 0x00020000);
+  const uint8_t* const code_row = p.codes + (long)my_row * p.in_groups * 2;
+
+  f32x4 acc[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_codes = [&](int chunk, uint32_t (&cw)[CWN]) {
+    const uint8_t* src = code_row + (long)((k_begin + chunk * 64) / G) * 2;
+    if constexpr (CWN == 4) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+      cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+    } else {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(src);
+      cw[0] = v.x; cw[1] = v.y;
+    }
+  };
+  // two 32-deep steps per chunk; lane (arow, kg) needs code 4*step + kg (g8) or code 2*step + kg/2, half kg&1 (g16)
+  auto gather = [&](const uint32_t (&cw)[CWN], u32x4 (&af)[2]) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      uint32_t off;
+      if constexpr (G == 8) {
+        const uint32_t dw = (kg & 2) ? cw[2 * st + 1] : cw[2 * st];
+        off = ((dw >> (16 * (kg & 1))) & 0xffffu) * 16u;
+      } else {
+        const uint32_t dw = cw[st];
+        off = ((dw >> (16 * (kg >> 1))) & 0xffffu) * 32u + (uint32_t)(kg & 1) * 16u;
+      }
+      af[st] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+  };
+  // X chunk: lane takes pieces q = lane + 64*s -> row b = q >> 3, piece c = q & 7 (full 128-B rows: no over-fetch)
+  auto load_x = [&](int chunk, u32x4 (&xr)[PER_LANE]) {
+    const int k0 = k_begin + chunk * 64;
+#pragma unroll
+    for (int s = 0; s < PER_LANE; ++s) {
+      const int q = lane + 64 * s, b = q >> 3, c = q & 7;
+      xr[s] = b < p.B ? *reinterpret_cast<const u32x4*>(p.X + (long)b * p.xs + k0 + c * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_x = [&](const u32x4 (&xr)[PER_LANE]) {
+#pragma unroll
+    for (int s = 0; s < PER_LANE; ++s) {
+      const int q = lane + 64 * s;
+      xl[xswz(q >> 3, q & 7)] = xr[s];
+    }
+  };
+
+  uint32_t cw_a[CWN], cw_b[CWN];
+  u32x4 af_a[2], af_b[2];
+  u32x4 xr[PER_LANE];
+  load_x(0, xr);
+  load_codes(0, cw_a);
+  if (nchunks > 1) load_codes(1, cw_b);
+  gather(cw_a, af_a);
+  store_x(xr);
+
+  auto step = [&](int ch, uint32_t (&cw_free)[CWN], const uint32_t (&cw_next)[CWN], const u32x4 (&af_cur)[2], u32x4 (&af_nxt)[2]) {
+    const bool more = ch + 1 < nchunks;
+    if (more) {
+      load_x(ch + 1, xr);
+      gather(cw_next, af_nxt);
+      if (ch + 2 < nchunks) load_codes(ch + 2, cw_free);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) {
+        const u32x4 bfrag = xl[xswz(t * 16 + arow, st * 4 + kg)];
+        acc[t] = mfma16<T>(af_cur[st], bfrag, acc[t]);
+      }
+    }
+    if (more) store_x(xr);  // same-wave LDS ops execute in order: these writes follow the reads above
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    step(ch, cw_a, cw_b, af_a, af_b);
+    if (ch + 1 < nchunks) step(ch + 1, cw_b, cw_a, af_b, af_a);
+  }
+
+  // cross-wave K reduction through LDS (re-using the X images), then the fused epilogue
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(&xl_all[0][0]);  // [4 waves][16 rows][BPAD]
+#pragma unroll
+  for (int t = 0; t < NBT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + kg * 4 + r) * BPAD + t * 16 + arow] = acc[t][r];
+  __syncthreads();
+  for (int q = tid; q < 16 * BPAD; q += 256) {
+    const int b = q >> 4, r = q & 15;   // consecutive threads -> consecutive rows of one batch column (32-B runs of Y)
+    const int row = row0 + r;
+    if (b < p.B && row < p.M) {
+      const float s = red[(0 * 16 + r) * BPAD + b] + red[(1 * 16 + r) * BPAD + b] + red[(2 * 16 + r) * BPAD + b] +
+                      red[(3 * 16 + r) * BPAD + b];
+      const float scale = T::to_float(p.scales[row]);
+      const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+      p.Y[(long)b * p.ys + row] = T::from_float(s * scale + bias);
+    }
+  }
+}
+
+template <class T, int G>
+static int launch_gemm16(const Gemm16Params& p, int bpad, hipStream_t stream) {
+  const int blocks = (p.M + 15) / 16;
+  if (bpad <= 16) hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 1>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (bpad <= 32) hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 2>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (bpad <= 64) hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 4>), dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 8>), dim3(blocks), dim3(256), 0, stream, p);
+  return check_hip(hipGetLastError(), "gemm_1x16_mfma16 launch");
 }
 
 struct GemmPlan {
@@ -283,8 +463,33 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
     return AQLM_HIP_E_INVALID;
   }
   // batch > 128 is processed in slabs of 128 columns (codes re-gathered per slab)
+  const bool splitk_free = (in_features % 256 == 0) && tuning().gemm_splitk_free;  // measured slower: opt-in
   for (int b0 = 0; b0 < batch; b0 += 128) {
     const int nb = std::min(128, batch - b0);
+    if (splitk_free) {
+      Gemm16Params q{};
+      q.codes = (const uint8_t*)codes;
+      q.codebook = (const uint8_t*)codebook;
+      q.X = (const uint16_t*)X + (long)b0 * xs;
+      q.scales = (const uint16_t*)scales;
+      q.bias = (const uint16_t*)bias;
+      q.Y = (uint16_t*)Y + (long)b0 * ys;
+      q.M = out_features;
+      q.K = in_features;
+      q.B = nb;
+      q.in_groups = in_features / in_group_size;
+      q.xs = xs;
+      q.ys = ys;
+      q.cb_bytes = 65536 * in_group_size * 2;
+      const int bpad = (nb + 15) / 16 * 16;
+      int e;
+      if (dtype == AQLM_HIP_F16)
+        e = in_group_size == 8 ? launch_gemm16<F16, 8>(q, bpad, stream) : launch_gemm16<F16, 16>(q, bpad, stream);
+      else
+        e = in_group_size == 8 ? launch_gemm16<BF16, 8>(q, bpad, stream) : launch_gemm16<BF16, 16>(q, bpad, stream);
+      if (e) return e;
+      continue;
+    }
     const GemmPlan g = plan_gemm(nb, out_features, in_features);
     GemmParams p{};
     p.codes = (const uint8_t*)codes;

@@ -175,6 +175,42 @@ def cpu_baseline(sample_seconds=12.0):
     }
 
 
+def large_batch_detail(dev, reps):
+    """BASELINE config 4: 1x16g8 4096->4096 at batch 128.  Fused dequant-tile -> MFMA op (W never in HBM) next to the
+    reference-equivalent pipeline (our dequant kernel + hipBLASLt GEMM through F.linear) and a dense fp16 GEMM."""
+    import torch.nn.functional as F
+
+    from aqlm_amd.inference_kernels import hip_kernel as hk
+
+    fin = fout = 4096
+    B = 128
+    layers = [Layer(fin, fout, 1, 16, 8, 424242 + i, dev) for i in range(24)]  # rotate: 24 x 5.3 MB > L2
+    x = torch.randn((B, fin), device=dev, dtype=torch.float16)
+
+    def timeit(fn):
+        for l in layers[:3]:
+            fn(l)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 0
+        for _ in range(max(2, reps // 2)):
+            for l in layers:
+                fn(l)
+                n += 1
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    fused = timeit(lambda l: hk.code1x16_matmat_dequant(x, l.codes, l.codebooks, l.scales, None))
+    ref_like = timeit(lambda l: F.linear(x, hk.code1x16_dequant(l.codes, l.codebooks, l.scales)))
+    W = hk.code1x16_dequant(layers[0].codes, layers[0].codebooks, layers[0].scales)
+    dense = timeit(lambda l: F.linear(x, W))
+    flop = 2.0 * B * fin * fout
+    return {"fused_mfma_us": fused, "fused_TFLOPs": flop / fused * 1e-6, "dequant_plus_gemm_us": ref_like,
+            "dense_fp16_gemm_us": dense, "note": "eager launches incl. python overhead; same x, 24 rotating layers"}
+
+
 def sharded_70b(lib, dev, rank, world, steps):
     """North-star config 5: Llama-3-70B 8192->28672 1x16g8 layer, split along `in` over `world` ranks, partial outputs
     summed with an RCCL all-reduce (fp16, 56 KiB).  With world == 1 only the per-shard kernel for /8 is timed."""
@@ -357,6 +393,7 @@ def main():
                                                         "algorithmic_GBps": gp.bytes / ms * 1e-6,
                                                         "frac_of_8TBps": gp.bytes / ms * 1e-6 / HBM_PEAK_GBPS}
             del gp, tok
+        detail["bs128_1x16g8_4096x4096"] = large_batch_detail(dev, reps)
         result["detail"] = detail
         result["sharded_70b"] = sharded_70b(lib, dev, rank, world, args.steps)
 

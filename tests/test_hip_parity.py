@@ -227,6 +227,24 @@ def test_matmat_dequant_mfma(hk, g, fin, fout, B, dt):
     check_close(y, y64, dtype, f"mfma g{g} {fin}->{fout} B{B}")
 
 
+def test_matmat_dequant_mfma_splitk_free_variant(hk):
+    """The experimental split-K-free 16x16x32 kernel (tuning knob) must agree with the oracle too."""
+    from aqlm_amd import _native
+
+    _native.set_tuning("gemm_splitk_free", 1)
+    try:
+        for g, fin, fout, B, dt in [(8, 4096, 1000, 100, "float16"), (16, 1024, 256, 20, "bfloat16"), (8, 512, 48, 128, "float16")]:
+            dtype = tdtype(dt)
+            L = orc.make_layer(5150 + B, fin, fout, 1, 16, g, batch=B, bias=True,
+                               float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+            T = to_dev(L, dtype)
+            y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+            y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+            check_close(y, y64, dtype, f"mfma16 g{g} {fin}->{fout} B{B}")
+    finally:
+        _native.set_tuning("gemm_splitk_free", 0)
+
+
 @pytest.mark.parametrize("K,g", [(2, 8), (1, 8), (8, 32)])
 def test_matmat_dequant_kx8(hk, K, g):
     L = orc.make_layer(99, 2048, 192, K, 8, g, batch=40, bias=True)

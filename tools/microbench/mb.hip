@@ -388,6 +388,55 @@ static void bench_gemv(int argc, char** argv) {
   }
 }
 
+// ---------------------------------------------------------------- large-batch ops through the C ABI
+static void bench_gemm(bool nosync) {
+  const int in = 4096, out = 4096;
+  const Scheme s{"1x16g8", 1, 16, 8};
+  printf("%-28s %5s %10s %10s\n", "op", "B", "us", "TFLOP/s");
+  for (int B : {16, 32, 64, 128, 256}) {
+    auto layers = make_layers(s, in, out, 8, 24);
+    void *X, *Y, *W, *ws;
+    CK(hipMalloc(&X, (size_t)B * in * 2)); CK(hipMalloc(&Y, (size_t)B * out * 2)); CK(hipMalloc(&W, (size_t)in * out * 2));
+    const size_t wsb = aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMM_1X16_MFMA, B, out, in);
+    CK(hipMalloc(&ws, wsb));
+    hipLaunchKernelGGL(fill_half, dim3(256), dim3(256), 0, 0, (uint32_t*)X, (size_t)B * in / 2, 99u);
+    CK(hipDeviceSynchronize());
+    auto time_it = [&](auto fn) {
+      hipStream_t st; CK(hipStreamCreate(&st));
+      fprintf(stderr, "  eager...\n");
+      for (auto& L : layers) { fn(L, st); if (!nosync) CK(hipStreamSynchronize(st)); }
+      CK(hipStreamSynchronize(st));
+      fprintf(stderr, "  capture...\n");
+      hipGraph_t g; hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      for (auto& L : layers) fn(L, st);
+      CK(hipStreamEndCapture(st, &g));
+      CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+      fprintf(stderr, "  timing...\n");
+      Timer t; t.start(st);
+      for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ge, st));
+      const float ms = t.stop_ms(st);
+      CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(st));
+      return ms * 1e3 / (5.0 * layers.size());
+    };
+    fprintf(stderr, "B=%d wsb=%zu fused\n", B, wsb);
+    const double fused = time_it([&](const Layer& L, hipStream_t st) {
+      int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
+      if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
+    });
+    fprintf(stderr, "B=%d dequant\n", B);
+    const double deq = time_it([&](const Layer& L, hipStream_t st) {
+      aqlm_hip_dequant_1x16(L.codes, L.cb, L.scales, W, out, in, 8, AQLM_HIP_F16, st);
+    });
+    const double flop = 2.0 * B * in * out;
+    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (fused)", B, fused, flop / fused * 1e-6);
+    printf("%-28s %5d %10.2f %10s   (reference pipeline = this + a %d x %d x %d library GEMM)\n", "dequant_1x16 alone", B, deq, "-", B, out, in);
+    hipFree(X); hipFree(Y); hipFree(W); hipFree(ws);
+    free_layers(layers);
+  }
+}
+
 int main(int argc, char** argv) {
   const char* what = argc > 1 ? argv[1] : "all";
   hipDeviceProp_t prop;
@@ -397,5 +446,6 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "ldsgather") || !strcmp(what, "all")) bench_lds();
   if (!strcmp(what, "stream") || !strcmp(what, "all")) bench_stream();
   if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
+  if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
   return 0;
 }
