@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const FinalizeParams
     if (m < p.M && b < p.B) {
       const float scale = T::to_float(p.scales[m]);
       const float bias = p.bias ? T::to_float(p.bias[m]) : 0.f;
-      p.Y[(long)b * p.ys + m] = T::from_float(tile[tx][ty + i * 8] * scale + bias);
+      p.Y[(long)b * p.ys + m] = T::from_float(__builtin_fmaf(tile[tx][ty + i * 8], scale, bias));
     }
   }
 }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void gemm_1x16_mfma16_kernel(const Gemm16Param
                       red[(3 * 16 + r) * BPAD + b];
       const float scale = T::to_float(p.scales[row]);
       const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-      p.Y[(long)b * p.ys + row] = T::from_float(s * scale + bias);
+      p.Y[(long)b * p.ys + row] = T::from_float(__builtin_fmaf(s, scale, bias));
     }
   }
 }

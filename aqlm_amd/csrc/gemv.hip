@@ -77,28 +77,63 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
   int nrows = p.M - row0;
   nrows = nrows < p.rpw ? nrows : p.rpw;
 
-  // (1) first code word goes in flight before anything else (HBM latency overlaps the LDS fill)
+  // ---- prologue: every global load is issued before the first wait (no load-wait-store loops: hipcc puts a
+  // vmcnt(0) in front of each ds_write of such a loop, i.e. one L2 round trip per iteration, ~1 us per kernel).
+  // (a) x pieces, 8 per thread, staged in registers (clamped, always-valid addresses)
+  const int pieces_per_row = p.in_groups * P;
+  const int total_x = NB * pieces_per_row;
+  auto x_piece = [&](int q) -> u32x4 {
+    q = q < total_x ? q : total_x - 1;
+    int b = 0, qq = q;
+    if constexpr (NB > 1) { b = q / pieces_per_row; qq = q - b * pieces_per_row; }
+    return *reinterpret_cast<const u32x4*>(p.x + (long)b * p.xs + (long)qq * 8);
+  };
+  auto x_store = [&](int q, const u32x4& v) {
+    if (q < total_x) {
+      int b = 0, qq = q;
+      if constexpr (NB > 1) { b = q / pieces_per_row; qq = q - b * pieces_per_row; }
+      const int j = qq / P, pp = qq % P;
+      const int u = j / U, i = j % U;
+      xl[((b * U + i) * P + pp) * p.pitch + u] = v;
+    }
+  };
+  u32x4 xstage[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) xstage[k] = x_piece(tid + k * NT);
+
+  // (b) scale / bias of the first row: unconditional loads (clamped row; bias pointer aliased to scales when absent)
+  const uint16_t* const bias_src = p.bias ? p.bias : p.scales;
+  const float bias_on = p.bias ? 1.f : 0.f;
+  const int row_c0 = row0 < p.M ? row0 : p.M - 1;
+  uint16_t scale_h = p.scales[row_c0], bias_h = bias_src[row_c0];
+
+  // (c) first code word (HBM latency overlaps the LDS fill)
   uint32_t cw_next[CW];
 #pragma unroll
   for (int k = 0; k < CW; ++k) cw_next[k] = 0;
   if (nrows > 0 && lane < p.nunits) load_code_word<CW>(p.codes + (long)row0 * p.code_row_bytes + (long)lane * UB, cw_next);
 
-  // (2) stage x: element (b, group j = u*U+i, piece pp) -> xl[((b*U+i)*P+pp)*pitch + u]
-  {
-    const int pieces_per_row = p.in_groups * P;
-    for (int q = tid; q < NB * pieces_per_row; q += NT) {
-      const int b = q / pieces_per_row;
-      const int qq = q - b * pieces_per_row;
-      const int j = qq / P, pp = qq % P;
-      const int u = j / U, i = j % U;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + (long)b * p.xs + (long)qq * 8);
-      xl[((b * U + i) * P + pp) * p.pitch + u] = v;
-    }
-  }
-  // (3) codebooks -> LDS (Kx8)
+  // (d) codebooks (Kx8): staged the same way, compile-time trip count
   if constexpr (CB_LDS) {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.codebooks);
-    for (int q = tid; q < KC * 256 * P; q += NT) cbl[q] = src[q];
+    constexpr int TOTAL = KC * 256 * P;
+    constexpr int PER = (TOTAL + NT - 1) / NT;
+    u32x4 cstage[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) cstage[k] = src[tid + k * NT < TOTAL ? tid + k * NT : TOTAL - 1];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (tid + k * NT < TOTAL) cbl[tid + k * NT] = cstage[k];
+  }
+  // (e) x -> LDS: element (b, group j = u*U+i, piece pp) -> xl[((b*U+i)*P+pp)*pitch + u]
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x_store(tid + k * NT, xstage[k]);
+  for (int q0 = tid + 8 * NT; q0 < total_x; q0 += NT * 4) {  // rare: more than 8 pieces per thread (large batch x K)
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x_piece(q0 + k * NT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x_store(q0 + k * NT, v[k]);
   }
 
   // optional: touch a 16 KiB slice of the codebook so that this XCD's L2 is warm before the random gathers
@@ -122,8 +157,13 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
 
   for (int r = 0; r < nrows; ++r) {
     const int row = row0 + r;
-    const float scale = T::to_float(p.scales[row]);
-    const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+    const float scale = T::to_float(scale_h);
+    const float bias = T::to_float(bias_h) * bias_on;
+    {
+      const int rn = row + 1 < p.M ? row + 1 : p.M - 1;  // next row's epilogue operands (unused after the last row)
+      scale_h = p.scales[rn];
+      bias_h = bias_src[rn];
+    }
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
@@ -188,7 +228,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
     for (int b = 0; b < NB; ++b) acc[b] = wave_sum(acc[b]);
     if (lane == 0) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) p.y[(long)b * p.ys + row] = T::from_float(acc[b] * scale + bias);
+      for (int b = 0; b < NB; ++b) p.y[(long)b * p.ys + row] = T::from_float(__builtin_fmaf(acc[b], scale, bias));
     }
   }
   // keep the prefetch loads alive without ever waiting on them early
@@ -243,7 +283,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const GenericParams p
   for (int b = 0; b < AQLM_HIP_MAX_GEMV_BATCH; ++b) {
     if (b < p.batch) {
       const float s = wave_sum(acc[b]);
-      if (lane == 0) p.y[(long)b * p.ys + row] = T::from_float(s * scale + bias);
+      if (lane == 0) p.y[(long)b * p.ys + row] = T::from_float(__builtin_fmaf(s, scale, bias));
     }
   }
 }
@@ -423,6 +463,9 @@ extern "C" int aqlm_hip_gemv_1x16(const void* codes, const void* codebook, const
 }
 
 namespace aqlm {
+int gemv_kx8_replicated(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x,
+                        void* y, int out_features, int in_features, int num_codebooks, int dtype, hipStream_t stream);
+
 // Kx8 instances: (KC, G, U, NWAVES)
 template <class T, int KC, int G, int U, int NWAVES>
 static int dispatch_kx8_nb(int nb, const GemvParams& p, hipStream_t s) {
@@ -461,6 +504,12 @@ extern "C" int aqlm_hip_gemv_kx8(const void* codes, const void* codebooks, const
   if (!fast)
     return run_generic(codes, codebooks, scales, bias, x, y, out_features, in_features, K, 8, G, batch, xs, ys, dtype,
                        stream);
+  // batch 1, g = 8, 1 or 2 codebooks, enough rows to amortise the 64-128 KiB fill: conflict-free replicated-LDS kernel
+  const int rep = tuning().kx8_replicas;  // 1 = auto, 0 = never, 2 = whenever the shape fits
+  if (batch == 1 && G == 8 && (K == 1 || K == 2) && rep != 0 && (rep == 2 || out_features >= 2048)) {
+    const int e = gemv_kx8_replicated(codes, codebooks, scales, bias, x, y, out_features, in_features, K, dtype, stream);
+    if (e != AQLM_HIP_E_UNSUPPORTED) return e;
+  }
   GemvParams p{};
   p.codes = (const uint8_t*)codes;
   p.codebooks = (const uint8_t*)codebooks;

@@ -1,0 +1,197 @@
+// K x 8-bit (g = 8, K in {1, 2}) matvec with 16-fold replicated codebooks in LDS: conflict-free gathers.  gfx950.
+//
+// Why: in the plain K x 8 kernel (gemv.hip) every code is a random ds_read_b128 from a 4-8 KiB table.  A wave64
+// ds_read_b128 is serviced in four fixed 16-lane groups; 16 random 16-B slots collide ~3-way, so the gather runs at
+// ~5.5 lanes/clk/CU instead of 16 (measured through the packed 1x16 kernel's ablation).  With each entry
+// stored 16 times -- copy r of entry v of codebook c at 16-B slot ((c*256 + v)*16 + r) -- and lane l reading copy
+// r = l & 15, the 16 lanes of every service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) touch 16 distinct
+// slots of the 256-B bank row whatever the codes are.  This is the wave64 / 64-bank counterpart of the reference's
+// 8-fold replication for 32-lane warps (cuda_kernel.cu:168-173), derived from MI355X's service groups.
+//
+// 2 x 256 x 16 x 16 B = 128 KiB (+ the x tile) fills the LDS, so the grid is one 16-wave workgroup per CU and every
+// wave walks many rows (the 0.7 us replicated fill is paid once per CU, not once per 4 rows).  Rows are reduced four
+// at a time (7 cross-lane steps per 4 rows).  Same contract and epilogue as gemv_kernel.
+#include <algorithm>
+
+#include "aqlm_common.h"
+
+namespace aqlm {
+
+struct RepParams {
+  const uint8_t* codes;
+  const uint8_t* codebooks;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  const uint16_t* x;
+  uint16_t* y;
+  int M, in_groups, nunits, iters, pitch;
+  int rows_per_block;  // multiple of 4
+  long code_row_bytes;
+};
+
+__device__ __forceinline__ float rep_reduce4(float a, float b, float c, float d, int lane) {
+  const bool upper = lane >= 32;
+  float p = upper ? a : c, q = upper ? b : d;
+  p = __shfl_xor(p, 32, WAVE);
+  q = __shfl_xor(q, 32, WAVE);
+  const float u = (upper ? c : a) + p, v = (upper ? d : b) + q;
+  const bool odd16 = (lane & 16) != 0;
+  float w = odd16 ? u : v;
+  w = __shfl_xor(w, 16, WAVE);
+  float keep = (odd16 ? v : u) + w;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) keep += __shfl_xor(keep, o, WAVE);
+  return keep;  // lanes 0-15: a, 16-31: b, 32-47: c, 48-63: d
+}
+
+template <class T, int KC>
+__global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
+  constexpr int NT = 1024, NWAVES = 16;
+  constexpr int UB = 8 * KC;       // code bytes per unit of 8 groups
+  constexpr int CW = UB / 4;
+  constexpr int ENTRIES = KC * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* const cbl = reinterpret_cast<u32x4*>(smem_raw);   // [ENTRIES][16 replicas]
+  u32x4* const xl = cbl + ENTRIES * 16;                      // [8][pitch]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row_begin = blockIdx.x * p.rows_per_block;
+  int nrows = p.M - row_begin;
+  nrows = nrows < 0 ? 0 : (nrows < p.rows_per_block ? nrows : p.rows_per_block);
+  const int nbatches = (nrows + 3) >> 2;
+
+  // replicated codebook fill: thread t writes copy r = t & 15 of entries (t >> 4) + 64 k.  The 8 lanes of a
+  // ds_write_b128 service group then hit 8 distinct 16-B slots (conflict free); the 16 threads of an entry read the
+  // same 16 B from L2 (one request).
+  {
+    const int r = tid & 15;
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebooks);
+    u32x4 v[ENTRIES / 64];
+#pragma unroll
+    for (int k = 0; k < ENTRIES / 64; ++k) v[k] = src[(tid >> 4) + 64 * k];
+#pragma unroll
+    for (int k = 0; k < ENTRIES / 64; ++k) cbl[((tid >> 4) + 64 * k) * 16 + r] = v[k];
+  }
+  for (int q0 = tid; q0 < p.in_groups; q0 += NT * 2) {  // x: staged loads (no load-wait-store round trips)
+    u32x4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = q0 + k * NT < p.in_groups ? q0 + k * NT : p.in_groups - 1;
+      v[k] = *reinterpret_cast<const u32x4*>(p.x + (long)q * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = q0 + k * NT;
+      if (q < p.in_groups) xl[(q & 7) * p.pitch + (q >> 3)] = v[k];
+    }
+  }
+  __syncthreads();
+
+  const uint32_t rep_off = (uint32_t)(lane & 15) << 4;  // this lane's replica: conflict-free in every service group
+  const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
+  const uint8_t* const lane_base = p.codes + (long)row_begin * p.code_row_bytes + (long)lane * UB;
+
+  auto load_cw = [&](int r, int it, uint32_t (&cw)[CW]) {
+    const int u = it * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < CW; ++k) cw[k] = 0;
+    if (r < nrows && u < p.nunits) {
+      const uint8_t* ptr = lane_base + (uint32_t)r * (uint32_t)p.code_row_bytes + (uint32_t)it * 64u * UB;
+      if constexpr (CW == 4) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+        cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+      } else {
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(ptr));
+        cw[0] = v.x; cw[1] = v.y;
+      }
+    }
+  };
+
+  for (int batch = wave; batch < nbatches; batch += NWAVES) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t cw_next[CW];
+    load_cw(batch * 4, 0, cw_next);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = batch * 4 + q;
+      for (int it = 0; it < p.iters; ++it) {
+        uint32_t cw[CW];
+#pragma unroll
+        for (int k = 0; k < CW; ++k) cw[k] = cw_next[k];
+        {  // prefetch the next (row, iteration) of this batch
+          int nit = it + 1, nq = q;
+          if (nit == p.iters) { nit = 0; nq = q + 1; }
+          if (nq < 4) load_cw(batch * 4 + nq, nit, cw_next);
+        }
+        const int u = it * 64 + lane;
+        if (r < nrows && u < p.nunits) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const u32x4 xv = xl[i * p.pitch + u];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+              const uint32_t code = code_at<1>(cw, i * KC + c);
+              const u32x4 e = *reinterpret_cast<const u32x4*>(cb_bytes + ((((uint32_t)c << 8) + code) << 8) + rep_off);
+              acc[q] = dot8<T>(e, xv, acc[q]);
+            }
+          }
+        }
+      }
+    }
+    const float tot = rep_reduce4(acc[0], acc[1], acc[2], acc[3], lane);
+    const int r = batch * 4 + (lane >> 4);
+    if ((lane & 15) == 0 && r < nrows) {
+      const int row = row_begin + r;
+      const float scale = T::to_float(p.scales[row]);
+      const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+      p.y[row] = T::from_float(__builtin_fmaf(tot, scale, bias));
+    }
+  }
+}
+
+template <class T, int KC>
+static int launch_rep(const RepParams& p, int blocks, hipStream_t stream) {
+  auto kern = gemv_kx8_rep_kernel<T, KC>;
+  const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
+  static thread_local size_t granted = 0;
+  if (granted < lds) {
+    if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+      return e;
+    granted = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p);
+  return check_hip(hipGetLastError(), "gemv_kx8_rep launch");
+}
+
+// Used by aqlm_hip_gemv_kx8 for batch 1, g = 8, K in {1,2} and enough rows to amortise the replicated fill.
+// Returns AQLM_HIP_E_UNSUPPORTED when the shape does not fit (caller falls back to gemv_kernel).
+int gemv_kx8_replicated(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x,
+                        void* y, int out_features, int in_features, int num_codebooks, int dtype, hipStream_t stream) {
+  const int in_groups = in_features / 8;
+  if ((num_codebooks != 1 && num_codebooks != 2) || in_groups % 8 != 0) return AQLM_HIP_E_UNSUPPORTED;
+  RepParams p{};
+  p.codes = (const uint8_t*)codes;
+  p.codebooks = (const uint8_t*)codebooks;
+  p.scales = (const uint16_t*)scales;
+  p.bias = (const uint16_t*)bias;
+  p.x = (const uint16_t*)x;
+  p.y = (uint16_t*)y;
+  p.M = out_features;
+  p.in_groups = in_groups;
+  p.nunits = in_groups / 8;
+  p.iters = (p.nunits + 63) / 64;
+  p.pitch = p.nunits | 1;
+  p.code_row_bytes = (long)in_groups * num_codebooks;
+  const size_t lds = (size_t)num_codebooks * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
+  if (lds > 160 * 1024) return AQLM_HIP_E_UNSUPPORTED;
+  p.rows_per_block = ((out_features + 255) / 256 + 3) / 4 * 4;
+  const int blocks = (out_features + p.rows_per_block - 1) / p.rows_per_block;
+  if (dtype == AQLM_HIP_F16)
+    return num_codebooks == 1 ? launch_rep<F16, 1>(p, blocks, stream) : launch_rep<F16, 2>(p, blocks, stream);
+  return num_codebooks == 1 ? launch_rep<BF16, 1>(p, blocks, stream) : launch_rep<BF16, 2>(p, blocks, stream);
+}
+
+}  // namespace aqlm

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemv_1x16_lds_finalize(const LdsFinalizeP
   for (int k = 0; k < 8; ++k) s += p.partial[(long)k * p.M + row];
   const float scale = T::to_float(p.scales[row]);
   const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-  p.y[row] = T::from_float(s * scale + bias);
+  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
 }
 
 template <class T, int ITERS, int NWAVES, int VAR>

@@ -227,7 +227,17 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
     fetch(bst[k], l16 + 16, lo_q2[k], hi_q2[k]);
   }
 
-  for (int q = tid; q < p.in_groups; q += NT) xl[q] = *reinterpret_cast<const u32x4*>(p.x + (size_t)q * 8);
+  for (int q0 = tid; q0 < p.in_groups; q0 += NT * 2) {  // x: staged loads (no load-wait-store round trips)
+    u32x4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = q0 + k * NT < p.in_groups ? q0 + k * NT : p.in_groups - 1;
+      v[k] = *reinterpret_cast<const u32x4*>(p.x + (size_t)q * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (q0 + k * NT < p.in_groups) xl[q0 + k * NT] = v[k];
+  }
   if (tid == 0) xl[p.in_groups] = u32x4{0u, 0u, 0u, 0u};
   if constexpr (!(VAR & 4)) {
     // all loads of the 128 KiB slice are issued before the first LDS write (one memory round trip, not eight)
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const PackedFin
   for (int k = 0; k < PK_S; ++k) s += p.partial[(size_t)k * p.M + row];
   const float scale = T::to_float(p.scales[row]);
   const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-  p.y[row] = T::from_float(s * scale + bias);
+  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
 }
 
 }  // namespace aqlm

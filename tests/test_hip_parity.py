@@ -441,3 +441,30 @@ def test_quantized_linear_uses_prepacked_path_for_large_layers(hk):
     check_close(y1.float().cpu().numpy(), y64[:1], torch.float16, "module packed path")
     check_close(y2.float().cpu().numpy(), y64, torch.float16, "module direct path")
     assert "_packed_codes" not in m.state_dict()
+
+
+@pytest.mark.parametrize("K,fin,fout,dt,bias", [
+    (2, 4096, 4096, "float16", True),
+    (2, 11008, 2050, "float16", False),   # 3 iterations per row, ragged last batch of rows
+    (1, 4096, 3001, "bfloat16", True),
+    (2, 4096, 8192, "bfloat16", True),
+    (1, 8192, 2048, "float16", True),
+])
+def test_gemv_kx8_replicated_kernel(hk, K, fin, fout, dt, bias):
+    """Batch-1 K x 8 g8 layers with >= 2048 rows run the replicated-LDS kernel; it must agree with the oracle and,
+    closely, with the plain LDS kernel."""
+    from aqlm_amd import _native
+
+    dtype = tdtype(dt)
+    L = orc.make_layer(8100 + fin + fout + K, fin, fout, K, 8, 8, batch=1, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = hk.codekx8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, f"replicated {K}x8 {fin}->{fout}")
+    _native.set_tuning("kx8_replicas", 0)
+    try:
+        y_plain = hk.codekx8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    finally:
+        _native.set_tuning("kx8_replicas", 1)
+    check_close(y.float().cpu().numpy(), y_plain.float().cpu().numpy().astype(np.float64), dtype, "replicated vs plain")

@@ -365,6 +365,8 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"var=1(nosched)", "lds_variant", 1}});
       variants.push_back({{"var=2(direct store)", "lds_variant", 2}});
       variants.push_back({{"var=3", "lds_variant", 3}});
+    } else if (c.s.nbits == 8 && c.s.g == 8) {
+      variants.push_back({{"replicas=off", "kx8_replicas", 0}});
     } else if (!quick && !c.s.lds) {
       variants.push_back({{"rpw=2", "gemv_rows_per_wave", 2}});
       variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
@@ -382,7 +384,7 @@ static void bench_gemv(int argc, char** argv) {
                ab / cold * 1e-3 / 80.0);
         fflush(stdout);
       }
-      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, 0);
+      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, !strcmp(kv.key, "kx8_replicas") ? 1 : 0);
     }
     free_layers(layers);
   }
