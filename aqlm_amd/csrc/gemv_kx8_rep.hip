@@ -44,7 +44,7 @@ __device__ __forceinline__ float rep_reduce4(float a, float b, float c, float d,
   return keep;  // lanes 0-15: a, 16-31: b, 32-47: c, 48-63: d
 }
 
-template <class T, int KC>
+template <class T, int KC, int ITERS>
 __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
   constexpr int NT = 1024, NWAVES = 16;
   constexpr int UB = 8 * KC;       // code bytes per unit of 8 groups
@@ -59,7 +59,6 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
   const int row_begin = blockIdx.x * p.rows_per_block;
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.rows_per_block ? nrows : p.rows_per_block);
-  const int nbatches = (nrows + 3) >> 2;
 
   // replicated codebook fill: thread t writes copy r = t & 15 of entries (t >> 4) + 64 k.  The 8 lanes of a
   // ds_write_b128 service group then hit 8 distinct 16-B slots (conflict free); the 16 threads of an entry read the
@@ -90,40 +89,40 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
 
   const uint32_t rep_off = (uint32_t)(lane & 15) << 4;  // this lane's replica: conflict-free in every service group
   const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
-  const uint8_t* const lane_base = p.codes + (long)row_begin * p.code_row_bytes + (long)lane * UB;
 
-  auto load_cw = [&](int r, int it, uint32_t (&cw)[CW]) {
-    const int u = it * 64 + lane;
+  // Rows are dealt round-robin: in round `base`, wave w owns rows base + w + 16 q (q = 0..3).  All code words of the
+  // wave's (up to 4 x ITERS) row pieces are requested up front with clamped, always-valid addresses -- the first
+  // round even before the LDS fill -- so a wave pays ONE HBM latency per round, not one per row.
+  auto load_round = [&](int base, uint32_t (&cwq)[4][ITERS][CW]) {
 #pragma unroll
-    for (int k = 0; k < CW; ++k) cw[k] = 0;
-    if (r < nrows && u < p.nunits) {
-      const uint8_t* ptr = lane_base + (uint32_t)r * (uint32_t)p.code_row_bytes + (uint32_t)it * 64u * UB;
-      if constexpr (CW == 4) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
-        cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-      } else {
-        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(ptr));
-        cw[0] = v.x; cw[1] = v.y;
+    for (int q = 0; q < 4; ++q) {
+      int r = base + wave + 16 * q;
+      r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        int u = it * 64 + lane;
+        u = u < p.nunits ? u : p.nunits - 1;
+        const uint8_t* ptr = p.codes + ((long)row_begin + r) * p.code_row_bytes + (long)u * UB;
+        if constexpr (CW == 4) {
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+          cwq[q][it][0] = v.x; cwq[q][it][1] = v.y; cwq[q][it][2] = v.z; cwq[q][it][3] = v.w;
+        } else {
+          const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(ptr));
+          cwq[q][it][0] = v.x; cwq[q][it][1] = v.y;
+        }
       }
     }
   };
 
-  for (int batch = wave; batch < nbatches; batch += NWAVES) {
+  for (int base = 0; base < nrows; base += 64) {
+    uint32_t cwq[4][ITERS][CW];
+    load_round(base, cwq);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    uint32_t cw_next[CW];
-    load_cw(batch * 4, 0, cw_next);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int r = batch * 4 + q;
-      for (int it = 0; it < p.iters; ++it) {
-        uint32_t cw[CW];
+      const int r = base + wave + 16 * q;
 #pragma unroll
-        for (int k = 0; k < CW; ++k) cw[k] = cw_next[k];
-        {  // prefetch the next (row, iteration) of this batch
-          int nit = it + 1, nq = q;
-          if (nit == p.iters) { nit = 0; nq = q + 1; }
-          if (nq < 4) load_cw(batch * 4 + nq, nit, cw_next);
-        }
+      for (int it = 0; it < ITERS; ++it) {
         const int u = it * 64 + lane;
         if (r < nrows && u < p.nunits) {
 #pragma unroll
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
             const u32x4 xv = xl[i * p.pitch + u];
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-              const uint32_t code = code_at<1>(cw, i * KC + c);
+              const uint32_t code = code_at<1>(cwq[q][it], i * KC + c);
               const u32x4 e = *reinterpret_cast<const u32x4*>(cb_bytes + ((((uint32_t)c << 8) + code) << 8) + rep_off);
               acc[q] = dot8<T>(e, xv, acc[q]);
             }
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
       }
     }
     const float tot = rep_reduce4(acc[0], acc[1], acc[2], acc[3], lane);
-    const int r = batch * 4 + (lane >> 4);
+    const int r = base + wave + 16 * (lane >> 4);
     if ((lane & 15) == 0 && r < nrows) {
       const int row = row_begin + r;
       const float scale = T::to_float(p.scales[row]);
@@ -150,9 +149,9 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
   }
 }
 
-template <class T, int KC>
-static int launch_rep(const RepParams& p, int blocks, hipStream_t stream) {
-  auto kern = gemv_kx8_rep_kernel<T, KC>;
+template <class T, int KC, int ITERS>
+static int launch_rep_i(const RepParams& p, int blocks, hipStream_t stream) {
+  auto kern = gemv_kx8_rep_kernel<T, KC, ITERS>;
   const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
   static thread_local size_t granted = 0;
   if (granted < lds) {
@@ -164,6 +163,15 @@ static int launch_rep(const RepParams& p, int blocks, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p);
   return check_hip(hipGetLastError(), "gemv_kx8_rep launch");
+}
+
+template <class T, int KC>
+static int launch_rep(const RepParams& p, int blocks, hipStream_t stream) {
+  switch (p.iters) {
+    case 1: return launch_rep_i<T, KC, 1>(p, blocks, stream);
+    case 2: return launch_rep_i<T, KC, 2>(p, blocks, stream);
+    default: return launch_rep_i<T, KC, 3>(p, blocks, stream);
+  }
 }
 
 // Used by aqlm_hip_gemv_kx8 for batch 1, g = 8, K in {1,2} and enough rows to amortise the replicated fill.
@@ -186,7 +194,7 @@ int gemv_kx8_replicated(const void* codes, const void* codebooks, const void* sc
   p.pitch = p.nunits | 1;
   p.code_row_bytes = (long)in_groups * num_codebooks;
   const size_t lds = (size_t)num_codebooks * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
-  if (lds > 160 * 1024) return AQLM_HIP_E_UNSUPPORTED;
+  if (lds > 160 * 1024 || p.iters > 3) return AQLM_HIP_E_UNSUPPORTED;  // in_features <= 12288
   p.rows_per_block = ((out_features + 255) / 256 + 3) / 4 * 4;
   const int blocks = (out_features + p.rows_per_block - 1) / p.rows_per_block;
   if (dtype == AQLM_HIP_F16)

@@ -452,19 +452,20 @@ def test_quantized_linear_uses_prepacked_path_for_large_layers(hk):
 ])
 def test_gemv_kx8_replicated_kernel(hk, K, fin, fout, dt, bias):
     """Batch-1 K x 8 g8 layers with >= 2048 rows run the replicated-LDS kernel; it must agree with the oracle and,
-    closely, with the plain LDS kernel."""
+    closely, with the plain LDS kernel.  (Default routing: >= 4096 rows.)"""
     from aqlm_amd import _native
 
     dtype = tdtype(dt)
     L = orc.make_layer(8100 + fin + fout + K, fin, fout, K, 8, 8, batch=1, bias=bias,
                        float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
     T = to_dev(L, dtype)
-    y = hk.codekx8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
-    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-    check_close(y.float().cpu().numpy(), y64, dtype, f"replicated {K}x8 {fin}->{fout}")
-    _native.set_tuning("kx8_replicas", 0)
+    _native.set_tuning("kx8_replicas", 2)   # force the replicated kernel whatever the row count
     try:
+        y = hk.codekx8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+        _native.set_tuning("kx8_replicas", 0)
         y_plain = hk.codekx8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
     finally:
         _native.set_tuning("kx8_replicas", 1)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, f"replicated {K}x8 {fin}->{fout}")
     check_close(y.float().cpu().numpy(), y_plain.float().cpu().numpy().astype(np.float64), dtype, "replicated vs plain")

@@ -367,6 +367,7 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"var=3", "lds_variant", 3}});
     } else if (c.s.nbits == 8 && c.s.g == 8) {
       variants.push_back({{"replicas=off", "kx8_replicas", 0}});
+      variants.push_back({{"replicas=force", "kx8_replicas", 2}});
     } else if (!quick && !c.s.lds) {
       variants.push_back({{"rpw=2", "gemv_rows_per_wave", 2}});
       variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
