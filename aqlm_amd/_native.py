@@ -19,6 +19,7 @@ MAX_GEMV_BATCH = 8
 OP_GEMM_1X16_MFMA = 1
 OP_GEMV_1X16_LDS = 2
 OP_GEMV_1X16_PACKED = 3
+OP_GEMV_8X8_LUT = 4
 
 _vp, _ci, _cl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 
@@ -32,6 +33,7 @@ SIGNATURES = {
     "aqlm_hip_prepack_1x16_bytes": (_sz, [_ci, _ci, _ci]),
     "aqlm_hip_prepack_1x16": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_1x16_packed": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_8x8_lut": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_dequant_1x16": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_dequant_kx8": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]),

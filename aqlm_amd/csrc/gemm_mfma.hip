@@ -423,7 +423,13 @@ static int launch_gemm(const GemmParams& p, int nbt, hipStream_t stream) {
 
 using namespace aqlm;
 
+namespace aqlm {
+size_t gemv_8x8_lut_workspace(int out_features, int in_features, int in_group_size);
+}
+
 extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features) {
+  if (op == AQLM_HIP_OP_GEMV_8X8_LUT && batch > 0 && out_features > 0 && in_features > 0 && in_features % batch == 0)
+    return aqlm::gemv_8x8_lut_workspace(out_features, in_features, /*in_group_size=*/batch);
   if (batch <= 0 || out_features <= 0 || in_features <= 0) return 0;
   if (op == AQLM_HIP_OP_GEMV_1X16_LDS || op == AQLM_HIP_OP_GEMV_1X16_PACKED) return (size_t)8 * out_features * sizeof(float);
   if (op != AQLM_HIP_OP_GEMM_1X16_MFMA) return 0;

@@ -1,0 +1,233 @@
+// 8 x 8-bit matvec (any g multiple of 8, e.g. the 2-bit 8x8 g32 scheme) through per-token look-up tables in LDS.  gfx950.
+//
+// Why: with 8 codebooks of 256 x g the direct kernel (gemv.hip) reads 8 x g/8 x 16 B of LDS and issues 8 x g/2
+// v_dot2c per input group -- 16 B of LDS traffic per weight at g = 32, 4x the 2x8 scheme -- and ran at 3.5 % of the HBM
+// roofline (15 us for 4096x4096).  The reference's CPU kernel avoids exactly this with
+//     lut[j, c, v] = < codebooks[c, v], x_j >      ;      y[i] = sum_{j, c} lut[j, c, codes[i, j, c]]
+// (numba_kernel.py:37-48).  On the GPU the table of one token is in_groups x 8 x 256 fp32 = 1 MiB (in = 4096): too big
+// for one CU, so the input groups are cut into slabs of 16 (16 x 8 x 256 x 4 B = 128 KiB of LDS): workgroup
+// (slab, row range) builds its slab of the table (a [2048 x g] x [g x 16] product, on the matrix cores), then every quarter-wave walks rows: lane = one input group = 8 code bytes = 8 ds_read_b32 + 8 adds.  fp32
+// partials [slab][row] -> finalize (sum over slabs, scale, bias, one rounding).  Per code: one 4-B LDS read and one
+// add instead of g/8 ds_read_b128 and g/2 v_dot2c.  Arithmetic is the same fp32 accumulation of exact fp16/bf16
+// products, in a different association order.
+#include <algorithm>
+
+#include "aqlm_common.h"
+
+namespace aqlm {
+
+constexpr int LUT_KC = 8;
+constexpr int LUT_JS = 16;                       // input groups per slab
+constexpr int LUT_ENTRIES = LUT_JS * LUT_KC * 256;  // 32768 fp32 = 128 KiB
+
+typedef _Float16 lut_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lut_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class T>
+__device__ __forceinline__ f32x4 lut_mfma16(const u32x4& a, const u32x4& b, const f32x4& c);
+template <>
+__device__ __forceinline__ f32x4 lut_mfma16<F16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lut_f16x8, a), __builtin_bit_cast(lut_f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 lut_mfma16<BF16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lut_bf16x8, a), __builtin_bit_cast(lut_bf16x8, b), c, 0, 0, 0);
+}
+
+struct LutParams {
+  const uint8_t* codes;      // [M][in_groups][8]
+  const uint16_t* codebooks; // [8][256][G]
+  const uint16_t* x;
+  float* partial;            // [nslabs][M]
+  int M, in_groups, nslabs, nranges, rows_per_range;
+};
+
+template <class T, int G>
+__global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
+  constexpr int NT = 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* const lut = reinterpret_cast<float*>(smem_raw);  // [16 groups][8 codebooks][256]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, quarter = lane >> 4;
+  const int slab = blockIdx.x % p.nslabs, range = blockIdx.x / p.nslabs;
+  const int j0 = slab * LUT_JS;
+  const int row_begin = range * p.rows_per_range;
+  int nrows = p.M - row_begin;
+  nrows = nrows < 0 ? 0 : (nrows < p.rows_per_range ? nrows : p.rows_per_range);
+
+  // code bytes of this quarter-wave's first rows go in flight before the table is built (clamped, unconditional)
+  const int jmine = j0 + l16 < p.in_groups ? j0 + l16 : p.in_groups - 1;
+  const bool group_ok = j0 + l16 < p.in_groups;
+  const int r0 = wave * 4 + quarter;  // rows r0, r0 + 64, ...
+  auto load_codes = [&](int r) -> u32x2 {
+    const int rc = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+    return __builtin_nontemporal_load(
+        reinterpret_cast<const u32x2*>(p.codes + (((long)row_begin + rc) * p.in_groups + jmine) * 8));
+  };
+  u32x2 cq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cq[k] = load_codes(r0 + 64 * k);
+
+  // ---- table on the matrix cores: lut[jl][cv] = sum_k cb[cv][k] * x[j0+jl][k] is a [2048 x g] x [g x 16] product.
+  // v_mfma_f32_16x16x32: A = 16 (c,v) rows x 32 k (lane l: row l%16, 8 k of piece l/16), B = x of the 16 groups
+  // (lane l: group l%16, same piece), D[row (l/16)*4 + r][group l%16] -> 4 consecutive table entries = one 16-B LDS
+  // write.  g < 32 pads k with zero pieces.  128 tiles per workgroup, 8 per wave (the VALU version of this build cost
+  // 3.4 us per workgroup).
+  {
+    constexpr int P = G / 8;  // pieces of 8 k per vector: 1, 2 or 4
+    const int col = lane & 15, kg = lane >> 4;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const int jb = j0 + col < p.in_groups ? j0 + col : p.in_groups - 1;
+    const u32x4 bfrag = kg < P ? reinterpret_cast<const u32x4*>(p.x + (size_t)jb * G)[kg] : zero;
+    u32x4 afrag[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int cv = (wave * 8 + t) * 16 + col;  // this lane's A row
+      afrag[t] = kg < P ? reinterpret_cast<const u32x4*>(p.codebooks + (size_t)cv * G)[kg] : zero;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 d = lut_mfma16<T>(afrag[t], bfrag, f32x4{0.f, 0.f, 0.f, 0.f});
+      const int cv0 = (wave * 8 + t) * 16 + kg * 4;
+      *reinterpret_cast<f32x4*>(lut + col * (LUT_KC * 256) + cv0) = d;
+    }
+  }
+  __syncthreads();
+
+  // ---- rows: lane = input group j0 + l16 (8 code bytes), quarter-wave = one row
+  const float* const my = lut + l16 * (LUT_KC * 256);
+  float* const out = p.partial + (size_t)slab * p.M + row_begin;
+  for (int rbase = r0; __any(rbase < nrows); rbase += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rbase + 64 * k;
+      const u32x2 cw = cq[k];
+      cq[k] = load_codes(r + 256);  // next round's codes for this slot
+      float acc = 0.f;
+      if (group_ok) {
+        acc += my[0 * 256 + (cw.x & 0xffu)];
+        acc += my[1 * 256 + ((cw.x >> 8) & 0xffu)];
+        acc += my[2 * 256 + ((cw.x >> 16) & 0xffu)];
+        acc += my[3 * 256 + (cw.x >> 24)];
+        acc += my[4 * 256 + (cw.y & 0xffu)];
+        acc += my[5 * 256 + ((cw.y >> 8) & 0xffu)];
+        acc += my[6 * 256 + ((cw.y >> 16) & 0xffu)];
+        acc += my[7 * 256 + (cw.y >> 24)];
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+      if (l16 == 0 && r < nrows) out[r] = acc;
+    }
+  }
+}
+
+struct LutFinalizeParams {
+  const float* partial;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  int M, nslabs;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gemv_8x8_lut_finalize(const LutFinalizeParams p) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.M) return;
+  float s = 0.f;
+  for (int k = 0; k < p.nslabs; ++k) s += p.partial[(size_t)k * p.M + row];
+  const float scale = T::to_float(p.scales[row]);
+  const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
+}
+
+size_t gemv_8x8_lut_workspace(int out_features, int in_features, int in_group_size) {
+  const int in_groups = in_features / in_group_size;
+  const int nslabs = (in_groups + LUT_JS - 1) / LUT_JS;
+  return (size_t)nslabs * out_features * sizeof(float);
+}
+
+template <class T, int G>
+static int launch_lut(const LutParams& p, hipStream_t stream) {
+  auto kern = gemv_8x8_lut_kernel<T, G>;
+  const size_t lds = (size_t)LUT_ENTRIES * 4;
+  static thread_local bool granted = false;
+  if (!granted) {
+    if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+      return e;
+    granted = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.nslabs * p.nranges), dim3(1024), lds, stream, p);
+  return check_hip(hipGetLastError(), "gemv_8x8_lut launch");
+}
+
+// batch-1 8x8 matvec through LDS look-up tables; AQLM_HIP_E_UNSUPPORTED when the shape does not fit
+int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x, void* y,
+                 int out_features, int in_features, int in_group_size, int dtype, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream) {
+  const int G = in_group_size;
+  if (G != 8 && G != 16 && G != 32) return AQLM_HIP_E_UNSUPPORTED;
+  LutParams p{};
+  p.codes = (const uint8_t*)codes;
+  p.codebooks = (const uint16_t*)codebooks;
+  p.x = (const uint16_t*)x;
+  p.partial = (float*)workspace;
+  p.M = out_features;
+  p.in_groups = in_features / G;
+  p.nslabs = (p.in_groups + LUT_JS - 1) / LUT_JS;
+  if (workspace_bytes < (size_t)p.nslabs * out_features * sizeof(float) || !workspace) return AQLM_HIP_E_INVALID;
+  p.nranges = std::max(1, 256 / p.nslabs);
+  p.rows_per_range = (out_features + p.nranges - 1) / p.nranges;
+  int e;
+  if (dtype == AQLM_HIP_F16)
+    e = G == 8 ? launch_lut<F16, 8>(p, stream) : G == 16 ? launch_lut<F16, 16>(p, stream) : launch_lut<F16, 32>(p, stream);
+  else
+    e = G == 8 ? launch_lut<BF16, 8>(p, stream) : G == 16 ? launch_lut<BF16, 16>(p, stream) : launch_lut<BF16, 32>(p, stream);
+  if (e) return e;
+  LutFinalizeParams f{};
+  f.partial = (const float*)workspace;
+  f.scales = (const uint16_t*)scales;
+  f.bias = (const uint16_t*)bias;
+  f.y = (uint16_t*)y;
+  f.M = out_features;
+  f.nslabs = p.nslabs;
+  if (dtype == AQLM_HIP_F16)
+    hipLaunchKernelGGL(gemv_8x8_lut_finalize<F16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
+  else
+    hipLaunchKernelGGL(gemv_8x8_lut_finalize<BF16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
+  return check_hip(hipGetLastError(), "gemv_8x8_lut_finalize launch");
+}
+
+}  // namespace aqlm
+
+using namespace aqlm;
+
+extern "C" int aqlm_hip_gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias,
+                                     const void* x, void* y, int out_features, int in_features, int in_group_size,
+                                     int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!codes || !codebooks || !scales || !x || !y) {
+    set_last_error("aqlm_hip_gemv_8x8_lut: null pointer argument");
+    return AQLM_HIP_E_INVALID;
+  }
+  if (out_features <= 0 || in_features <= 0 || in_group_size <= 0 || in_features % in_group_size != 0) {
+    set_last_error("aqlm_hip_gemv_8x8_lut: bad sizes out=%d in=%d g=%d", out_features, in_features, in_group_size);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
+    set_last_error("aqlm_hip_gemv_8x8_lut: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)", dtype);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (!aligned16(codebooks) || !aligned16(x) || (reinterpret_cast<uintptr_t>(codes) & 7u)) {
+    set_last_error("aqlm_hip_gemv_8x8_lut: misaligned buffer");
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  const int e = gemv_8x8_lut(codes, codebooks, scales, bias, x, y, out_features, in_features, in_group_size, dtype,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+  if (e == AQLM_HIP_E_UNSUPPORTED) set_last_error("aqlm_hip_gemv_8x8_lut: in_group_size %d not in {8,16,32}", in_group_size);
+  if (e == AQLM_HIP_E_INVALID) set_last_error("aqlm_hip_gemv_8x8_lut: workspace too small or null");
+  return e;
+}

@@ -197,11 +197,40 @@ def code1x8_matmat(input, codes, codebooks, scales, bias=None):
     return _gemv(input, codes, codebooks, scales, bias, "kx8")
 
 
+# single-row 8 x 8-bit matvecs use per-token look-up tables in LDS (aqlm_hip_gemv_8x8_lut) instead of LDS gathers
+USE_8X8_LUT = True
+
+
+def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
+    dt = _dtype_id(input)
+    g = codebooks.shape[3]
+    out_features, in_features = codes.shape[0], codes.shape[1] * g
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _flat_rows(input)
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
+    ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
+    ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.aqlm_hip_gemv_8x8_lut(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                        x.data_ptr(), y.data_ptr(), out_features, in_features, g, dt, ws.data_ptr(),
+                                        ws_bytes, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm gemv_8x8_lut")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
 def codekx8_matmat(input, codes, codebooks, scales, bias=None):
     """Any K x 8-bit scheme (e.g. 8x8 g32): the HIP replacement for the reference's Triton fallback
     (kernel_selector.py:91-94, triton_kernel.py:187-205)."""
     if codebooks.shape[1] != 256:
         raise NotImplementedError(f"codekx8_matmat needs 256-entry codebooks, got {tuple(codebooks.shape)}")
+    if (USE_8X8_LUT and codebooks.shape[0] == 8 and codebooks.shape[2] == 1 and codebooks.shape[3] in (8, 16, 32)
+            and input.numel() == input.shape[-1] and input.dtype == codebooks.dtype):
+        return _gemv_8x8_lut(input, codes, codebooks, scales, bias)
     return _gemv(input, codes, codebooks, scales, bias, "kx8")
 
 

@@ -88,6 +88,13 @@ class Layer:
             rc = lib.aqlm_hip_gemv_1x16_packed(self.packed.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(),
                                                None, self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g,
                                                _native.F16, self.ws.data_ptr(), self.ws.numel() * 4, stream)
+        elif batch == 1 and self.K == 8 and self.nbits == 8:
+            if getattr(self, "lut_ws", None) is None:
+                n = lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, self.g, self.fout, self.fin)
+                self.lut_ws = torch.empty((n // 4,), dtype=torch.float32, device=self.codes.device)
+            rc = lib.aqlm_hip_gemv_8x8_lut(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
+                                           self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, _native.F16,
+                                           self.lut_ws.data_ptr(), self.lut_ws.numel() * 4, stream)
         elif self.nbits == 16:
             rc = lib.aqlm_hip_gemv_1x16(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                         self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, batch,

@@ -148,9 +148,22 @@ int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codebook, const vo
                               const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Batch-1 matvec for 8 x 8-bit schemes (e.g. the 2-bit 8x8 g32 models; in_group_size 8, 16 or 32) through per-token
+ * look-up tables in LDS:  lut[j,c,v] = <codebooks[c,v], x_j>,  y[i] = sum lut[j,c,codes[i,j,c]]  -- the formulation of
+ * the reference's CPU kernel (numba_kernel.py:37-48) mapped onto LDS slabs.  Same result contract as aqlm_hip_gemv_kx8
+ * (which it replaces for num_codebooks == 8; reference route: triton_kernel.py).  workspace:
+ * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_8X8_LUT, in_group_size, out, in) bytes  [note: the `batch` slot carries
+ * in_group_size for this op].
+ */
+int aqlm_hip_gemv_8x8_lut(const void* codes_i8, const void* codebooks, const void* scales, const void* bias,
+                          const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_LDS 2
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3
+#define AQLM_HIP_OP_GEMV_8X8_LUT 4
 size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);
 
 /*

@@ -469,3 +469,27 @@ def test_gemv_kx8_replicated_kernel(hk, K, fin, fout, dt, bias):
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
     check_close(y.float().cpu().numpy(), y64, dtype, f"replicated {K}x8 {fin}->{fout}")
     check_close(y.float().cpu().numpy(), y_plain.float().cpu().numpy().astype(np.float64), dtype, "replicated vs plain")
+
+
+@pytest.mark.parametrize("g,fin,fout,dt,bias", [
+    (32, 4096, 4096, "float16", True),
+    (32, 11008, 1000, "float16", False),   # 344 groups: last slab half empty; ragged row ranges
+    (32, 4096, 37, "bfloat16", True),
+    (8, 1024, 512, "float16", True),
+    (16, 2048, 300, "bfloat16", True),
+])
+def test_gemv_8x8_lut(hk, g, fin, fout, dt, bias):
+    """Look-up-table kernel for 8 x 8-bit schemes vs the oracle and vs the direct LDS-gather kernel."""
+    dtype = tdtype(dt)
+    L = orc.make_layer(4400 + fin + fout + g, fin, fout, 8, 8, g, batch=1, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = hk._gemv_8x8_lut(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, f"lut 8x8g{g} {fin}->{fout}")
+    yd = hk._gemv(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "kx8")
+    check_close(y.float().cpu().numpy(), yd.float().cpu().numpy().astype(np.float64), dtype, "lut vs gather kernel")
+    assert torch.equal(y, hk.codekx8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]))  # default route
+    if bias:
+        yz = hk._gemv_8x8_lut(torch.zeros_like(T["x"]), T["codes"], T["codebooks"], T["scales"], T["bias"])
+        assert torch.equal(yz[0], T["bias"])

@@ -229,6 +229,7 @@ struct Scheme {
   int K, nbits, g;
   bool lds = false;  // route 1x16 through aqlm_hip_gemv_1x16_lds
   bool packed = false;  // route 1x16 through aqlm_hip_gemv_1x16_packed
+  bool lut = false;     // route 8x8 through aqlm_hip_gemv_8x8_lut
 };
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -241,6 +242,8 @@ static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
 }
 
 static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st) {
+  if (s.lut)
+    return aqlm_hip_gemv_8x8_lut(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16 && s.packed)
     return aqlm_hip_gemv_1x16_packed(L.packed, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16 && s.lds)
@@ -317,17 +320,18 @@ static void free_layers(std::vector<Layer>& v) {
 }
 
 static void bench_gemv(int argc, char** argv) {
-  g_ws_bytes = (size_t)8 * 32768 * 4;
+  g_ws_bytes = (size_t)32 * 32768 * 4;
   CK(hipMalloc(&g_ws, g_ws_bytes));
   const Scheme S1x16L{"1x16g8L", 1, 16, 8, true};
   const Scheme S1x16P{"1x16g8P", 1, 16, 8, false, true};
+  const Scheme S8x8L{"8x8g32LUT", 8, 8, 32, false, false, true};
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
   std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672},
                              {S1x16L, 4096, 4096}, {S1x16L, 4096, 11008}, {S1x16L, 4096, 14336}, {S1x16L, 14336, 4096}, {S1x16L, 4096, 1024}, {S1x16L, 8192, 28672},
                              {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
                              {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
-                             {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}};
+                             {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}, {S8x8L, 4096, 4096}, {S8x8L, 4096, 11008}, {S8x8L, 11008, 4096}};
   const bool quick = argc > 2 && !strcmp(argv[2], "quick");
   const char* only = argc > 3 ? argv[3] : nullptr;  // run only schemes whose name contains this
   const int only_out = argc > 4 ? atoi(argv[4]) : 0;
