@@ -19,11 +19,12 @@ from .utils import get_int_dtype
 # rows (batch * seq) at or below which the gemv op is used; the reference's value (inference.py:95-96)
 GEMV_MAX_ROWS = 6
 
-# Single-row 1x16 g8 matvecs of layers with at least this many output rows run on slice-bucketed ("prepacked")
-# codes (aqlm_hip_gemv_1x16_packed): 1.6-3x faster than the direct L2-gather kernel on MI355X for large layers, at the
-# price of a one-off repack at first use and 1.55x the code bytes kept next to the original codes.  0 disables.
-# Measured crossover ~4400 rows; the default leaves 4096-row layers on the direct kernel.
-PREPACK_MIN_OUT_FEATURES = 8192
+# Single-row 1x16 g8 matvecs of layers with at least this many codes (out_features * in_features / 8) run on
+# slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): 1.7-3x faster than the direct L2-gather kernel on
+# MI355X for large layers, at the price of a one-off repack at first use and 1.55x the code bytes kept next to the
+# original codes.  0 disables.  Measured: the packed path costs ~7 us more per call than the direct kernel and ~3.2 ps
+# less per code, i.e. it wins above ~2.2 M codes (4096x4096 is a tie, 4096->11008 and 14336->4096 are 1.75-1.9x).
+PREPACK_MIN_CODES = 3_000_000
 
 
 class QuantizedLinear(nn.Module):
@@ -97,7 +98,7 @@ class QuantizedLinear(nn.Module):
         # load-time re-layout of the codes for the decode kernel (the reference does the analogous thing for its CPU
         # kernel here, inference.py:78-83 -- but in place; we keep `codes` untouched and add a derived buffer)
         self._packed_codes = None
-        if (PREPACK_MIN_OUT_FEATURES and self.out_features >= PREPACK_MIN_OUT_FEATURES and self.num_codebooks == 1
+        if (PREPACK_MIN_CODES and self.out_features * (self.in_features // 8) >= PREPACK_MIN_CODES and self.num_codebooks == 1
                 and self.nbits_per_codebook == 16 and self.in_group_size == 8 and self.out_group_size == 1
                 and self.codes.is_cuda and self.codebooks.dtype in (torch.float16, torch.bfloat16)):
             from .inference_kernels import hip_kernel

@@ -34,9 +34,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# 1x16 g8 layers with at least this many output rows run the prepacked (slice-bucketed) decode kernel, like
-# aqlm_amd.inference.PREPACK_MIN_OUT_FEATURES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
-PACK_MIN_OUT = 8192
+# 1x16 g8 layers with at least this many codes run the prepacked (slice-bucketed) decode kernel, like
+# aqlm_amd.inference.PREPACK_MIN_CODES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
+PACK_MIN_OUT = 3_000_000
 
 
 def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
@@ -62,7 +62,7 @@ class Layer:
         self.y = torch.empty((batch, fout), device=device, dtype=torch.float16)
         self.bytes = algorithmic_bytes(fin, fout, K, nbits, g, batch)
         self.packed = None
-        if PACK_MIN_OUT and (K, nbits, g) == (1, 16, 8) and fout >= PACK_MIN_OUT:
+        if PACK_MIN_OUT and (K, nbits, g) == (1, 16, 8) and fout * (fin // 8) >= PACK_MIN_OUT:
             from aqlm_amd import _native
 
             self.prepack(_native.lib)
@@ -357,7 +357,7 @@ def main():
         "config": {"workload": "decode step = 32 blocks x {4096->4096, 4096->11008} 1x16g8 matvec, bs=1, 64 distinct "
                                "layers (own codes + codebook), 564 MB algorithmic bytes/step, hipGraph replay",
                    "scheme": "1x16g8", "batch": 1, "layers_per_step": step.n, "algorithmic_bytes_per_step": step.bytes,
-                   "kernels": ("direct L2-gather gemv for out<8192, prepacked slice-bucketed gemv for out>=8192"
+                   "kernels": ("direct L2-gather gemv below 3 M codes per layer (4096->4096), prepacked slice-bucketed gemv above (4096->11008)"
                                if PACK_MIN_OUT else "direct L2-gather gemv"),
                    "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
         "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
