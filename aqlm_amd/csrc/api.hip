@@ -32,9 +32,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "gemv_rows_per_wave")) return &t.gemv_rows_per_wave;
   if (!strcmp(key, "gemv1x16_aux")) return &t.gemv1x16_aux;
   if (!strcmp(key, "gemv1x16_prefetch_cb")) return &t.gemv1x16_prefetch_cb;
-  if (!strcmp(key, "gemv1x16_xreg")) return &t.gemv1x16_xreg;
   if (!strcmp(key, "kx8_replicas")) return &t.kx8_replicas;
-  if (!strcmp(key, "lds_variant")) return &t.lds_variant;
   if (!strcmp(key, "gemm_splitk_free")) return &t.gemm_splitk_free;
   if (!strcmp(key, "force_generic")) return &t.force_generic;
   return nullptr;

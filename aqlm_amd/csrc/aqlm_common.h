@@ -92,9 +92,7 @@ struct Tuning {
   int gemv_rows_per_wave = 0;    // 0 = heuristic
   int gemv1x16_aux = AUX_DEFAULT;  // cache policy of the codebook gathers: 0 default, 1 sc0, 2 nt, 16 sc1
   int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
-  int gemv1x16_xreg = 0;         // reserved
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
-  int lds_variant = 0;           // experiment switch of the slice-scan kernel
   int gemm_splitk_free = 0;      // 1: large-batch 1x16 op uses the split-K-free 16x16x32 kernel when in % 256 == 0
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
 };

@@ -45,7 +45,6 @@ struct LutParams {
 
 template <class T, int G>
 __global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
-  constexpr int NT = 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* const lut = reinterpret_cast<float*>(smem_raw);  // [16 groups][8 codebooks][256]
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ float rep_reduce4(float a, float b, float c, float d,
 
 template <class T, int KC, int ITERS>
 __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
-  constexpr int NT = 1024, NWAVES = 16;
+  constexpr int NT = 1024;
   constexpr int UB = 8 * KC;       // code bytes per unit of 8 groups
   constexpr int CW = UB / 4;
   constexpr int ENTRIES = KC * 256;

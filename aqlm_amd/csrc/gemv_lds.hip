@@ -54,11 +54,10 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
 
 // LDS map (16-B units): [0, 8192) codebook slice | 8192: one all-zero entry | then x as [i][unit] rows of `pitch` |
 // then rows_per_group floats of per-row accumulators.
-template <class T, int ITERS, int NWAVES, int VAR>
+template <class T, int ITERS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_lds_kernel(const LdsGemvParams p) {
   constexpr int NT = NWAVES * 64;
   constexpr int SLICE_ENTRIES = 8192;              // 128 KiB of 16-B entries
-  constexpr uint32_t ZOFF = SLICE_ENTRIES * 16;    // byte offset of the zero entry
   constexpr int NWS = NWAVES / ITERS;              // waves that share one `it`
   static_assert(NWAVES % ITERS == 0, "waves must split evenly over the iterations");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -139,21 +138,19 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_lds_kernel(const LdsGem
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (m[i]) e[i] = *reinterpret_cast<const u32x4*>(cb_bytes + off[i]);
-      if constexpr (!(VAR & 1)) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (m[i]) acc[q] = dot8<T>(e[i], xr[i], acc[q]);
-      if constexpr (!(VAR & 1)) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const float tot = wave_reduce4(acc[0], acc[1], acc[2], acc[3], lane);
     const int r = batch * 4 + (lane >> 4);
     if ((lane & 15) == 0 && r < nrows) {
-      if constexpr (ITERS == 1 && (VAR & 2)) p.partial[(long)slice * p.M + row_begin + r] = tot;
-      else if constexpr (ITERS == 1) rowacc[r] = tot;   // single writer per row
+      if constexpr (ITERS == 1) rowacc[r] = tot;   // single writer per row
       else atomicAdd(&rowacc[r], tot);             // ds_add_f32: ITERS waves contribute to a row
     }
   }
-  if constexpr (ITERS == 1 && (VAR & 2)) return;
   __syncthreads();
   for (int r = tid; r < nrows; r += NT) p.partial[(long)slice * p.M + row_begin + r] = rowacc[r];
 }
@@ -178,9 +175,9 @@ __global__ __launch_bounds__(256) void gemv_1x16_lds_finalize(const LdsFinalizeP
   p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
 }
 
-template <class T, int ITERS, int NWAVES, int VAR>
-static int launch_lds_v(const LdsGemvParams& p, hipStream_t stream) {
-  auto kern = gemv_1x16_lds_kernel<T, ITERS, NWAVES, VAR>;
+template <class T, int ITERS, int NWAVES>
+static int launch_lds(const LdsGemvParams& p, hipStream_t stream) {
+  auto kern = gemv_1x16_lds_kernel<T, ITERS, NWAVES>;
   const size_t lds = (size_t)(8192 + 1 + 8 * p.pitch) * 16 + (size_t)p.rows_per_group * 4;
   static thread_local size_t granted = 0;
   if (granted < lds) {
@@ -192,16 +189,6 @@ static int launch_lds_v(const LdsGemvParams& p, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3(256), dim3(NWAVES * 64), lds, stream, p);
   return check_hip(hipGetLastError(), "gemv_1x16_lds launch");
-}
-
-template <class T, int ITERS, int NWAVES>
-static int launch_lds(const LdsGemvParams& p, hipStream_t stream) {
-  switch (tuning().lds_variant & 3) {
-    case 1: return launch_lds_v<T, ITERS, NWAVES, 1>(p, stream);
-    case 2: return launch_lds_v<T, ITERS, NWAVES, 2>(p, stream);
-    case 3: return launch_lds_v<T, ITERS, NWAVES, 3>(p, stream);
-    default: return launch_lds_v<T, ITERS, NWAVES, 0>(p, stream);
-  }
 }
 
 }  // namespace aqlm

@@ -174,7 +174,7 @@ __device__ __forceinline__ float packed_entry(uint32_t lo, uint32_t hi, const un
   return dot8<T>(e, xv, acc);
 }
 
-template <class T, int NWAVES, int PD, int VAR>
+template <class T, int NWAVES, int PD>
 __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
   constexpr int NT = NWAVES * 64;
   constexpr int STRIDE = NWAVES * 4;  // rows between two consecutive rows of one quarter-wave
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
       if (q0 + k * NT < p.in_groups) xl[q0 + k * NT] = v[k];
   }
   if (tid == 0) xl[p.in_groups] = u32x4{0u, 0u, 0u, 0u};
-  if constexpr (!(VAR & 4)) {
+  {
     // all loads of the 128 KiB slice are issued before the first LDS write (one memory round trip, not eight)
     const u32x4* src = reinterpret_cast<const u32x4*>(p.codebook) + (size_t)slice * PK_SLICE_ENTRIES;
     constexpr int PER = PK_SLICE_ENTRIES / NT;
@@ -255,10 +255,6 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
   const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
   const unsigned char* const x_bytes = reinterpret_cast<const unsigned char*>(xl);
   auto consume = [&](const u32x2& lo, uint32_t hi, float acc) -> float {
-    if constexpr (VAR & 1) {  // ablation: no LDS gathers
-      const u32x4 fake = {lo.x, lo.y, hi, lo.x ^ hi};
-      return dot8<T>(fake, fake, acc);
-    }
     acc = packed_entry<T, 0, 0>(lo.x, hi, cb_bytes, x_bytes, acc);
     acc = packed_entry<T, 16, 8>(lo.x, hi, cb_bytes, x_bytes, acc);
     acc = packed_entry<T, 0, 16>(lo.y, hi, cb_bytes, x_bytes, acc);
@@ -270,7 +266,6 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
   while (__any(r < nrows)) {
 #pragma unroll
     for (int s6 = 0; s6 < NB2; ++s6) {  // no early exit: a single back-edge keeps every in-flight load in place
-      constexpr int dummy = 0; (void)dummy;
       const int es = s6 % PD;
       const uint32_t st = bst[s6], en = ben[s6];
       const u32x2 lo = lo_q[es], lo2 = lo_q2[es];
@@ -289,10 +284,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
         fetch(st, c, lo3, hi3);
         if (c < nchunks) acc = consume(lo3, hi3, acc);
       }
-      if constexpr (!(VAR & 2)) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
-      }
+      for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
       if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + r] = acc;
       r += STRIDE;
     }
@@ -417,16 +410,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
     hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
-  int e;
-  if (dtype == AQLM_HIP_BF16) e = launch(gemv_1x16_packed_kernel<BF16, NW, 3, 0>);
-  else switch (tuning().lds_variant & 7) {  // ablation switches (experiments only; results are wrong for != 0)
-    case 1: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 1>); break;
-    case 2: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 2>); break;
-    case 3: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 3>); break;
-    case 4: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 4>); break;
-    case 7: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 7>); break;
-    default: e = launch(gemv_1x16_packed_kernel<F16, NW, 3, 0>); break;
-  }
+  const int e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3>);
   if (e) return e;
   PackedFinalizeParams f{};
   f.partial = (const float*)workspace;

@@ -360,15 +360,7 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
     } else if (c.s.packed) {
-      variants.push_back({{"abl=1(no lds gather)", "lds_variant", 1}});
-      variants.push_back({{"abl=2(no reduce)", "lds_variant", 2}});
-      variants.push_back({{"abl=3", "lds_variant", 3}});
-      variants.push_back({{"abl=4(no cb fill)", "lds_variant", 4}});
-      variants.push_back({{"abl=7(skeleton)", "lds_variant", 7}});
     } else if (c.s.lds) {
-      variants.push_back({{"var=1(nosched)", "lds_variant", 1}});
-      variants.push_back({{"var=2(direct store)", "lds_variant", 2}});
-      variants.push_back({{"var=3", "lds_variant", 3}});
     } else if (c.s.nbits == 8 && c.s.g == 8) {
       variants.push_back({{"replicas=off", "kx8_replicas", 0}});
       variants.push_back({{"replicas=force", "kx8_replicas", 2}});
