@@ -499,3 +499,22 @@ def test_gemv_8x8_lut(hk, g, fin, fout, dt, bias):
     if bias:
         yz = hk._gemv_8x8_lut(torch.zeros_like(T["x"]), T["codes"], T["codebooks"], T["scales"], T["bias"])
         assert torch.equal(yz[0], T["bias"])
+
+
+def test_ops_trace_under_torch_compile(hk):
+    """torch.ops.aqlm.* carry fake impls (like cuda_kernel.py:20-22), so Dynamo traces a QuantizedLinear without
+    graph breaks -- what the reference's CUDA-graph notebook relies on (notebooks/aqlm_cuda_graph.ipynb)."""
+    import torch._dynamo as dynamo
+
+    L = orc.make_layer(71, 1024, 256, 1, 16, 8, batch=1, bias=True)
+    m, T = _module_from(L, 1, 16, 8, 1024, 256, torch.float16)
+    m(T["x"])  # resolve the kernels eagerly first (lazy prepare_matmul_op)
+    explanation = dynamo.explain(lambda x: torch.ops.aqlm.code1x16_matmat(x, m.codes, m.codebooks, m.scales, m.bias))(T["x"])
+    assert explanation.graph_break_count == 0, explanation.break_reasons
+    ops = [str(n.target) for g in explanation.graphs for n in g.graph.nodes if n.op == "call_function"]
+    assert any("code1x16_matmat" in o for o in ops), ops
+    compiled = torch.compile(lambda x: torch.ops.aqlm.code1x16_matmat(x, m.codes, m.codebooks, m.scales, m.bias) * 2.0,
+                             backend="eager", fullgraph=True)
+    y = compiled(T["x"])
+    ref = torch.ops.aqlm.code1x16_matmat(T["x"], m.codes, m.codebooks, m.scales, m.bias) * 2.0
+    assert torch.equal(y, ref)
