@@ -1,6 +1,6 @@
 #!/bin/bash
 set +e
-OUT=gpurun_out/call4
+OUT=gpurun_out/call7
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
