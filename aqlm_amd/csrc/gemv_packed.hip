@@ -17,8 +17,8 @@
 //   rowoff[(g*S + s)*(RG+1) + r] = global index of the first entry of row r of stream (g, s); slot RG closes the
 //   stream.  ~3.07 bytes per code + 4 bytes per (row, slice): 1.55x the canonical 2 bytes per code.
 //
-// Kernel: grid = 256 workgroups = 32 groups x 8 slices (the 8 slices of a group share bid % 8, observed = the XCD,
-// for speed only).  Workgroup (g, s): slice s of the codebook and x go to LDS; each quarter-wave (16 lanes) owns one
+// Kernel: grid = 256 workgroups = 32 groups x 8 slices (slice = bid % 8 = the XCD the block is observed to land on, so
+// each XCD's L2 holds one slice; for speed only).  Workgroup (g, s): slice s of the codebook and x go to LDS; each quarter-wave (16 lanes) owns one
 // row of the group at a time; a lane takes 4 consecutive entries of that row's bucket per step (the typical 64-entry
 // bucket is one step): per entry 2 ds_read_b128 (codebook entry, x[j]) + 4 v_dot2c.  Entry loads run PD rows ahead.  fp32 partials [slice][row] -> workspace -> finalize kernel
 // (adds the 8 slices, scale + bias, one rounding).  Every lane does useful work (no scan, no 8x re-read of codes).
@@ -185,9 +185,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, quarter = lane >> 4;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int slice = local & 7;
-  const int group = xcd * 4 + (local >> 3);
+  // slice = blockIdx % 8: blocks are observed to land on XCD blockIdx % 8, so each XCD's L2 serves ONE 128 KiB slice
+  // (fetched once) instead of the whole codebook (speed only; any placement is correct).  Workgroups of one row-group
+  // share nothing -- each walks its own bucket stream -- so they need not be co-located.
+  const int slice = blockIdx.x & 7;
+  const int group = blockIdx.x >> 3;
   const int row_begin = group * p.RG;
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
