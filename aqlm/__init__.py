@@ -42,6 +42,7 @@ if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
 
 from aqlm_amd import QuantizedLinear, __version__, optimize_for_training  # noqa: E402,F401
 from aqlm_amd import get_backward_pass_kernel, get_forward_pass_kernel  # noqa: E402,F401
+from aqlm_amd import SharedInputGroup, fuse_shared_input_linears, unfuse_shared_input_linears  # noqa: E402,F401
 
 inference = importlib.import_module(__name__ + ".inference")
 utils = importlib.import_module(__name__ + ".utils")

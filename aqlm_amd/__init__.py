@@ -4,6 +4,7 @@ Drop-in for the reference's ``aqlm`` package on that one path (the top-level ``a
 re-exports these names so that ``from aqlm import QuantizedLinear`` -- what Hugging Face does -- resolves here).
 """
 from . import inference_kernels
+from .fusion import SharedInputGroup, fuse_shared_input_linears, unfuse_shared_input_linears
 from .inference import QuantizedLinear
 from .inference_kernels import get_backward_pass_kernel, get_forward_pass_kernel, optimize_for_training
 
@@ -15,4 +16,7 @@ __all__ = [
     "get_forward_pass_kernel",
     "optimize_for_training",
     "inference_kernels",
+    "SharedInputGroup",
+    "fuse_shared_input_linears",
+    "unfuse_shared_input_linears",
 ]

@@ -21,13 +21,27 @@ OP_GEMV_1X16_LDS = 2
 OP_GEMV_1X16_PACKED = 3
 OP_GEMV_8X8_LUT = 4
 
+MAX_SEGMENTS = 4
+
 _vp, _ci, _cl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+
+
+class Segment(ctypes.Structure):
+    """aqlm_hip_segment (include/aqlm_hip.h): one layer of a shared-input launch."""
+
+    _fields_ = [("codes", _vp), ("codebook", _vp), ("scales", _vp), ("bias", _vp), ("y", _vp),
+                ("y_row_stride", _cl), ("out_features", _ci), ("reserved", _ci)]
+
+
+_segp = ctypes.POINTER(Segment)
 
 # name -> (restype, argtypes); mirrors include/aqlm_hip.h one to one
 SIGNATURES = {
     "aqlm_hip_abi_version": (_ci, []),
     "aqlm_hip_last_error": (ctypes.c_char_p, []),
     "aqlm_hip_gemv_1x16": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
+    "aqlm_hip_gemv_1x16_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _cl, _ci, _vp]),
+    "aqlm_hip_gemv_1x16_packed_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_lds": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_prepack_1x16_bytes": (_sz, [_ci, _ci, _ci]),

@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "aqlm_common.h"
 
 namespace aqlm {
@@ -19,6 +23,22 @@ int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
   set_last_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
   return (int)e;
+}
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  if (int e = check_hip(hipGetDevice(&dev), "hipGetDevice")) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[{kernel, dev}];
+  if (have >= bytes) return 0;
+  if (int e = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+    return e;
+  have = bytes;
+  return 0;
 }
 
 Tuning& tuning() {

@@ -87,6 +87,9 @@ __device__ __forceinline__ uint32_t code_at(const uint32_t (&cw)[N], int idx) {
 // ---------------------------------------------------------------------------------------------
 void set_last_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
+// Raise a kernel's dynamic-LDS limit (needed above the 64 KiB default) once per (kernel, device): a process may drive
+// several GPUs (device_map="auto"), and the attribute is per device.  Returns 0 or an error code.
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 struct Tuning {
   int gemv_rows_per_wave = 0;    // 0 = heuristic

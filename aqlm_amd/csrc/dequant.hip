@@ -122,16 +122,7 @@ template <class T, int CODE_BYTES, int KC, int G, bool CB_LDS, int NT>
 static int launch_dequant(const DequantParams& p, hipStream_t stream) {
   auto kern = dequant_kernel<T, CODE_BYTES, KC, G, CB_LDS, NT>;
   const size_t lds = CB_LDS ? (size_t)KC * 256 * G * 2 : 0;
-  if (lds > 48 * 1024) {
-    static thread_local bool granted = false;
-    if (!granted) {
-      if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
-        return e;
-      granted = true;
-    }
-  }
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   long need = (p.total_groups + NT - 1) / NT;
   // LDS-resident codebooks: persistent blocks amortise the fill; L2 gathers: plenty of small blocks
   const long cap = CB_LDS ? (lds > 48 * 1024 ? 256 : 256 * 8) : 256 * 32;

@@ -57,8 +57,9 @@ __device__ __forceinline__ void load_code_word(const uint8_t* p, uint32_t (&cw)[
 
 // T: F16/BF16; CODE_BYTES: 1|2; KC: codebooks; G: in_group_size; U: groups per lane-unit; NB: batch rows;
 // CB_LDS: codebooks in LDS (Kx8) or L2 gathers (1x16); NWAVES: waves per block; AUX: gather cache policy.
+// `block` is the workgroup's index within its own code matrix (== blockIdx.x for a single-matrix launch).
 template <class T, int CODE_BYTES, int KC, int G, int U, int NB, bool CB_LDS, int NWAVES, int AUX>
-__global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
+__device__ __forceinline__ void gemv_body(const GemvParams& p, const int block) {
   constexpr int P = G / 8;                  // 16-B pieces per codebook vector
   constexpr int UB = U * KC * CODE_BYTES;   // code bytes per unit
   constexpr int CW = UB / 4;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int row0 = (blockIdx.x * NWAVES + wave) * p.rpw;
+  const int row0 = (block * NWAVES + wave) * p.rpw;
   int nrows = p.M - row0;
   nrows = nrows < p.rpw ? nrows : p.rpw;
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
   if constexpr (!CB_LDS) {
     if (p.prefetch) {
       const int nchunks = p.cb_bytes >> 14;  // 16 KiB chunks
-      const int chunk = (blockIdx.x >> 3) % (nchunks > 0 ? nchunks : 1);
+      const int chunk = (block >> 3) % (nchunks > 0 ? nchunks : 1);
       const u32x4* src = reinterpret_cast<const u32x4*>(p.codebooks + ((long)chunk << 14));
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -236,6 +237,53 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
   for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(pf[k]));
 }
 
+template <class T, int CODE_BYTES, int KC, int G, int U, int NB, bool CB_LDS, int NWAVES, int AUX>
+__global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
+  gemv_body<T, CODE_BYTES, KC, G, U, NB, CB_LDS, NWAVES, AUX>(p, blockIdx.x);
+}
+
+// Several code matrices that multiply the SAME x (q/k/v, gate/up of a decoder layer) in one launch: every workgroup
+// belongs to one segment (own codes, codebook, scales, bias, y) and runs the unchanged body on it, so results are
+// bit-identical to separate launches.  One launch instead of 2-3 removes the ~2 us dependent-launch gaps and lets the
+// segments' ramp-up / tail overlap.
+struct GemvSegment {
+  const uint8_t* codes;
+  const uint8_t* codebooks;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  long ys;
+  int M;
+  int block_begin;
+};
+
+struct GemvMultiParams {
+  GemvParams common;  // x, geometry; per-segment fields are overwritten in the kernel
+  int nseg;
+  GemvSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+template <class T, int CODE_BYTES, int KC, int G, int U, int NB, bool CB_LDS, int NWAVES, int AUX>
+__global__ __launch_bounds__(NWAVES * 64) void gemv_multi_kernel(const GemvMultiParams mp) {
+  GemvParams p = mp.common;
+  int begin = 0;
+  // scalar select chain (no dynamic indexing of the kernel-argument struct)
+#pragma unroll
+  for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
+    if (k == 0 || (k < mp.nseg && (int)blockIdx.x >= mp.seg[k].block_begin)) {
+      p.codes = mp.seg[k].codes;
+      p.codebooks = mp.seg[k].codebooks;
+      p.scales = mp.seg[k].scales;
+      p.bias = mp.seg[k].bias;
+      p.y = mp.seg[k].y;
+      p.ys = mp.seg[k].ys;
+      p.M = mp.seg[k].M;
+      begin = mp.seg[k].block_begin;
+    }
+  }
+  gemv_body<T, CODE_BYTES, KC, G, U, NB, CB_LDS, NWAVES, AUX>(p, (int)blockIdx.x - begin);
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic kernel: any scheme, any alignment.  One wave per row, lanes stride over input groups.
 // The role triton_kernel.py plays in the reference (kernel_selector.py:91-94).
@@ -303,20 +351,32 @@ static int launch_gemv(const GemvParams& p, hipStream_t stream) {
     set_last_error("gemv: LDS request %zu B exceeds 160 KiB", lds);
     return AQLM_HIP_E_UNSUPPORTED;
   }
-  if (lds > 48 * 1024) {
-    static thread_local size_t granted = 0;  // per instantiation
-    if (granted < lds) {
-      int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-      if (e) return e;
-      granted = lds;
-    }
-  }
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   const int rows_per_block = NWAVES * p.rpw;
   const int blocks = (p.M + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVES * 64), lds, stream, p);
   return check_hip(hipGetLastError(), "gemv launch");
+}
+
+template <class T, int CODE_BYTES, int KC, int G, int U, int NB, bool CB_LDS, int NWAVES, int AUX>
+static int launch_gemv_multi(GemvMultiParams& mp, hipStream_t stream) {
+  constexpr int P = G / 8;
+  auto kern = gemv_multi_kernel<T, CODE_BYTES, KC, G, U, NB, CB_LDS, NWAVES, AUX>;
+  size_t lds = (size_t)NB * U * P * mp.common.pitch * 16;
+  if (CB_LDS) lds += (size_t)KC * 256 * G * 2;
+  if (lds > 160 * 1024) {
+    set_last_error("gemv_multi: LDS request %zu B exceeds 160 KiB", lds);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+  const int rows_per_block = NWAVES * mp.common.rpw;
+  int blocks = 0;
+  for (int k = 0; k < mp.nseg; ++k) {
+    mp.seg[k].block_begin = blocks;
+    blocks += (mp.seg[k].M + rows_per_block - 1) / rows_per_block;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVES * 64), lds, stream, mp);
+  return check_hip(hipGetLastError(), "gemv_multi launch");
 }
 
 template <int U>
@@ -402,6 +462,16 @@ static int launch_1x16(const GemvParams& p, hipStream_t s) {
 }
 
 template <class T, int G>
+static int dispatch_1x16_multi_nb(int nb, GemvMultiParams& mp, hipStream_t s) {
+  switch (nb) {
+    case 1: return launch_gemv_multi<T, 2, 1, G, 8, 1, false, 4, AUX_DEFAULT>(mp, s);
+    case 2: return launch_gemv_multi<T, 2, 1, G, 8, 2, false, 4, AUX_DEFAULT>(mp, s);
+    case 4: return launch_gemv_multi<T, 2, 1, G, 8, 4, false, 4, AUX_DEFAULT>(mp, s);
+    default: return launch_gemv_multi<T, 2, 1, G, 8, 8, false, 4, AUX_DEFAULT>(mp, s);
+  }
+}
+
+template <class T, int G>
 static int dispatch_1x16_nb(int nb, const GemvParams& p, hipStream_t s) {
   switch (nb) {
     case 1: return launch_1x16<T, G, 1>(p, s);
@@ -456,6 +526,74 @@ extern "C" int aqlm_hip_gemv_1x16(const void* codes, const void* codebook, const
       e = in_group_size == 8 ? dispatch_1x16_nb<F16, 8>(nb, p, stream) : dispatch_1x16_nb<F16, 16>(nb, p, stream);
     else
       e = in_group_size == 8 ? dispatch_1x16_nb<BF16, 8>(nb, p, stream) : dispatch_1x16_nb<BF16, 16>(nb, p, stream);
+    if (e) return e;
+    done += nb;
+  }
+  return 0;
+}
+
+extern "C" int aqlm_hip_gemv_1x16_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                        int in_features, int in_group_size, int batch, long xs, int dtype,
+                                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!segments || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS) {
+    set_last_error("aqlm_hip_gemv_1x16_multi: 1..%d segments required, got %d", AQLM_HIP_MAX_SEGMENTS, num_segments);
+    return AQLM_HIP_E_INVALID;
+  }
+  long total_rows = 0;
+  bool fast = true;
+  for (int k = 0; k < num_segments; ++k) {
+    const aqlm_hip_segment& sg = segments[k];
+    if (int e = validate_common(sg.codes, sg.codebook, sg.scales, x, sg.y, sg.out_features, in_features, in_group_size,
+                                batch, dtype, "aqlm_hip_gemv_1x16_multi"))
+      return e;
+    total_rows += sg.out_features;
+    fast = fast && aligned16(sg.codes) && aligned16(sg.codebook);
+  }
+  if (in_group_size != 8 && in_group_size != 16) {
+    set_last_error("aqlm_hip_gemv_1x16_multi: only codebooks with 8 or 16 features are supported, got %d", in_group_size);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  const int in_groups = in_features / in_group_size;
+  const size_t x_row_bytes = (size_t)in_features * 2;
+  fast = fast && !tuning().force_generic && (in_groups % 8 == 0) && aligned16(x) && (xs % 8 == 0) &&
+         x_row_bytes <= kMaxXTileBytes;
+  if (!fast) {  // same results, one launch per segment
+    for (int k = 0; k < num_segments; ++k) {
+      const aqlm_hip_segment& sg = segments[k];
+      if (int e = aqlm_hip_gemv_1x16(sg.codes, sg.codebook, sg.scales, sg.bias, x, sg.y, sg.out_features, in_features,
+                                     in_group_size, batch, xs, sg.y_row_stride, dtype, stream_))
+        return e;
+    }
+    return 0;
+  }
+  GemvMultiParams mp{};
+  mp.nseg = num_segments;
+  GemvParams& p = mp.common;
+  p.xs = xs;
+  p.code_row_bytes = (long)in_groups * 2;
+  p.cb_bytes = 65536 * in_group_size * 2;
+  p.prefetch = tuning().gemv1x16_prefetch_cb;
+  finish_params<8>(p, in_groups, (int)std::min<long>(total_rows, 1 << 30), 4 * 4096);
+  int done = 0;
+  while (done < batch) {
+    const int nb = pick_nb(batch - done, x_row_bytes);
+    p.x = (const uint16_t*)x + (long)done * xs;
+    for (int k = 0; k < num_segments; ++k) {
+      const aqlm_hip_segment& sg = segments[k];
+      mp.seg[k].codes = (const uint8_t*)sg.codes;
+      mp.seg[k].codebooks = (const uint8_t*)sg.codebook;
+      mp.seg[k].scales = (const uint16_t*)sg.scales;
+      mp.seg[k].bias = (const uint16_t*)sg.bias;
+      mp.seg[k].y = (uint16_t*)sg.y + (long)done * sg.y_row_stride;
+      mp.seg[k].ys = sg.y_row_stride;
+      mp.seg[k].M = sg.out_features;
+    }
+    int e;
+    if (dtype == AQLM_HIP_F16)
+      e = in_group_size == 8 ? dispatch_1x16_multi_nb<F16, 8>(nb, mp, stream) : dispatch_1x16_multi_nb<F16, 16>(nb, mp, stream);
+    else
+      e = in_group_size == 8 ? dispatch_1x16_multi_nb<BF16, 8>(nb, mp, stream) : dispatch_1x16_multi_nb<BF16, 16>(nb, mp, stream);
     if (e) return e;
     done += nb;
   }

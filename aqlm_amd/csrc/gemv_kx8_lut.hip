@@ -152,14 +152,7 @@ template <class T, int G>
 static int launch_lut(const LutParams& p, hipStream_t stream) {
   auto kern = gemv_8x8_lut_kernel<T, G>;
   const size_t lds = (size_t)LUT_ENTRIES * 4;
-  static thread_local bool granted = false;
-  if (!granted) {
-    if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
-      return e;
-    granted = true;
-  }
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   hipLaunchKernelGGL(kern, dim3(p.nslabs * p.nranges), dim3(1024), lds, stream, p);
   return check_hip(hipGetLastError(), "gemv_8x8_lut launch");
 }

@@ -153,14 +153,7 @@ template <class T, int KC, int ITERS>
 static int launch_rep_i(const RepParams& p, int blocks, hipStream_t stream) {
   auto kern = gemv_kx8_rep_kernel<T, KC, ITERS>;
   const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
-  static thread_local size_t granted = 0;
-  if (granted < lds) {
-    if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
-      return e;
-    granted = lds;
-  }
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p);
   return check_hip(hipGetLastError(), "gemv_kx8_rep launch");
 }

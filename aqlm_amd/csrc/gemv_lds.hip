@@ -179,14 +179,7 @@ template <class T, int ITERS, int NWAVES>
 static int launch_lds(const LdsGemvParams& p, hipStream_t stream) {
   auto kern = gemv_1x16_lds_kernel<T, ITERS, NWAVES>;
   const size_t lds = (size_t)(8192 + 1 + 8 * p.pitch) * 16 + (size_t)p.rows_per_group * 4;
-  static thread_local size_t granted = 0;
-  if (granted < lds) {
-    if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
-      return e;
-    granted = lds;
-  }
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(NWAVES * 64), lds, stream, p);
   return check_hip(hipGetLastError(), "gemv_1x16_lds launch");
 }

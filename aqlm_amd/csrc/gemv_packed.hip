@@ -174,8 +174,9 @@ __device__ __forceinline__ float packed_entry(uint32_t lo, uint32_t hi, const un
   return dot8<T>(e, xv, acc);
 }
 
+// `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
 template <class T, int NWAVES, int PD>
-__global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
+__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
   constexpr int NT = NWAVES * 64;
   constexpr int STRIDE = NWAVES * 4;  // rows between two consecutive rows of one quarter-wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
   // slice = blockIdx % 8: blocks are observed to land on XCD blockIdx % 8, so each XCD's L2 serves ONE 128 KiB slice
   // (fetched once) instead of the whole codebook (speed only; any placement is correct).  Workgroups of one row-group
   // share nothing -- each walks its own bucket stream -- so they need not be co-located.
-  const int slice = blockIdx.x & 7;
-  const int group = blockIdx.x >> 3;
+  const int slice = block & 7;
+  const int group = block >> 3;
   const int row_begin = group * p.RG;
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
@@ -292,6 +293,56 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
       r += STRIDE;
     }
   }
+  // (An in-kernel finalize -- last-arriving slice workgroup of a row-group adds the eight partials -- was measured:
+  // with __threadfence() it costs +80 us (the agent-scope buffer_inv throws away the L2 lines every other workgroup of
+  // the XCD is streaming through); with write-through sc1 stores / sc1 loads and no fence it is correct but exactly as
+  // slow as the separate finalize launch, +-0.3 us on every shape.  Hence the plain two-kernel form.)
+}
+
+template <class T, int NWAVES, int PD>
+__global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
+  gemv_1x16_packed_body<T, NWAVES, PD>(p, blockIdx.x);
+}
+
+// Several prepacked layers that multiply the same x (gate/up) in one launch of 256 workgroups per layer; the second
+// layer's workgroups start as CUs free up, so the first layer's tail and the second's LDS fill overlap.
+struct PackedSegment {
+  const uint32_t* rowoff;
+  const uint16_t* lo16;
+  const uint8_t* hi8;
+  const uint8_t* codebook;
+  float* partial;
+  int M, RG;
+  uint32_t lo16_bytes, hi8_bytes;
+};
+
+struct PackedMultiParams {
+  const uint16_t* x;
+  int in_groups, nseg;
+  PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+template <class T, int NWAVES, int PD>
+__global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_multi_kernel(const PackedMultiParams mp) {
+  const int sidx = (int)blockIdx.x >> 8;
+  PackedGemvParams p{};
+  p.x = mp.x;
+  p.in_groups = mp.in_groups;
+#pragma unroll
+  for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
+    if (k == 0 || sidx == k) {  // scalar select chain (no dynamic indexing of the kernel-argument struct)
+      p.rowoff = mp.seg[k].rowoff;
+      p.lo16 = mp.seg[k].lo16;
+      p.hi8 = mp.seg[k].hi8;
+      p.codebook = mp.seg[k].codebook;
+      p.partial = mp.seg[k].partial;
+      p.M = mp.seg[k].M;
+      p.RG = mp.seg[k].RG;
+      p.lo16_bytes = mp.seg[k].lo16_bytes;
+      p.hi8_bytes = mp.seg[k].hi8_bytes;
+    }
+  }
+  gemv_1x16_packed_body<T, NWAVES, PD>(p, (int)blockIdx.x & 255);
 }
 
 struct PackedFinalizeParams {
@@ -305,6 +356,37 @@ struct PackedFinalizeParams {
 template <class T>
 __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const PackedFinalizeParams p) {
   const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.M) return;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < PK_S; ++k) s += p.partial[(size_t)k * p.M + row];
+  const float scale = T::to_float(p.scales[row]);
+  const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
+}
+
+struct PackedFinalizeSegment {
+  PackedFinalizeParams f;
+  int block_begin;
+};
+
+struct PackedFinalizeMultiParams {
+  int nseg;
+  PackedFinalizeSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const PackedFinalizeMultiParams mp) {
+  PackedFinalizeParams p = mp.seg[0].f;
+  int begin = 0;
+#pragma unroll
+  for (int k = 1; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
+    if (k < mp.nseg && (int)blockIdx.x >= mp.seg[k].block_begin) {
+      p = mp.seg[k].f;
+      begin = mp.seg[k].block_begin;
+    }
+  }
+  const int row = ((int)blockIdx.x - begin) * 256 + threadIdx.x;
   if (row >= p.M) return;
   float s = 0.f;
 #pragma unroll
@@ -401,14 +483,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 1) * 16;
   constexpr int NW = 16;
   auto launch = [&](auto kern) -> int {
-    static thread_local size_t granted = 0;
-    if (granted < lds) {
-      if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
-        return e;
-      granted = lds;
-    }
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
     hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
@@ -425,4 +500,80 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   else
     hipLaunchKernelGGL(gemv_1x16_packed_finalize<BF16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
   return check_hip(hipGetLastError(), "gemv_1x16_packed_finalize launch");
+}
+
+extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                               int in_features, int in_group_size, int dtype, void* workspace,
+                                               size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!segments || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS || !x) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi: 1..%d segments and a non-null x required (got %d)",
+                   AQLM_HIP_MAX_SEGMENTS, num_segments);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)",
+                   dtype);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  PackedMultiParams mp{};
+  PackedFinalizeMultiParams fm{};
+  mp.x = (const uint16_t*)x;
+  mp.nseg = fm.nseg = num_segments;
+  size_t need = 0;
+  int fblocks = 0;
+  for (int k = 0; k < num_segments; ++k) {
+    const aqlm_hip_segment& sg = segments[k];
+    if (!sg.codes || !sg.codebook || !sg.scales || !sg.y) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi: null pointer in segment %d", k);
+      return AQLM_HIP_E_INVALID;
+    }
+    PackedLayout L;
+    if (!packed_layout(sg.out_features, in_features, in_group_size, L) || !aligned16(sg.codes) ||
+        !aligned16(sg.codebook) || !aligned16(x)) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi: unsupported shape or misaligned buffer (segment %d, g=%d in=%d)",
+                     k, in_group_size, in_features);
+      return AQLM_HIP_E_UNSUPPORTED;
+    }
+    const uint8_t* base = (const uint8_t*)sg.codes;
+    PackedSegment& ps = mp.seg[k];
+    ps.rowoff = (const uint32_t*)(base + L.off_rowoff);
+    ps.lo16 = (const uint16_t*)(base + L.off_lo16);
+    ps.hi8 = base + L.off_hi8;
+    ps.codebook = (const uint8_t*)sg.codebook;
+    ps.partial = (float*)((uint8_t*)workspace + need);
+    ps.M = L.M;
+    ps.RG = L.RG;
+    ps.lo16_bytes = (uint32_t)((L.entries + PK_PAD) * 2);
+    ps.hi8_bytes = (uint32_t)(L.entries + PK_PAD);
+    mp.in_groups = L.in_groups;
+    PackedFinalizeSegment& fs = fm.seg[k];
+    fs.f.partial = ps.partial;
+    fs.f.scales = (const uint16_t*)sg.scales;
+    fs.f.bias = (const uint16_t*)sg.bias;
+    fs.f.y = (uint16_t*)sg.y;
+    fs.f.M = sg.out_features;
+    fs.block_begin = fblocks;
+    fblocks += (sg.out_features + 255) / 256;
+    need += (size_t)PK_S * sg.out_features * sizeof(float);
+  }
+  if (!workspace || workspace_bytes < need) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return AQLM_HIP_E_INVALID;
+  }
+  const size_t lds = (size_t)(PK_SLICE_ENTRIES + mp.in_groups + 1) * 16;
+  constexpr int NW = 16;
+  auto launch = [&](auto kern) -> int {
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(256 * num_segments), dim3(NW * 64), lds, stream, mp);
+    return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
+  };
+  const int e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3>)
+                                      : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3>);
+  if (e) return e;
+  if (dtype == AQLM_HIP_F16)
+    hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);
+  else
+    hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<BF16>, dim3(fblocks), dim3(256), 0, stream, fm);
+  return check_hip(hipGetLastError(), "gemv_1x16_packed_finalize_multi launch");
 }

@@ -1,0 +1,121 @@
+"""Shared-input launches for decoder layers.
+
+The q/k/v projections (and gate/up) of a decoder layer multiply the same hidden state.  The reference issues one
+``code1x16_matmat`` per projection (inference.py:68-76 -> cuda_kernel.cpp:148-182); on MI355X a single-row matvec of a
+<= 4096-row layer is bounded by launch + memory-latency floors, so running the 2-3 projections in ONE launch
+(``aqlm_hip_gemv_1x16_multi`` / ``aqlm_hip_gemv_1x16_packed_multi``) removes most of that cost.
+
+``fuse_shared_input_linears(model)`` groups sibling ``QuantizedLinear`` modules by name; the modules stay in place
+(same parameters, same state_dict), Hugging Face's modeling code keeps calling ``q_proj(x)``, ``k_proj(x)``,
+``v_proj(x)`` one after the other: the first call launches the whole group and parks the siblings' outputs, the
+following calls on the *same tensor object* pick theirs up.  Outputs are bit-identical to the unfused modules.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .inference import GEMV_MAX_ROWS, QuantizedLinear
+
+DEFAULT_PATTERNS: Tuple[Tuple[str, ...], ...] = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))
+MAX_MEMBERS = 4  # AQLM_HIP_MAX_SEGMENTS
+
+
+def _version(t: torch.Tensor) -> int:
+    try:
+        return t._version
+    except RuntimeError:  # inference tensors carry no version counter (and cannot be modified in place outside
+        return 0          # inference mode anyway)
+
+
+class SharedInputGroup:
+    """2..4 ``QuantizedLinear`` modules (1x16 scheme, equal in_features / in_group_size / dtype / device) that are
+    always applied to the same input."""
+
+    def __init__(self, members: Sequence[QuantizedLinear]):
+        members = list(members)
+        if not (2 <= len(members) <= MAX_MEMBERS):
+            raise ValueError(f"a shared-input group has 2..{MAX_MEMBERS} members, got {len(members)}")
+        first = members[0]
+        for m in members:
+            if not isinstance(m, QuantizedLinear):
+                raise TypeError(f"shared-input groups hold QuantizedLinear modules, got {type(m).__name__}")
+            if (m.num_codebooks, m.nbits_per_codebook, m.out_group_size) != (1, 16, 1) or m.in_group_size not in (8, 16):
+                raise NotImplementedError("shared-input launches cover the 1x16 scheme (in_group_size 8 or 16)")
+            if (m.in_features, m.in_group_size) != (first.in_features, first.in_group_size):
+                raise ValueError("members of a shared-input group must agree on in_features and in_group_size")
+            if m.codebooks.dtype != first.codebooks.dtype or m.codebooks.device != first.codebooks.device:
+                raise ValueError("members of a shared-input group must share dtype and device")
+        self.members: List[QuantizedLinear] = members
+        self._input: Optional[torch.Tensor] = None
+        self._version = -1
+        self._pending: Dict[int, torch.Tensor] = {}
+        self.launches = 0  # statistics: fused launches issued / outputs served from a previous launch
+        self.served = 0
+
+    def applicable(self, input: torch.Tensor) -> bool:
+        if not input.is_cuda or math.prod(input.shape[:-1]) > GEMV_MAX_ROWS:
+            return False
+        if torch.is_grad_enabled() and input.requires_grad:
+            return False
+        return not torch.compiler.is_compiling()
+
+    def forward(self, member: QuantizedLinear, input: torch.Tensor) -> torch.Tensor:
+        idx = next(i for i, m in enumerate(self.members) if m is member)
+        if self._input is input and self._version == _version(input) and idx in self._pending:
+            out = self._pending.pop(idx)
+            if not self._pending:
+                self._input = None
+            self.served += 1
+            return out
+        outs = self._launch(input)
+        self._input, self._version = input, _version(input)  # the reference keeps `input` alive while outputs are parked
+        self._pending = {i: o for i, o in enumerate(outs) if i != idx}
+        self.launches += 1
+        return outs[idx]
+
+    def _launch(self, input: torch.Tensor) -> List[torch.Tensor]:
+        from .inference_kernels import hip_kernel
+
+        ms = self.members
+        for m in ms:
+            if m.gemv_op is None:
+                m.prepare_matmul_op(input)
+        if input.numel() == ms[0].in_features and all(m._packed_codes is not None for m in ms):
+            return hip_kernel.code1x16_matmat_packed_multi(
+                input, [m._packed_codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms],
+                [m.bias for m in ms], [m.out_features for m in ms])
+        return torch.ops.aqlm.code1x16_matmat_multi(
+            input, [m.codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms], [m.bias for m in ms])
+
+
+def fuse_shared_input_linears(model: nn.Module,
+                              patterns: Iterable[Sequence[str]] = DEFAULT_PATTERNS) -> List[SharedInputGroup]:
+    """Group sibling ``QuantizedLinear`` children named like one of ``patterns`` (default: q/k/v and gate/up) under
+    every sub-module of ``model``.  Siblings that cannot share a launch (other scheme, different in_features) are left
+    alone.  Returns the groups created.  Idempotent; ``unfuse_shared_input_linears`` undoes it."""
+    groups = []
+    for parent in model.modules():
+        for names in patterns:
+            members = [getattr(parent, n, None) for n in names]
+            if not all(isinstance(m, QuantizedLinear) for m in members):
+                continue
+            if any(getattr(m, "_shared_input_group", None) is not None for m in members):
+                continue
+            try:
+                group = SharedInputGroup(members)
+            except (NotImplementedError, ValueError):
+                continue
+            for m in members:
+                m._shared_input_group = group
+            groups.append(group)
+    return groups
+
+
+def unfuse_shared_input_linears(model: nn.Module) -> None:
+    for m in model.modules():
+        if isinstance(m, QuantizedLinear):
+            m._shared_input_group = None

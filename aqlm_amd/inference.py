@@ -67,12 +67,16 @@ class QuantizedLinear(nn.Module):
         self.gemm_op = None
         self.use_gemv_rule = None
         self._packed_codes = None  # derived, never saved: rebuilt from `codes` at first use
+        self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
 
     def extra_repr(self) -> str:
         return (f"in_features={self.in_features}, out_features={self.out_features}, scheme="
                 f"{self.num_codebooks}x{self.nbits_per_codebook}g{self.in_group_size}, bias={self.bias is not None}")
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        group = self._shared_input_group
+        if group is not None and group.applicable(input):
+            return group.forward(self, input)  # one launch for all projections of this input (fusion.py)
         if self.gemv_op is None:
             self.prepare_matmul_op(input)
         if self._packed_codes is not None and input.numel() == self.in_features and not (

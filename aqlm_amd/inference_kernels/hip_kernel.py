@@ -169,6 +169,86 @@ def code1x16_matmat_packed(input, packed, codebooks, scales, bias, out_features:
     return y.reshape(input.shape[:-1] + (out_features,))
 
 
+def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
+    """Several 1x16 layers applied to the SAME input in one launch (aqlm_hip_gemv_1x16_multi): the q/k/v or gate/up
+    projections of a decoder layer.  Lists of per-layer tensors in, list of outputs out; each output is bit-identical
+    to code1x16_matmat on that layer.  Up to 8 input rows per launch like the single-layer op."""
+    n = len(codes)
+    if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == n):
+        raise ValueError(f"code1x16_matmat_multi takes 1..{_native.MAX_SEGMENTS} layers with one entry per list")
+    dt = _dtype_id(input)
+    in_group_size = codebooks[0].shape[3]
+    in_features = codes[0].shape[1] * in_group_size
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layers expect {in_features}")
+    keep = []
+    segs = (_native.Segment * n)()
+    x = _flat_rows(input)
+    B = x.shape[0]
+    outs = []
+    for k in range(n):
+        cb = codebooks[k]
+        if cb.shape[0] != 1 or cb.shape[1] != 65536 or cb.shape[2] != 1 or cb.shape[3] != in_group_size:
+            raise NotImplementedError(f"code1x16_matmat_multi needs codebooks [1, 65536, 1, {in_group_size}], "
+                                      f"got {tuple(cb.shape)}")
+        if codes[k].shape[1] * in_group_size != in_features:
+            raise ValueError("all layers of a shared-input launch must have the same in_features")
+        if cb.dtype != input.dtype or scales[k].dtype != input.dtype:
+            raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {cb.dtype}")
+        c, cb, sc = _c(codes[k]), _c(cb), _c(scales[k])
+        bi = None if bias[k] is None else _c(bias[k])
+        out_features = c.shape[0]
+        y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+        keep += [c, cb, sc, bi]
+        outs.append(y)
+        segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = c.data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
+        segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), out_features, out_features
+    stream = _stream_ptr()
+    with torch.cuda.device(input.device):
+        for b0 in range(0, B, _native.MAX_GEMV_BATCH):
+            nb = min(_native.MAX_GEMV_BATCH, B - b0)
+            for k in range(n):
+                segs[k].y = outs[k].data_ptr() + b0 * outs[k].shape[1] * 2
+            rc = _lib.aqlm_hip_gemv_1x16_multi(segs, n, x.data_ptr() + b0 * x.stride(0) * 2, in_features, in_group_size,
+                                               nb, x.stride(0), dt, stream)
+            if rc:
+                _native.check(rc, "aqlm gemv_1x16_multi")
+    return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
+
+
+def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias, out_features):
+    """Several prepacked 1x16 g8 layers applied to the same single input row in one launch
+    (aqlm_hip_gemv_1x16_packed_multi); outputs bit-identical to code1x16_matmat_packed per layer."""
+    n = len(packed)
+    if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == len(out_features) == n):
+        raise ValueError(f"code1x16_matmat_packed_multi takes 1..{_native.MAX_SEGMENTS} layers with one entry per list")
+    dt = _dtype_id(input)
+    in_features = input.shape[-1]
+    if input.numel() != in_features:
+        raise ValueError("the packed kernel handles exactly one input row")
+    x = _flat_rows(input)
+    segs = (_native.Segment * n)()
+    keep, outs = [], []
+    total = sum(int(o) for o in out_features)
+    ws = torch.empty((8 * total,), dtype=torch.float32, device=input.device)
+    for k in range(n):
+        cb, sc = _c(codebooks[k]), _c(scales[k])
+        bi = None if bias[k] is None else _c(bias[k])
+        if cb.dtype != input.dtype or sc.dtype != input.dtype:
+            raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {cb.dtype}")
+        y = torch.empty((1, int(out_features[k])), dtype=input.dtype, device=input.device)
+        keep += [cb, sc, bi]
+        outs.append(y)
+        segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = packed[k].data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
+        segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), int(out_features[k]), int(out_features[k])
+    with torch.cuda.device(input.device):
+        rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, n, x.data_ptr(), in_features, 8, dt, ws.data_ptr(),
+                                                  ws.numel() * 4, _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm gemv_1x16_packed_multi")
+    return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
+
+
 def _lds_gemv_applicable(input, codes, codebooks):
     return (codebooks.shape[3] == 8 and input.numel() == input.shape[-1] and input.shape[-1] % 64 == 0
             and input.shape[-1] <= 14336 and input.dtype == codebooks.dtype)
@@ -395,6 +475,17 @@ for _name, (_impl, _fake) in _OPS.items():
     _LIB.impl(_name, _impl, "CUDA")
     torch.library.register_fake(f"aqlm::{_name}")(_fake)
 
+# shared-input launch (no reference counterpart)
+_LIB.define("code1x16_matmat_multi(Tensor input, Tensor[] codes, Tensor[] codebooks, Tensor[] scales, Tensor?[] bias)"
+            " -> Tensor[]")
+_LIB.impl("code1x16_matmat_multi", code1x16_matmat_multi, "CUDA")
+
+
+@torch.library.register_fake("aqlm::code1x16_matmat_multi")
+def _fake_multi(input, codes, codebooks, scales, bias):
+    return [torch.empty(input.shape[:-1] + (c.shape[0],), device=input.device, dtype=input.dtype) for c in codes]
+
+
 # what benchmark/matmul_benchmark.py:6,103 reaches for: CUDA_KERNEL.code1x16_matmat etc. (pybind module in the
 # reference, cuda_kernel.cpp:686-699)
 HIP_KERNEL = SimpleNamespace(
@@ -412,5 +503,6 @@ HIP_KERNEL = SimpleNamespace(
     code1x8_matmat_dequant_transposed=code1x8_matmat_dequant_transposed,
     codekx8_matmat=codekx8_matmat,
     generic_matmat=generic_matmat,
+    code1x16_matmat_multi=code1x16_matmat_multi,
 )
 CUDA_KERNEL = HIP_KERNEL

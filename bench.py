@@ -67,6 +67,9 @@ class Layer:
 
             self.prepack(_native.lib)
 
+    def alg_bytes(self, batch=1):
+        return algorithmic_bytes(self.fin, self.fout, self.K, self.nbits, self.g, batch)
+
     def prepack(self, lib):
         """One-off load-time repack for the slice-bucketed decode kernel (layers with >= PACK_MIN_OUT rows)."""
         from aqlm_amd import _native
@@ -107,12 +110,52 @@ class Layer:
             _native.check(rc)
 
 
+class FusedLayers:
+    """Several 1x16 layers applied to one x in ONE launch (aqlm_hip_gemv_1x16_multi, or the prepacked variant when
+    every member is prepacked): the q/k/v or gate/up projections of a decoder block."""
+
+    def __init__(self, members, mode="auto"):
+        from aqlm_amd import _native
+
+        self.members = members
+        self.fin, self.g = members[0].fin, members[0].g
+        self.n_matvecs = len(members)
+        self.packed = mode != "direct" and all(m.packed is not None for m in members)
+        if mode == "packed" and not self.packed:
+            for m in members:
+                m.prepack(_native.lib)
+            self.packed = all(m.packed is not None for m in members)
+        self.x = members[0].x
+        self.segs = (_native.Segment * len(members))()
+        for sg, m in zip(self.segs, members):
+            sg.codes = m.packed.data_ptr() if self.packed else m.codes.data_ptr()
+            sg.codebook, sg.scales, sg.bias = m.codebooks.data_ptr(), m.scales.data_ptr(), None
+            sg.y, sg.y_row_stride, sg.out_features = m.y.data_ptr(), m.fout, m.fout
+        if self.packed:
+            self.ws = torch.empty((8 * sum(m.fout for m in members),), dtype=torch.float32, device=self.x.device)
+
+    def alg_bytes(self, batch=1):
+        return sum(m.alg_bytes(batch) for m in self.members)
+
+    def launch(self, lib, stream, batch=1):
+        from aqlm_amd import _native
+
+        if self.packed and batch == 1:
+            rc = lib.aqlm_hip_gemv_1x16_packed_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g,
+                                                     _native.F16, self.ws.data_ptr(), self.ws.numel() * 4, stream)
+        else:
+            rc = lib.aqlm_hip_gemv_1x16_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g, batch,
+                                              self.fin, _native.F16, stream)
+        if rc:
+            _native.check(rc)
+
+
 class GraphedPass:
     """A list of layer launches captured once into a hipGraph on a side stream."""
 
     def __init__(self, layers, lib, batch=1):
         self.layers, self.n = layers, len(layers)
-        self.bytes = sum(algorithmic_bytes(l.fin, l.fout, l.K, l.nbits, l.g, batch) for l in layers)
+        self.bytes = sum(l.alg_bytes(batch) for l in layers)
         self.stream = torch.cuda.Stream()
         with torch.cuda.stream(self.stream):
             for l in layers:  # eager warm-up (also sets kernel attributes outside capture)
@@ -390,7 +433,31 @@ def main():
         ms = gp.time_replays(reps)
         detail["llama3_8b_1x16g8_linear_stack"] = {"launches": gp.n, "ms_per_token": ms, "tokens_per_s": 1e3 / ms,
                                                    "algorithmic_GBps": gp.bytes / ms * 1e-6}
-        del gp, tok
+        # the same token with shared-input launches: [q,k,v] in one launch, o, [gate,up] in one launch, down
+        fused = []
+        for b in range(32):
+            q, k, v, o, gate, up, down = tok[7 * b: 7 * b + 7]
+            fused += [FusedLayers([q, k, v]), o, FusedLayers([gate, up]), down]
+        gf = GraphedPass(fused, lib)
+        msf = gf.time_replays(reps)
+        detail["llama3_8b_1x16g8_linear_stack_shared_input_launches"] = {
+            "launches": gf.n, "matvecs": gp.n, "ms_per_token": msf, "tokens_per_s": 1e3 / msf,
+            "algorithmic_GBps": gf.bytes / msf * 1e-6, "speedup_vs_one_launch_per_layer": ms / msf}
+        del gp, gf, fused, tok
+        # q/k/v of a Llama-2-7B block (3 x 4096->4096): separate launches vs one launch, direct and prepacked
+        qkv = [Layer(4096, 4096, 1, 16, 8, 8000 + rank * 10000 + i, dev) for i in range(3 * 40)]
+        trio = {}
+        gsep = GraphedPass(qkv, lib)
+        trio["separate_direct_us"] = gsep.time_replays(reps) * 1e3 / 40
+        gdir = GraphedPass([FusedLayers(qkv[i: i + 3], "direct") for i in range(0, len(qkv), 3)], lib)
+        trio["one_launch_direct_us"] = gdir.time_replays(reps) * 1e3 / 40
+        gpk = GraphedPass([FusedLayers(qkv[i: i + 3], "packed") for i in range(0, len(qkv), 3)], lib)
+        trio["one_launch_prepacked_us"] = gpk.time_replays(reps) * 1e3 / 40
+        gsp = GraphedPass(qkv, lib)  # members are prepacked now -> separate prepacked launches
+        trio["separate_prepacked_us"] = gsp.time_replays(reps) * 1e3 / 40
+        trio["algorithmic_bytes"] = 3 * qkv[0].bytes
+        detail["qkv_3x_4096x4096_1x16g8"] = trio
+        del gsep, gdir, gpk, gsp, qkv
         for sname, (K, nb, g) in {"2x8g8": (2, 8, 8), "8x8g32": (8, 8, 32)}.items():
             shapes7 = [(4096, 4096)] * 4 + [(4096, 11008)] * 2 + [(11008, 4096)]
             tok = [Layer(fi, fo, K, nb, g, 9000 + rank * 10000 + 7 * b + j, dev) for b in range(32) for j, (fi, fo) in enumerate(shapes7)]

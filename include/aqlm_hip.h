@@ -65,6 +65,32 @@ int aqlm_hip_gemv_1x16(const void* codes_i16, const void* codebook, const void* 
                        long x_row_stride, long y_row_stride, int dtype, void* stream);
 
 /*
+ * One launch for up to AQLM_HIP_MAX_SEGMENTS 1x16 layers that multiply the SAME x (q/k/v or gate/up of a decoder
+ * layer): y_s[b, :] = (W_s x[b, :]) * scales_s + bias_s for every segment s.  Each segment has its own codes,
+ * codebook, scales, bias and output; all share in_features, in_group_size, batch, dtype.  Results are bit-identical to
+ * num_segments calls of aqlm_hip_gemv_1x16.
+ *
+ * Replaces: the three (two) consecutive code1x16_matmat calls a decoder layer issues on one hidden state
+ *           (cuda_kernel.cpp:148-182 called from inference.py:68-76 once per projection); SURVEY.md section 8(f)2.
+ */
+typedef struct aqlm_hip_segment {
+  const void* codes;     /* [out_features][in_features/in_group_size] int16 (aqlm_hip_gemv_1x16_multi), or the
+                            prepacked buffer of aqlm_hip_prepack_1x16 (aqlm_hip_gemv_1x16_packed_multi) */
+  const void* codebook;  /* [65536][in_group_size] */
+  const void* scales;    /* [out_features] */
+  const void* bias;      /* [out_features] or NULL */
+  void* y;               /* [batch][out_features], row stride y_row_stride elements */
+  long y_row_stride;
+  int out_features;
+  int reserved;          /* set to 0 */
+} aqlm_hip_segment;
+
+#define AQLM_HIP_MAX_SEGMENTS 4
+
+int aqlm_hip_gemv_1x16_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                             int in_group_size, int batch, long x_row_stride, int dtype, void* stream);
+
+/*
  * Same contract for K x 8-bit schemes (256-entry codebooks held in LDS): num_codebooks in 1..16, any
  * in_group_size that is a multiple of 8 (tuned instances: 1x8 g8, 2x8 g8, 8x8 g32; other shapes run a generic kernel).
  *
@@ -147,6 +173,16 @@ int aqlm_hip_prepack_1x16(const void* codes_i16, int out_features, int in_featur
 int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codebook, const void* scales, const void* bias,
                               const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
                               void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * aqlm_hip_gemv_1x16_packed for up to AQLM_HIP_MAX_SEGMENTS prepacked layers that share x (batch 1), in one launch
+ * (+ one finalize); segment.codes is the prepacked buffer, y_row_stride is unused.  workspace: the sum over segments
+ * of aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, 1, out_features_s, in_features), 16-B aligned.  Results
+ * are bit-identical to separate aqlm_hip_gemv_1x16_packed calls.
+ */
+int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                    int in_features, int in_group_size, int dtype, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /*
  * Batch-1 matvec for 8 x 8-bit schemes (e.g. the 2-bit 8x8 g32 models; in_group_size 8, 16 or 32) through per-token

@@ -67,6 +67,33 @@ def test_argument_validation_without_gpu(native):
         native.check(native.E_INVALID)
 
 
+def test_segment_struct_and_multi_validation(native):
+    # aqlm_hip_segment: 5 pointers + long + 2 ints, no padding surprises
+    assert ctypes.sizeof(native.Segment) == 56
+    assert native.Segment.y_row_stride.offset == 40 and native.Segment.out_features.offset == 48
+    L = native.lib
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(buf)
+    segs = (native.Segment * 2)()
+    rc = L.aqlm_hip_gemv_1x16_multi(segs, 0, p, 512, 8, 1, 512, native.F16, None)
+    assert rc == native.E_INVALID and "segments" in native.last_error()
+    rc = L.aqlm_hip_gemv_1x16_multi(segs, native.MAX_SEGMENTS + 1, p, 512, 8, 1, 512, native.F16, None)
+    assert rc == native.E_INVALID
+    rc = L.aqlm_hip_gemv_1x16_multi(segs, 2, p, 512, 8, 1, 512, native.F16, None)  # null segment pointers
+    assert rc == native.E_INVALID and "null pointer" in native.last_error()
+    for s in segs:
+        s.codes = s.codebook = s.scales = s.y = p
+        s.out_features, s.y_row_stride = 64, 64
+    rc = L.aqlm_hip_gemv_1x16_multi(segs, 2, p, 512, 4, 1, 512, native.F16, None)
+    assert rc == native.E_UNSUPPORTED and "8 or 16" in native.last_error()
+    rc = L.aqlm_hip_gemv_1x16_multi(segs, 2, p, 512, 8, 1, 512, 5, None)
+    assert rc == native.E_UNSUPPORTED and "float16 and bfloat16" in native.last_error()
+    rc = L.aqlm_hip_gemv_1x16_packed_multi(segs, 2, p, 512, 16, native.F16, p, 1 << 20, None)  # g16 not packable
+    assert rc == native.E_UNSUPPORTED
+    rc = L.aqlm_hip_gemv_1x16_packed_multi(segs, 2, p, 512, 8, native.F16, None, 0, None)
+    assert rc == native.E_INVALID and "workspace" in native.last_error()
+
+
 def test_workspace_bytes(native):
     L = native.lib
     n = L.aqlm_hip_workspace_bytes(native.OP_GEMM_1X16_MFMA, 128, 4096, 4096)

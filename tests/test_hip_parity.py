@@ -518,3 +518,150 @@ def test_ops_trace_under_torch_compile(hk):
     y = compiled(T["x"])
     ref = torch.ops.aqlm.code1x16_matmat(T["x"], m.codes, m.codebooks, m.scales, m.bias) * 2.0
     assert torch.equal(y, ref)
+
+
+# ------------------------------------------------------------------ shared-input launches
+def _layers_sharing_x(seed, fin, fouts, g, dtype, batch, biases):
+    fd = np.float16 if dtype == torch.float16 else "bfloat16"
+    Ls = [orc.make_layer(seed + 17 * k, fin, fo, 1, 16, g, batch=batch, bias=b, float_dtype=fd)
+          for k, (fo, b) in enumerate(zip(fouts, biases))]
+    Ts = [to_dev(L, dtype) for L in Ls]
+    return Ls, Ts, Ts[0]["x"]
+
+
+@pytest.mark.parametrize("fin,fouts,g,dt,batch", [
+    (4096, (4096, 1024, 1024), 8, "float16", 1),     # Llama-3-8B q/k/v
+    (1024, (37, 512), 8, "bfloat16", 3),             # ragged rows, batch 3
+    (2048, (256, 256, 64, 1000), 16, "float16", 8),  # g16, four segments, full batch
+    (520, (128, 96), 8, "float16", 2),               # in_groups % 8 != 0 -> per-segment generic launches
+    (4096, (512,), 8, "float16", 11),                # one segment, two batch chunks
+])
+def test_gemv_1x16_multi_is_bit_identical_to_separate_launches(hk, fin, fouts, g, dt, batch):
+    dtype = tdtype(dt)
+    biases = [k % 2 == 0 for k in range(len(fouts))]
+    Ls, Ts, x = _layers_sharing_x(4000 + fin, fin, fouts, g, dtype, batch, biases)
+    outs = torch.ops.aqlm.code1x16_matmat_multi(x, [T["codes"] for T in Ts], [T["codebooks"] for T in Ts],
+                                                [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    assert len(outs) == len(fouts)
+    for L, T, y in zip(Ls, Ts, outs):
+        single = hk.code1x16_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+        assert y.shape == single.shape and torch.equal(y, single)
+        y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y.float().cpu().numpy(), y64, dtype, f"multi 1x16g{g} {fin}->{L['codes'].shape[0]}")
+
+
+@pytest.mark.parametrize("fin,fouts,dt", [
+    (4096, (1024, 1024), "float16"),
+    (4096, (300, 2048, 77), "bfloat16"),
+    (11008, (256, 512, 128, 64), "float16"),
+])
+def test_gemv_1x16_packed_multi_is_bit_identical_to_separate_launches(hk, fin, fouts, dt):
+    dtype = tdtype(dt)
+    biases = [k % 2 == 1 for k in range(len(fouts))]
+    Ls, Ts, x = _layers_sharing_x(5000 + fin, fin, fouts, 8, dtype, 1, biases)
+    packed = [hk.prepack_1x16(T["codes"]) for T in Ts]
+    outs = hk.code1x16_matmat_packed_multi(x, packed, [T["codebooks"] for T in Ts], [T["scales"] for T in Ts],
+                                           [T["bias"] for T in Ts], list(fouts))
+    for L, T, pk, y, fo in zip(Ls, Ts, packed, outs, fouts):
+        single = hk.code1x16_matmat_packed(x, pk, T["codebooks"], T["scales"], T["bias"], fo)
+        assert torch.equal(y, single)
+        y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y.float().cpu().numpy(), y64, dtype, f"packed multi {fin}->{fo}")
+
+
+class _FakeDecoderBlock(torch.nn.Module):
+    """Calls its projections the way Hugging Face's Llama code does: q, k, v on one tensor; gate, up on another."""
+
+    def __init__(self, mods):
+        super().__init__()
+        for n, m in mods.items():
+            setattr(self, n, m)
+
+    def forward(self, h):
+        norm = lambda t: torch.nn.functional.normalize(t.float(), dim=-1).to(t.dtype)  # keeps fp16 finite
+        q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+        h2 = norm(q + torch.nn.functional.pad(k + v, (0, q.shape[-1] - k.shape[-1])))
+        return self.down_proj(norm(torch.nn.functional.silu(self.gate_proj(h2)).float() * self.up_proj(h2).float())), (q, k, v)
+
+
+def test_fused_shared_input_modules_match_unfused(hk):
+    import aqlm
+    import aqlm_amd.inference as inf
+
+    fin, kv, inter = 1024, 256, 3072
+    shapes = dict(q_proj=(fin, fin), k_proj=(fin, kv), v_proj=(fin, kv), gate_proj=(fin, inter), up_proj=(fin, inter),
+                  down_proj=(inter, fin))
+    old = inf.PREPACK_MIN_CODES
+    inf.PREPACK_MIN_CODES = 300_000   # gate/up/down (393 216 codes) take the prepacked route, q/k/v the direct one
+    try:
+        mods = {}
+        for k, (n, (fi, fo)) in enumerate(shapes.items()):
+            L = orc.make_layer(900 + k, fi, fo, 1, 16, 8, batch=4, bias=(k % 2 == 0))
+            mods[n], T = _module_from(L, 1, 16, 8, fi, fo, torch.float16)
+            if n == "q_proj":
+                x = T["x"]
+        block = _FakeDecoderBlock(mods)
+        with torch.no_grad():
+            for rows in (1, 4):
+                h = x[:rows].clone()
+                ref, (q0, k0, v0) = block(h)
+                groups = aqlm.fuse_shared_input_linears(block)
+                assert [len(g.members) for g in groups] == [3, 2]
+                assert aqlm.fuse_shared_input_linears(block) == []  # idempotent
+                out, (q1, k1, v1) = block(h)
+                assert torch.isfinite(ref).all()
+                assert torch.equal(out, ref) and torch.equal(q0, q1) and torch.equal(k0, k1) and torch.equal(v0, v1)
+                assert [(g.launches, g.served) for g in groups] == [(1, 2), (1, 1)]
+                assert all(g._input is None and not g._pending for g in groups)  # nothing kept alive
+                # a different tensor object (even with equal values) is a new launch; a repeated call too
+                out2, _ = block(h.clone())
+                assert torch.equal(out2, ref) and groups[0].launches == 2
+                y_a = block.q_proj(h)
+                y_b = block.q_proj(h)          # same member twice: second call must recompute, not starve
+                assert torch.equal(y_a, q0) and torch.equal(y_b, q0)
+                h_mut = h.clone()
+                k_first = block.k_proj(h_mut)  # parks q and v for h_mut ...
+                h_mut.mul_(2.0)                # ... but the tensor is modified in place before they are fetched
+                assert torch.equal(block.q_proj(h_mut), block.q_proj(h_mut.clone()))
+                assert torch.equal(k_first, k0)
+                aqlm.unfuse_shared_input_linears(block)
+                assert all(m._shared_input_group is None for m in mods.values())
+        assert mods["gate_proj"]._packed_codes is not None and mods["q_proj"]._packed_codes is None
+        # > GEMV_MAX_ROWS rows and inputs that need grad bypass the group
+        groups = aqlm.fuse_shared_input_linears(block)
+        big = torch.randn(16, fin, dtype=torch.float16, device=DEV)
+        block.q_proj(big)
+        xg = x[:2].clone().requires_grad_(True)
+        block.q_proj(xg).float().sum().backward()
+        assert xg.grad is not None and groups[0].launches == 0
+    finally:
+        inf.PREPACK_MIN_CODES = old
+
+
+def test_fused_group_inside_hipgraph(hk):
+    """Shared-input launches are capturable: replaying the graph on new input data reproduces the eager result."""
+    import aqlm
+
+    fin = 1024
+    mods = {}
+    for k, (n, fo) in enumerate([("q_proj", 1024), ("k_proj", 256), ("v_proj", 256)]):
+        L = orc.make_layer(950 + k, fin, fo, 1, 16, 8, batch=1, bias=True)
+        mods[n], T = _module_from(L, 1, 16, 8, fin, fo, torch.float16)
+    holder = torch.nn.Module()
+    for n, m in mods.items():
+        setattr(holder, n, m)
+    aqlm.fuse_shared_input_linears(holder)
+    static_x = torch.randn(1, fin, dtype=torch.float16, device=DEV)
+    with torch.no_grad():
+        [m(static_x) for m in mods.values()]  # warm-up (lazy kernel resolution) outside capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = [holder.q_proj(static_x), holder.k_proj(static_x), holder.v_proj(static_x)]
+        new_x = torch.randn(1, fin, dtype=torch.float16, device=DEV)
+        static_x.copy_(new_x)
+        graph.replay()
+        torch.cuda.synchronize()
+        aqlm.unfuse_shared_input_linears(holder)
+        for n, y in zip(mods, outs):
+            assert torch.equal(y, mods[n](new_x))

@@ -132,3 +132,48 @@ def test_hf_integration_replaces_linears_with_our_module():
     assert type(q) is aqlm_amd.QuantizedLinear
     assert q.codes.shape == (128, 16, 1) and q.codes.dtype == torch.int16
     assert not isinstance(model.lm_head, aqlm_amd.QuantizedLinear)
+
+
+def test_shared_input_grouping_rules_on_meta_modules():
+    """fuse_shared_input_linears groups q/k/v and gate/up siblings that can share a launch and nothing else."""
+    import torch.nn as nn
+
+    def ql(fin, fout, K=1, nbits=16, g=8):
+        return aqlm.QuantizedLinear(fin, fout, g, 1, K, nbits, bias=False, device="meta", dtype=torch.float16)
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj, self.o_proj = ql(512, 512), ql(512, 128), ql(512, 128), ql(512, 512)
+
+    class Mlp(nn.Module):
+        def __init__(self, K=1, nbits=16):
+            super().__init__()
+            self.gate_proj, self.up_proj = ql(512, 1024, K, nbits), ql(512, 1024, K, nbits)
+            self.down_proj = ql(1024, 512, K, nbits)
+
+    class Odd(nn.Module):  # siblings with different in_features, or a dense member, stay unfused
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj = ql(512, 1024), ql(256, 1024)
+            self.q_proj, self.k_proj, self.v_proj = ql(512, 512), nn.Linear(8, 8), ql(512, 512)
+
+    model = nn.ModuleList([Attn(), Mlp(), Mlp(2, 8), Odd()])
+    keys_before = list(model.state_dict().keys()) if False else [n for n, _ in model.named_parameters()]
+    groups = aqlm.fuse_shared_input_linears(model)
+    assert [[m.out_features for m in g.members] for g in groups] == [[512, 128, 128], [1024, 1024]]
+    assert model[0].o_proj._shared_input_group is None and model[1].down_proj._shared_input_group is None
+    assert model[2].gate_proj._shared_input_group is None      # 2x8: not covered by the shared-input kernels
+    assert model[3].gate_proj._shared_input_group is None and model[3].q_proj._shared_input_group is None
+    assert [n for n, _ in model.named_parameters()] == keys_before   # no parameters added or renamed
+    assert aqlm.fuse_shared_input_linears(model) == []
+    # CPU / meta inputs never take the group path (and then hit the usual "GPU only" error of the selector)
+    assert not groups[0].applicable(torch.zeros(1, 512))
+    with pytest.raises(ValueError):
+        aqlm.SharedInputGroup([model[0].q_proj])
+    with pytest.raises(ValueError):
+        aqlm.SharedInputGroup([model[0].q_proj, model[1].down_proj])
+    with pytest.raises(NotImplementedError):
+        aqlm.SharedInputGroup([model[2].gate_proj, model[2].up_proj])
+    aqlm.unfuse_shared_input_linears(model)
+    assert model[0].q_proj._shared_input_group is None

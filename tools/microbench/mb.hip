@@ -371,6 +371,24 @@ static void bench_gemv(int argc, char** argv) {
     }
     for (const auto& var : variants) {
       std::string vn = var.empty() ? "default" : "";
+      CK(hipMemset(g_ws, 0, g_ws_bytes));
+      if (c.s.packed && !var.empty()) {  // the variant must reproduce the default path bit for bit
+        std::vector<uint16_t> y0(c.out), y1(c.out);
+        CK(hipMemset(layers[0].y, 0xff, (size_t)c.out * 2));
+        launch_layer(c.s, layers[0], c.in, c.out, 1, nullptr);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(y0.data(), layers[0].y, (size_t)c.out * 2, hipMemcpyDeviceToHost));
+        for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, kv.val);
+        for (int rep = 0; rep < 3; ++rep) {
+          CK(hipMemset(layers[0].y, 0xff, (size_t)c.out * 2));
+          const int rc = launch_layer(c.s, layers[0], c.in, c.out, 1, nullptr);
+          CK(hipDeviceSynchronize());
+          CK(hipMemcpy(y1.data(), layers[0].y, (size_t)c.out * 2, hipMemcpyDeviceToHost));
+          size_t bad = 0;
+          for (int i = 0; i < c.out; ++i) bad += y0[i] != y1[i];
+          printf("# variant check rep %d: rc=%d mismatches=%zu of %d\n", rep, rc, bad, c.out);
+        }
+      }
       for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
       for (int batch : {1, 2, 4, 8}) {
         if (batch > 1 && (!var.empty() || c.s.lds || c.s.packed || quick)) continue;
