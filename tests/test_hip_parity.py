@@ -578,7 +578,7 @@ class _FakeDecoderBlock(torch.nn.Module):
             setattr(self, n, m)
 
     def forward(self, h):
-        norm = lambda t: torch.nn.functional.normalize(t.float(), dim=-1).to(t.dtype)  # keeps fp16 finite
+        norm = lambda t: torch.nn.functional.normalize(t.float(), dim=-1).to(h.dtype)  # keeps fp16 finite
         q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
         h2 = norm(q + torch.nn.functional.pad(k + v, (0, q.shape[-1] - k.shape[-1])))
         return self.down_proj(norm(torch.nn.functional.silu(self.gate_proj(h2)).float() * self.up_proj(h2).float())), (q, k, v)

@@ -5,6 +5,7 @@
 //   mb gemv       libaqlm_hip.so kernels through the C ABI: cold (rotating layers > 512 MiB, hipGraph replay)
 //                 and warm, for tuning-knob variants
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -442,12 +443,34 @@ static void bench_gemm(bool nosync) {
       int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
       if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
     });
+    // split-K-free kernel: same entry point behind the tuning knob; cross-check Y against the split-K result first
+    std::vector<uint16_t> y0((size_t)B * out), y1((size_t)B * out);
+    aqlm_hip_gemm_1x16_mfma(layers[0].codes, layers[0].cb, layers[0].scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(y0.data(), Y, y0.size() * 2, hipMemcpyDeviceToHost));
+    aqlm_hip_set_tuning("gemm_splitk_free", 1);
+    CK(hipMemset(Y, 0xff, y1.size() * 2));
+    aqlm_hip_gemm_1x16_mfma(layers[0].codes, layers[0].cb, layers[0].scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(y1.data(), Y, y1.size() * 2, hipMemcpyDeviceToHost));
+    {
+      auto h2f = [](uint16_t h) { _Float16 f; memcpy(&f, &h, 2); return (float)f; };
+      double num = 0, den = 0; size_t same = 0;
+      for (size_t i = 0; i < y0.size(); ++i) { num += fabs(h2f(y0[i]) - h2f(y1[i])); den += fabs(h2f(y0[i])); same += y0[i] == y1[i]; }
+      printf("# split-K-free vs split-K: mean-rel diff %.3e, %zu of %zu bit-identical\n", num / den, same, y0.size());
+    }
+    const double free_us = time_it([&](const Layer& L, hipStream_t st) {
+      int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
+      if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
+    });
+    aqlm_hip_set_tuning("gemm_splitk_free", 0);
     fprintf(stderr, "B=%d dequant\n", B);
     const double deq = time_it([&](const Layer& L, hipStream_t st) {
       aqlm_hip_dequant_1x16(L.codes, L.cb, L.scales, W, out, in, 8, AQLM_HIP_F16, st);
     });
     const double flop = 2.0 * B * in * out;
-    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (fused)", B, fused, flop / fused * 1e-6);
+    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (split-K)", B, fused, flop / fused * 1e-6);
+    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (split-K-free)", B, free_us, flop / free_us * 1e-6);
     printf("%-28s %5d %10.2f %10s   (reference pipeline = this + a %d x %d x %d library GEMM)\n", "dequant_1x16 alone", B, deq, "-", B, out, in);
     hipFree(X); hipFree(Y); hipFree(W); hipFree(ws);
     free_layers(layers);
