@@ -42,6 +42,7 @@ SIGNATURES = {
     "aqlm_hip_gemv_1x16": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_packed_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_kx8_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_lds": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_prepack_1x16_bytes": (_sz, [_ci, _ci, _ci]),

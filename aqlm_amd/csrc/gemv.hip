@@ -604,6 +604,19 @@ namespace aqlm {
 int gemv_kx8_replicated(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x,
                         void* y, int out_features, int in_features, int num_codebooks, int dtype, hipStream_t stream);
 
+int gemv_kx8_replicated_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                              int num_codebooks, int dtype, hipStream_t stream);
+
+template <class T, int KC>
+static int dispatch_kx8_multi_nb(int nb, GemvMultiParams& mp, hipStream_t s) {
+  switch (nb) {
+    case 1: return launch_gemv_multi<T, 1, KC, 8, 8, 1, true, 4, 0>(mp, s);
+    case 2: return launch_gemv_multi<T, 1, KC, 8, 8, 2, true, 4, 0>(mp, s);
+    case 4: return launch_gemv_multi<T, 1, KC, 8, 8, 4, true, 4, 0>(mp, s);
+    default: return launch_gemv_multi<T, 1, KC, 8, 8, 8, true, 4, 0>(mp, s);
+  }
+}
+
 // Kx8 instances: (KC, G, U, NWAVES)
 template <class T, int KC, int G, int U, int NWAVES>
 static int dispatch_kx8_nb(int nb, const GemvParams& p, hipStream_t s) {
@@ -698,4 +711,79 @@ extern "C" int aqlm_hip_gemv_generic(const void* codes, const void* codebooks, c
   }
   return run_generic(codes, codebooks, scales, bias, x, y, out_features, in_features, num_codebooks, nbits,
                      in_group_size, batch, xs, ys, dtype, (hipStream_t)stream);
+}
+
+extern "C" int aqlm_hip_gemv_kx8_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                       int in_features, int num_codebooks, int in_group_size, int batch, long xs,
+                                       int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!segments || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS) {
+    set_last_error("aqlm_hip_gemv_kx8_multi: 1..%d segments required, got %d", AQLM_HIP_MAX_SEGMENTS, num_segments);
+    return AQLM_HIP_E_INVALID;
+  }
+  long total_rows = 0;
+  bool aligned = aligned16(x);
+  for (int k = 0; k < num_segments; ++k) {
+    const aqlm_hip_segment& sg = segments[k];
+    if (int e = validate_common(sg.codes, sg.codebook, sg.scales, x, sg.y, sg.out_features, in_features, in_group_size,
+                                batch, dtype, "aqlm_hip_gemv_kx8_multi"))
+      return e;
+    total_rows += sg.out_features;
+    aligned = aligned && aligned16(sg.codes) && aligned16(sg.codebook);
+  }
+  if (num_codebooks < 1 || num_codebooks > 16) {
+    set_last_error("aqlm_hip_gemv_kx8_multi: num_codebooks %d outside 1..16", num_codebooks);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  const int in_groups = in_features / in_group_size;
+  const size_t x_row_bytes = (size_t)in_features * 2;
+  const int K = num_codebooks;
+  const size_t x_budget = std::min<size_t>(kMaxXTileBytes, 160 * 1024 - (size_t)K * 256 * 16 - 2048);
+  const bool fast = in_group_size == 8 && (K == 1 || K == 2) && !tuning().force_generic && in_groups % 8 == 0 &&
+                    aligned && xs % 8 == 0 && x_row_bytes + 256 <= x_budget;
+  if (!fast) {  // other schemes (8x8 ...) and odd shapes: one launch per segment, same results as the single-layer op
+    for (int k = 0; k < num_segments; ++k) {
+      const aqlm_hip_segment& sg = segments[k];
+      if (int e = aqlm_hip_gemv_kx8(sg.codes, sg.codebook, sg.scales, sg.bias, x, sg.y, sg.out_features, in_features, K,
+                                    in_group_size, batch, xs, sg.y_row_stride, dtype, stream_))
+        return e;
+    }
+    return 0;
+  }
+  const int rep = tuning().kx8_replicas;
+  if (batch == 1 && rep != 0 && (rep == 2 || total_rows >= 4096)) {
+    const int e = gemv_kx8_replicated_multi(segments, num_segments, x, in_features, K, dtype, stream);
+    if (e != AQLM_HIP_E_UNSUPPORTED) return e;
+  }
+  GemvMultiParams mp{};
+  mp.nseg = num_segments;
+  GemvParams& p = mp.common;
+  p.xs = xs;
+  p.code_row_bytes = (long)in_groups * K;
+  p.cb_bytes = K * 256 * 8 * 2;
+  p.prefetch = 0;
+  finish_params<8>(p, in_groups, (int)std::min<long>(total_rows, 1 << 30), 4 * 4096);
+  int done = 0;
+  while (done < batch) {
+    int nb = 0;
+    for (int cand : {8, 4, 2, 1})
+      if (cand <= batch - done && (size_t)cand * (x_row_bytes + 256) <= x_budget) { nb = cand; break; }
+    p.x = (const uint16_t*)x + (long)done * xs;
+    for (int k = 0; k < num_segments; ++k) {
+      const aqlm_hip_segment& sg = segments[k];
+      mp.seg[k].codes = (const uint8_t*)sg.codes;
+      mp.seg[k].codebooks = (const uint8_t*)sg.codebook;
+      mp.seg[k].scales = (const uint16_t*)sg.scales;
+      mp.seg[k].bias = (const uint16_t*)sg.bias;
+      mp.seg[k].y = (uint16_t*)sg.y + (long)done * sg.y_row_stride;
+      mp.seg[k].ys = sg.y_row_stride;
+      mp.seg[k].M = sg.out_features;
+    }
+    int e;
+    if (dtype == AQLM_HIP_F16) e = K == 1 ? dispatch_kx8_multi_nb<F16, 1>(nb, mp, stream) : dispatch_kx8_multi_nb<F16, 2>(nb, mp, stream);
+    else e = K == 1 ? dispatch_kx8_multi_nb<BF16, 1>(nb, mp, stream) : dispatch_kx8_multi_nb<BF16, 2>(nb, mp, stream);
+    if (e) return e;
+    done += nb;
+  }
+  return 0;
 }

@@ -44,8 +44,9 @@ __device__ __forceinline__ float rep_reduce4(float a, float b, float c, float d,
   return keep;  // lanes 0-15: a, 16-31: b, 32-47: c, 48-63: d
 }
 
+// `block` = the workgroup's index within its own code matrix (== blockIdx.x for a single-matrix launch)
 template <class T, int KC, int ITERS>
-__global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
+__device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int block) {
   constexpr int NT = 1024;
   constexpr int UB = 8 * KC;       // code bytes per unit of 8 groups
   constexpr int CW = UB / 4;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row_begin = blockIdx.x * p.rows_per_block;
+  const int row_begin = block * p.rows_per_block;
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.rows_per_block ? nrows : p.rows_per_block);
 
@@ -150,6 +151,66 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
 }
 
 template <class T, int KC, int ITERS>
+__global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
+  gemv_kx8_rep_body<T, KC, ITERS>(p, blockIdx.x);
+}
+
+// Shared-input launch: up to AQLM_HIP_MAX_SEGMENTS code matrices (own codebooks / scales / bias / y) times one x.
+// Every workgroup belongs to one segment and fills LDS with that segment's replicated codebooks.
+struct RepSegment {
+  const uint8_t* codes;
+  const uint8_t* codebooks;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  int M, rows_per_block, block_begin;
+};
+
+struct RepMultiParams {
+  RepParams common;
+  int nseg;
+  RepSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+template <class T, int KC, int ITERS>
+__global__ __launch_bounds__(1024) void gemv_kx8_rep_multi_kernel(const RepMultiParams mp) {
+  RepParams p = mp.common;
+  int begin = 0;
+#pragma unroll
+  for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
+    if (k == 0 || (k < mp.nseg && (int)blockIdx.x >= mp.seg[k].block_begin)) {  // scalar select chain
+      p.codes = mp.seg[k].codes;
+      p.codebooks = mp.seg[k].codebooks;
+      p.scales = mp.seg[k].scales;
+      p.bias = mp.seg[k].bias;
+      p.y = mp.seg[k].y;
+      p.M = mp.seg[k].M;
+      p.rows_per_block = mp.seg[k].rows_per_block;
+      begin = mp.seg[k].block_begin;
+    }
+  }
+  gemv_kx8_rep_body<T, KC, ITERS>(p, (int)blockIdx.x - begin);
+}
+
+template <class T, int KC, int ITERS>
+static int launch_rep_multi_i(const RepMultiParams& mp, int blocks, hipStream_t stream) {
+  auto kern = gemv_kx8_rep_multi_kernel<T, KC, ITERS>;
+  const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * mp.common.pitch * 16;
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, mp);
+  return check_hip(hipGetLastError(), "gemv_kx8_rep_multi launch");
+}
+
+template <class T, int KC>
+static int launch_rep_multi(const RepMultiParams& mp, int blocks, hipStream_t stream) {
+  switch (mp.common.iters) {
+    case 1: return launch_rep_multi_i<T, KC, 1>(mp, blocks, stream);
+    case 2: return launch_rep_multi_i<T, KC, 2>(mp, blocks, stream);
+    default: return launch_rep_multi_i<T, KC, 3>(mp, blocks, stream);
+  }
+}
+
+template <class T, int KC, int ITERS>
 static int launch_rep_i(const RepParams& p, int blocks, hipStream_t stream) {
   auto kern = gemv_kx8_rep_kernel<T, KC, ITERS>;
   const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
@@ -193,6 +254,45 @@ int gemv_kx8_replicated(const void* codes, const void* codebooks, const void* sc
   if (dtype == AQLM_HIP_F16)
     return num_codebooks == 1 ? launch_rep<F16, 1>(p, blocks, stream) : launch_rep<F16, 2>(p, blocks, stream);
   return num_codebooks == 1 ? launch_rep<BF16, 1>(p, blocks, stream) : launch_rep<BF16, 2>(p, blocks, stream);
+}
+
+// Shared-input variant (batch 1, g = 8, K in {1,2}): ~256 workgroups dealt to the segments in proportion to their rows.
+// Returns AQLM_HIP_E_UNSUPPORTED when the shape does not fit (caller falls back to the plain LDS kernel).
+int gemv_kx8_replicated_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                              int num_codebooks, int dtype, hipStream_t stream) {
+  const int in_groups = in_features / 8;
+  if ((num_codebooks != 1 && num_codebooks != 2) || in_groups % 8 != 0) return AQLM_HIP_E_UNSUPPORTED;
+  RepMultiParams mp{};
+  RepParams& p = mp.common;
+  p.x = (const uint16_t*)x;
+  p.in_groups = in_groups;
+  p.nunits = in_groups / 8;
+  p.iters = (p.nunits + 63) / 64;
+  p.pitch = p.nunits | 1;
+  p.code_row_bytes = (long)in_groups * num_codebooks;
+  const size_t lds = (size_t)num_codebooks * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
+  if (lds > 160 * 1024 || p.iters > 3) return AQLM_HIP_E_UNSUPPORTED;
+  long total = 0;
+  for (int k = 0; k < num_segments; ++k) total += segments[k].out_features;
+  mp.nseg = num_segments;
+  int blocks = 0;
+  for (int k = 0; k < num_segments; ++k) {
+    const aqlm_hip_segment& sg = segments[k];
+    RepSegment& rs = mp.seg[k];
+    rs.codes = (const uint8_t*)sg.codes;
+    rs.codebooks = (const uint8_t*)sg.codebook;
+    rs.scales = (const uint16_t*)sg.scales;
+    rs.bias = (const uint16_t*)sg.bias;
+    rs.y = (uint16_t*)sg.y;
+    rs.M = sg.out_features;
+    const int share = std::max(1, (int)((256L * sg.out_features + total / 2) / total));  // workgroups for this segment
+    rs.rows_per_block = ((sg.out_features + share - 1) / share + 3) / 4 * 4;
+    rs.block_begin = blocks;
+    blocks += (sg.out_features + rs.rows_per_block - 1) / rs.rows_per_block;
+  }
+  if (dtype == AQLM_HIP_F16)
+    return num_codebooks == 1 ? launch_rep_multi<F16, 1>(mp, blocks, stream) : launch_rep_multi<F16, 2>(mp, blocks, stream);
+  return num_codebooks == 1 ? launch_rep_multi<BF16, 1>(mp, blocks, stream) : launch_rep_multi<BF16, 2>(mp, blocks, stream);
 }
 
 }  // namespace aqlm

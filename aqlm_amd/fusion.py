@@ -32,8 +32,8 @@ def _version(t: torch.Tensor) -> int:
 
 
 class SharedInputGroup:
-    """2..4 ``QuantizedLinear`` modules (1x16 scheme, equal in_features / in_group_size / dtype / device) that are
-    always applied to the same input."""
+    """2..4 ``QuantizedLinear`` modules of one scheme -- 1x16 (g 8 / 16) or K x 8-bit with K in {1, 2}, g 8 -- with equal
+    in_features / dtype / device, that are always applied to the same input."""
 
     def __init__(self, members: Sequence[QuantizedLinear]):
         members = list(members)
@@ -43,10 +43,12 @@ class SharedInputGroup:
         for m in members:
             if not isinstance(m, QuantizedLinear):
                 raise TypeError(f"shared-input groups hold QuantizedLinear modules, got {type(m).__name__}")
-            if (m.num_codebooks, m.nbits_per_codebook, m.out_group_size) != (1, 16, 1) or m.in_group_size not in (8, 16):
-                raise NotImplementedError("shared-input launches cover the 1x16 scheme (in_group_size 8 or 16)")
-            if (m.in_features, m.in_group_size) != (first.in_features, first.in_group_size):
-                raise ValueError("members of a shared-input group must agree on in_features and in_group_size")
+            scheme = (m.num_codebooks, m.nbits_per_codebook, m.in_group_size)
+            ok = (scheme[:2] == (1, 16) and scheme[2] in (8, 16)) or (scheme[1] == 8 and scheme[0] in (1, 2) and scheme[2] == 8)
+            if not ok or m.out_group_size != 1:
+                raise NotImplementedError("shared-input launches cover 1x16 (g 8 / 16) and 1x8 / 2x8 (g 8)")
+            if (m.in_features,) + scheme != (first.in_features, first.num_codebooks, first.nbits_per_codebook, first.in_group_size):
+                raise ValueError("members of a shared-input group must agree on in_features and scheme")
             if m.codebooks.dtype != first.codebooks.dtype or m.codebooks.device != first.codebooks.device:
                 raise ValueError("members of a shared-input group must share dtype and device")
         self.members: List[QuantizedLinear] = members
@@ -84,12 +86,12 @@ class SharedInputGroup:
         for m in ms:
             if m.gemv_op is None:
                 m.prepare_matmul_op(input)
-        if input.numel() == ms[0].in_features and all(m._packed_codes is not None for m in ms):
+        if input.numel() == ms[0].in_features and all(getattr(m, "_packed_codes", None) is not None for m in ms):
             return hip_kernel.code1x16_matmat_packed_multi(
                 input, [m._packed_codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms],
                 [m.bias for m in ms], [m.out_features for m in ms])
-        return torch.ops.aqlm.code1x16_matmat_multi(
-            input, [m.codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms], [m.bias for m in ms])
+        op = torch.ops.aqlm.code1x16_matmat_multi if ms[0].nbits_per_codebook == 16 else torch.ops.aqlm.codekx8_matmat_multi
+        return op(input, [m.codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms], [m.bias for m in ms])
 
 
 def fuse_shared_input_linears(model: nn.Module,

@@ -169,15 +169,14 @@ def code1x16_matmat_packed(input, packed, codebooks, scales, bias, out_features:
     return y.reshape(input.shape[:-1] + (out_features,))
 
 
-def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
-    """Several 1x16 layers applied to the SAME input in one launch (aqlm_hip_gemv_1x16_multi): the q/k/v or gate/up
-    projections of a decoder layer.  Lists of per-layer tensors in, list of outputs out; each output is bit-identical
-    to code1x16_matmat on that layer.  Up to 8 input rows per launch like the single-layer op."""
+def _gemv_multi(input, codes, codebooks, scales, bias, kind):
     n = len(codes)
     if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == n):
-        raise ValueError(f"code1x16_matmat_multi takes 1..{_native.MAX_SEGMENTS} layers with one entry per list")
+        raise ValueError(f"shared-input ops take 1..{_native.MAX_SEGMENTS} layers with one entry per list")
     dt = _dtype_id(input)
-    in_group_size = codebooks[0].shape[3]
+    num_codebooks, codebook_size, out_group_size, in_group_size = codebooks[0].shape
+    if out_group_size != 1:
+        raise NotImplementedError("AQLM HIP kernels require out_group_size == 1")
     in_features = codes[0].shape[1] * in_group_size
     if input.shape[-1] != in_features:
         raise ValueError(f"input has {input.shape[-1]} features, layers expect {in_features}")
@@ -188,11 +187,11 @@ def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
     outs = []
     for k in range(n):
         cb = codebooks[k]
-        if cb.shape[0] != 1 or cb.shape[1] != 65536 or cb.shape[2] != 1 or cb.shape[3] != in_group_size:
-            raise NotImplementedError(f"code1x16_matmat_multi needs codebooks [1, 65536, 1, {in_group_size}], "
-                                      f"got {tuple(cb.shape)}")
-        if codes[k].shape[1] * in_group_size != in_features:
-            raise ValueError("all layers of a shared-input launch must have the same in_features")
+        if tuple(cb.shape) != (num_codebooks, codebook_size, 1, in_group_size):
+            raise NotImplementedError(f"all layers of a shared-input launch must use one scheme; got codebooks "
+                                      f"{tuple(cb.shape)} next to {tuple(codebooks[0].shape)}")
+        if codes[k].shape[1] * in_group_size != in_features or codes[k].shape[2] != num_codebooks:
+            raise ValueError("all layers of a shared-input launch must have the same in_features and num_codebooks")
         if cb.dtype != input.dtype or scales[k].dtype != input.dtype:
             raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {cb.dtype}")
         c, cb, sc = _c(codes[k]), _c(cb), _c(scales[k])
@@ -209,11 +208,34 @@ def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
             for k in range(n):
                 segs[k].y = outs[k].data_ptr() + b0 * outs[k].shape[1] * 2
-            rc = _lib.aqlm_hip_gemv_1x16_multi(segs, n, x.data_ptr() + b0 * x.stride(0) * 2, in_features, in_group_size,
-                                               nb, x.stride(0), dt, stream)
+            xp = x.data_ptr() + b0 * x.stride(0) * 2
+            if kind == "1x16":
+                rc = _lib.aqlm_hip_gemv_1x16_multi(segs, n, xp, in_features, in_group_size, nb, x.stride(0), dt, stream)
+            else:
+                rc = _lib.aqlm_hip_gemv_kx8_multi(segs, n, xp, in_features, num_codebooks, in_group_size, nb,
+                                                  x.stride(0), dt, stream)
             if rc:
-                _native.check(rc, "aqlm gemv_1x16_multi")
+                _native.check(rc, "aqlm shared-input gemv")
     return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
+
+
+def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
+    """Several 1x16 layers applied to the SAME input in one launch (aqlm_hip_gemv_1x16_multi): the q/k/v or gate/up
+    projections of a decoder layer.  Lists of per-layer tensors in, list of outputs out; each output is bit-identical
+    to code1x16_matmat on that layer.  Up to 8 input rows per launch like the single-layer op."""
+    for cb in codebooks:
+        if cb.shape[0] != 1 or cb.shape[1] != 65536:
+            raise NotImplementedError(f"code1x16_matmat_multi needs codebooks [1, 65536, 1, g], got {tuple(cb.shape)}")
+    return _gemv_multi(input, codes, codebooks, scales, bias, "1x16")
+
+
+def codekx8_matmat_multi(input, codes, codebooks, scales, bias):
+    """Several K x 8-bit layers of one scheme applied to the same input (aqlm_hip_gemv_kx8_multi): one launch for
+    1x8 / 2x8 g8, one launch per layer for other schemes.  Outputs agree with codekx8_matmat to fp32 rounding."""
+    for cb in codebooks:
+        if cb.shape[1] != 256:
+            raise NotImplementedError(f"codekx8_matmat_multi needs codebooks [K, 256, 1, g], got {tuple(cb.shape)}")
+    return _gemv_multi(input, codes, codebooks, scales, bias, "kx8")
 
 
 def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias, out_features):
@@ -476,14 +498,14 @@ for _name, (_impl, _fake) in _OPS.items():
     torch.library.register_fake(f"aqlm::{_name}")(_fake)
 
 # shared-input launch (no reference counterpart)
-_LIB.define("code1x16_matmat_multi(Tensor input, Tensor[] codes, Tensor[] codebooks, Tensor[] scales, Tensor?[] bias)"
-            " -> Tensor[]")
-_LIB.impl("code1x16_matmat_multi", code1x16_matmat_multi, "CUDA")
-
-
-@torch.library.register_fake("aqlm::code1x16_matmat_multi")
 def _fake_multi(input, codes, codebooks, scales, bias):
     return [torch.empty(input.shape[:-1] + (c.shape[0],), device=input.device, dtype=input.dtype) for c in codes]
+
+
+for _name, _impl in (("code1x16_matmat_multi", code1x16_matmat_multi), ("codekx8_matmat_multi", codekx8_matmat_multi)):
+    _LIB.define(f"{_name}(Tensor input, Tensor[] codes, Tensor[] codebooks, Tensor[] scales, Tensor?[] bias) -> Tensor[]")
+    _LIB.impl(_name, _impl, "CUDA")
+    torch.library.register_fake(f"aqlm::{_name}")(_fake_multi)
 
 
 # what benchmark/matmul_benchmark.py:6,103 reaches for: CUDA_KERNEL.code1x16_matmat etc. (pybind module in the
@@ -504,5 +526,6 @@ HIP_KERNEL = SimpleNamespace(
     codekx8_matmat=codekx8_matmat,
     generic_matmat=generic_matmat,
     code1x16_matmat_multi=code1x16_matmat_multi,
+    codekx8_matmat_multi=codekx8_matmat_multi,
 )
 CUDA_KERNEL = HIP_KERNEL

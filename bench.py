@@ -140,7 +140,11 @@ class FusedLayers:
     def launch(self, lib, stream, batch=1):
         from aqlm_amd import _native
 
-        if self.packed and batch == 1:
+        if self.members[0].nbits == 8:
+            m0 = self.members[0]
+            rc = lib.aqlm_hip_gemv_kx8_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, m0.K, self.g, batch,
+                                             self.fin, _native.F16, stream)
+        elif self.packed and batch == 1:
             rc = lib.aqlm_hip_gemv_1x16_packed_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g,
                                                      _native.F16, self.ws.data_ptr(), self.ws.numel() * 4, stream)
         else:
@@ -466,6 +470,18 @@ def main():
             detail[f"llama2_7b_{sname}_linear_stack"] = {"launches": gp.n, "ms_per_token": ms, "tokens_per_s": 1e3 / ms,
                                                         "algorithmic_GBps": gp.bytes / ms * 1e-6,
                                                         "frac_of_8TBps": gp.bytes / ms * 1e-6 / HBM_PEAK_GBPS}
+            if sname == "2x8g8":  # [q,k,v] and [gate,up] in one launch each (aqlm_hip_gemv_kx8_multi)
+                fused = []
+                for b in range(32):
+                    q, k, v, o, gate, up, down = tok[7 * b: 7 * b + 7]
+                    fused += [FusedLayers([q, k, v]), o, FusedLayers([gate, up]), down]
+                gf = GraphedPass(fused, lib)
+                msf = gf.time_replays(reps)
+                detail[f"llama2_7b_{sname}_linear_stack_shared_input_launches"] = {
+                    "launches": gf.n, "matvecs": gp.n, "ms_per_token": msf, "tokens_per_s": 1e3 / msf,
+                    "algorithmic_GBps": gf.bytes / msf * 1e-6, "frac_of_8TBps": gf.bytes / msf * 1e-6 / HBM_PEAK_GBPS,
+                    "speedup_vs_one_launch_per_layer": ms / msf}
+                del gf, fused
             del gp, tok
         detail["bs128_1x16g8_4096x4096"] = large_batch_detail(dev, reps)
         result["detail"] = detail

@@ -103,6 +103,18 @@ int aqlm_hip_gemv_kx8(const void* codes_i8, const void* codebooks, const void* s
                       int in_group_size, int batch, long x_row_stride, long y_row_stride, int dtype, void* stream);
 
 /*
+ * aqlm_hip_gemv_kx8 for up to AQLM_HIP_MAX_SEGMENTS layers of one K x 8-bit scheme that multiply the same x, in one
+ * launch (tuned: 1x8 / 2x8 g8; other schemes run one launch per segment).  segment.codes is int8
+ * [out_features][in_features/in_group_size][num_codebooks], segment.codebook is [num_codebooks][256][in_group_size].
+ * Results agree with separate aqlm_hip_gemv_kx8 calls to fp32 rounding (a segment may run on a different kernel of
+ * the family than it would alone: replicated-LDS vs plain LDS).
+ * Replaces: consecutive code2x8_matmat / code1x8_matmat calls on one hidden state (cuda_kernel.cpp:387-421, 552-586).
+ */
+int aqlm_hip_gemv_kx8_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                            int num_codebooks, int in_group_size, int batch, long x_row_stride, int dtype,
+                            void* stream);
+
+/*
  * Fully generic gemv (any num_codebooks, nbits <= 16, any in_group_size, codes in 8- or 16-bit containers):
  * the slow-but-correct path for every scheme without a tuned kernel (the role of triton_kernel.py in the
  * reference, kernel_selector.py:91-94).

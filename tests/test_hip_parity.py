@@ -569,6 +569,72 @@ def test_gemv_1x16_packed_multi_is_bit_identical_to_separate_launches(hk, fin, f
         check_close(y.float().cpu().numpy(), y64, dtype, f"packed multi {fin}->{fo}")
 
 
+@pytest.mark.parametrize("K,fin,fouts,dt,batch", [
+    (2, 4096, (4096, 1024, 1024), "float16", 1),   # 6144 rows -> replicated-LDS kernel for every segment
+    (2, 4096, (11008, 11008), "bfloat16", 1),      # gate/up
+    (1, 2048, (300, 37, 4096), "float16", 1),      # ragged segments, 1x8
+    (2, 1024, (256, 512), "float16", 1),           # < 4096 rows in total -> plain LDS kernel, one launch
+    (2, 4096, (4096, 4096), "float16", 5),         # batch > 1 -> plain LDS kernel, batch chunks 4 + 1
+    (1, 12352, (512, 512), "float16", 1),          # 4 unit iterations: replicated kernel refuses, plain kernel runs
+])
+def test_gemv_kx8_multi_matches_separate_launches(hk, K, fin, fouts, dt, batch):
+    dtype = tdtype(dt)
+    fd = np.float16 if dtype == torch.float16 else "bfloat16"
+    Ls = [orc.make_layer(6000 + fin + 13 * k, fin, fo, K, 8, 8, batch=batch, bias=(k % 2 == 0), float_dtype=fd)
+          for k, fo in enumerate(fouts)]
+    Ts = [to_dev(L, dtype) for L in Ls]
+    x = Ts[0]["x"]
+    outs = torch.ops.aqlm.codekx8_matmat_multi(x, [T["codes"] for T in Ts], [T["codebooks"] for T in Ts],
+                                               [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    for L, T, y in zip(Ls, Ts, outs):
+        y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y.float().cpu().numpy(), y64, dtype, f"multi {K}x8g8 {fin}->{L['codes'].shape[0]}")
+        single = hk.codekx8_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+        check_close(y.float().cpu().numpy(), single.float().cpu().numpy().astype(np.float64), dtype, "multi vs single")
+        if T["bias"] is not None:   # zero input -> exactly the bias
+            yz = torch.ops.aqlm.codekx8_matmat_multi(torch.zeros_like(x), [T["codes"]], [T["codebooks"]], [T["scales"]], [T["bias"]])[0]
+            assert torch.equal(yz, T["bias"].expand_as(yz))
+    # deterministic
+    again = torch.ops.aqlm.codekx8_matmat_multi(x, [T["codes"] for T in Ts], [T["codebooks"] for T in Ts],
+                                                [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
+
+
+def test_gemv_kx8_multi_other_schemes_fall_back_per_segment(hk):
+    Ls = [orc.make_layer(6500 + k, 1024, fo, 8, 8, 32, batch=2, bias=True) for k, fo in enumerate((128, 320))]
+    Ts = [to_dev(L, torch.float16) for L in Ls]
+    outs = torch.ops.aqlm.codekx8_matmat_multi(Ts[0]["x"], [T["codes"] for T in Ts], [T["codebooks"] for T in Ts],
+                                               [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    for T, y in zip(Ts, outs):
+        assert torch.equal(y, hk.codekx8_matmat(Ts[0]["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]))
+
+
+def test_fused_2x8_modules_match_unfused(hk):
+    import aqlm
+
+    fin = 2048
+    mods, x = {}, None
+    for k, (n, fo) in enumerate([("q_proj", 2048), ("k_proj", 2048), ("v_proj", 2048), ("gate_proj", 5504), ("up_proj", 5504)]):
+        L = orc.make_layer(980 + k, fin, fo, 2, 8, 8, batch=3, bias=(k == 0))
+        mods[n], T = _module_from(L, 2, 8, 8, fin, fo, torch.float16)
+        x = T["x"] if x is None else x
+    holder = torch.nn.Module()
+    for n, m in mods.items():
+        setattr(holder, n, m)
+    with torch.no_grad():
+        for rows in (1, 3):
+            h = x[:rows].clone()
+            ref = {n: m(h) for n, m in mods.items()}
+            groups = aqlm.fuse_shared_input_linears(holder)
+            assert [len(g.members) for g in groups] == [3, 2]
+            got = {n: getattr(holder, n)(h) for n in mods}
+            assert [(g.launches, g.served) for g in groups] == [(1, 2), (1, 1)]
+            aqlm.unfuse_shared_input_linears(holder)
+            for n in mods:
+                a, b = got[n].float().cpu().numpy(), ref[n].float().cpu().numpy().astype(np.float64)
+                check_close(a, b, torch.float16, f"fused 2x8 {n} rows={rows}")
+
+
 class _FakeDecoderBlock(torch.nn.Module):
     """Calls its projections the way Hugging Face's Llama code does: q, k, v on one tensor; gate, up on another."""
 

@@ -158,12 +158,18 @@ def test_shared_input_grouping_rules_on_meta_modules():
             self.gate_proj, self.up_proj = ql(512, 1024), ql(256, 1024)
             self.q_proj, self.k_proj, self.v_proj = ql(512, 512), nn.Linear(8, 8), ql(512, 512)
 
-    model = nn.ModuleList([Attn(), Mlp(), Mlp(2, 8), Odd()])
+    class Mlp8x8(nn.Module):  # 8x8 g32: no shared-input kernel
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj = ql(512, 1024, 8, 8, 32), ql(512, 1024, 8, 8, 32)
+
+    model = nn.ModuleList([Attn(), Mlp(), Mlp(2, 8), Odd(), Mlp8x8()])
     keys_before = list(model.state_dict().keys()) if False else [n for n, _ in model.named_parameters()]
     groups = aqlm.fuse_shared_input_linears(model)
-    assert [[m.out_features for m in g.members] for g in groups] == [[512, 128, 128], [1024, 1024]]
+    assert [[m.out_features for m in g.members] for g in groups] == [[512, 128, 128], [1024, 1024], [1024, 1024]]
+    assert groups[2].members[0].nbits_per_codebook == 8      # 2x8 g8 siblings share a launch too
     assert model[0].o_proj._shared_input_group is None and model[1].down_proj._shared_input_group is None
-    assert model[2].gate_proj._shared_input_group is None      # 2x8: not covered by the shared-input kernels
+    assert model[4].gate_proj._shared_input_group is None      # 8x8: not covered by the shared-input kernels
     assert model[3].gate_proj._shared_input_group is None and model[3].q_proj._shared_input_group is None
     assert [n for n, _ in model.named_parameters()] == keys_before   # no parameters added or renamed
     assert aqlm.fuse_shared_input_linears(model) == []
@@ -174,6 +180,8 @@ def test_shared_input_grouping_rules_on_meta_modules():
     with pytest.raises(ValueError):
         aqlm.SharedInputGroup([model[0].q_proj, model[1].down_proj])
     with pytest.raises(NotImplementedError):
-        aqlm.SharedInputGroup([model[2].gate_proj, model[2].up_proj])
+        aqlm.SharedInputGroup([model[4].gate_proj, model[4].up_proj])
+    with pytest.raises(ValueError):
+        aqlm.SharedInputGroup([model[1].gate_proj, model[2].up_proj])   # 1x16 next to 2x8
     aqlm.unfuse_shared_input_linears(model)
     assert model[0].q_proj._shared_input_group is None
