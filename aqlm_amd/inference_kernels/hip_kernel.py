@@ -385,8 +385,15 @@ def code1x8_dequant(codes, codebooks, scales):
 # ------------------------------------------------------------------------------------------------------
 # large-batch ops
 # ------------------------------------------------------------------------------------------------------
+# Rows (batch x sequence) up to which the large-batch 1x16 op runs the fused dequant->MFMA kernel.  The fused kernel
+# re-gathers the codebook entries for every slab of 128 rows (~30 us per slab at 4096x4096), whereas dequantising W once
+# costs 14 us and lets hipBLASLt run the GEMM at matrix-core speed: measured crossover between 128 and 256 rows
+# (DESIGN.md section 4.6), so long prefills take the dequant + GEMM route like the reference does (cuda_kernel.cpp:249-301).
+FUSED_MFMA_MAX_ROWS = 128
+
+
 def _fused_mfma_ok(x, in_features):
-    return in_features % 64 == 0
+    return in_features % 64 == 0 and x.shape[0] <= FUSED_MFMA_MAX_ROWS
 
 
 def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
@@ -401,11 +408,9 @@ def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
     x = _flat_rows(input)
     B = x.shape[0]
     if not _fused_mfma_ok(x, in_features):
+        # unscaled W is exact in the storage dtype (it IS the codebook entries); scaling W instead of y would round it
         W = _dequant(codes, codebooks, None, "1x16")
-        y = F.linear(x, W)
-        y = y * scales.reshape(1, -1)
-        if bias is not None:
-            y = y + bias
+        y = torch.addcmul(bias, F.linear(x, W), scales.reshape(1, -1)) if bias is not None else F.linear(x, W) * scales.reshape(1, -1)
         return y.reshape(input.shape[:-1] + (out_features,))
     codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
     if bias is not None:

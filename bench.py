@@ -261,8 +261,22 @@ def large_batch_detail(dev, reps):
     W = hk.code1x16_dequant(layers[0].codes, layers[0].codebooks, layers[0].scales)
     dense = timeit(lambda l: F.linear(x, W))
     flop = 2.0 * B * fin * fout
-    return {"fused_mfma_us": fused, "fused_TFLOPs": flop / fused * 1e-6, "dequant_plus_gemm_us": ref_like,
-            "dense_fp16_gemm_us": dense, "note": "eager launches incl. python overhead; same x, 24 rotating layers"}
+    out = {"fused_mfma_us": fused, "fused_TFLOPs": flop / fused * 1e-6, "dequant_plus_gemm_us": ref_like,
+           "dense_fp16_gemm_us": dense, "note": "eager launches incl. python overhead; same x, 24 rotating layers"}
+    # why the op switches to dequant + library GEMM above FUSED_MFMA_MAX_ROWS: the fused kernel re-gathers per 128-row slab
+    old = hk.FUSED_MFMA_MAX_ROWS
+    try:
+        for rows in (256, 1024):
+            xr = torch.randn((rows, fin), device=dev, dtype=torch.float16)
+            hk.FUSED_MFMA_MAX_ROWS = 1 << 30
+            f_us = timeit(lambda l: hk.code1x16_matmat_dequant(xr, l.codes, l.codebooks, l.scales, None))
+            hk.FUSED_MFMA_MAX_ROWS = 0
+            d_us = timeit(lambda l: hk.code1x16_matmat_dequant(xr, l.codes, l.codebooks, l.scales, None))
+            out[f"rows{rows}"] = {"fused_mfma_us": f_us, "dequant_plus_gemm_us": d_us,
+                                  "op_default": "dequant_plus_gemm" if rows > old else "fused_mfma"}
+    finally:
+        hk.FUSED_MFMA_MAX_ROWS = old
+    return out
 
 
 def sharded_70b(lib, dev, rank, world, steps):

@@ -219,7 +219,7 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
     (8, 4096, 1000, 100, "float16"),     # ragged rows and batch
     (8, 11008, 256, 7, "bfloat16"),
     (16, 4096, 512, 128, "float16"),
-    (8, 1024, 384, 300, "float16"),      # batch > 128: column slabs
+    (8, 1024, 384, 300, "float16"),      # > FUSED_MFMA_MAX_ROWS rows: dequant + library GEMM route (and, forced, slabs)
     (8, 520, 64, 16, "float16"),         # in % 64 != 0 -> dequant + F.linear route
 ])
 def test_matmat_dequant_mfma(hk, g, fin, fout, B, dt):
@@ -231,6 +231,13 @@ def test_matmat_dequant_mfma(hk, g, fin, fout, B, dt):
     W64 = orc.dequantize_weight(L["codes_unsigned"], L["codebooks"], L["scales"])
     y64 = L["x"].astype(np.float64) @ W64.T + L["bias"].astype(np.float64)
     check_close(y, y64, dtype, f"mfma g{g} {fin}->{fout} B{B}")
+    if B > hk.FUSED_MFMA_MAX_ROWS:   # the fused kernel's 128-column slabs stay covered through the same op
+        old, hk.FUSED_MFMA_MAX_ROWS = hk.FUSED_MFMA_MAX_ROWS, 1 << 30
+        try:
+            y2 = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+        finally:
+            hk.FUSED_MFMA_MAX_ROWS = old
+        check_close(y2, y64, dtype, f"mfma slabs g{g} {fin}->{fout} B{B}")
 
 
 def test_matmat_dequant_mfma_splitk_free_variant(hk):
