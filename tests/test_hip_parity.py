@@ -738,3 +738,24 @@ def test_fused_group_inside_hipgraph(hk):
         aqlm.unfuse_shared_input_linears(holder)
         for n, y in zip(mods, outs):
             assert torch.equal(y, mods[n](new_x))
+
+
+def test_prepack_model_runs_the_load_time_repack_eagerly(hk):
+    from aqlm.checkpoint import memory_report, prepack_model
+
+    mods = torch.nn.ModuleDict()
+    Ls = {}
+    for k, (n, fi, fo) in enumerate([("big", 2048, 1536), ("small", 512, 128)]):
+        Ls[n] = orc.make_layer(990 + k, fi, fo, 1, 16, 8, batch=1, bias=True)
+        mods[n], T = _module_from(Ls[n], 1, 16, 8, fi, fo, torch.float16)
+    assert memory_report(mods)["prepacked_layers"] == 0
+    rep = prepack_model(mods, min_codes=100_000)      # big: 393 216 codes -> repacked now; small: 8192 codes -> not
+    assert rep["quantized_linears"] == 2 and rep["prepacked_layers"] == 1
+    assert mods["big"]._packed_codes is not None and mods["small"]._packed_codes is None
+    assert 1.4 * 2 * 393216 < rep["prepacked"] < 1.8 * 2 * 393216           # ~1.55x the canonical code bytes
+    import aqlm_amd.inference as inf
+    assert inf.PREPACK_MIN_CODES == 2_000_000 or inf.PREPACK_MIN_CODES == 3_000_000   # the override did not leak
+    for n, m in mods.items():
+        T = to_dev(Ls[n], torch.float16)
+        y64 = orc.dequantize_gemm(Ls[n]["x"], Ls[n]["codes"], Ls[n]["codebooks"], Ls[n]["scales"], Ls[n]["bias"])
+        check_close(m(T["x"]).float().cpu().numpy(), y64, torch.float16, f"prepack_model {n}")

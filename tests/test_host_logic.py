@@ -185,3 +185,59 @@ def test_shared_input_grouping_rules_on_meta_modules():
         aqlm.SharedInputGroup([model[1].gate_proj, model[2].up_proj])   # 1x16 next to 2x8
     aqlm.unfuse_shared_input_linears(model)
     assert model[0].q_proj._shared_input_group is None
+
+
+def test_checkpoint_tooling_validates_and_upgrades_configs():
+    from aqlm.checkpoint import quantization_config_from, upgrade_legacy_config, validate_quantized_state_dict
+
+    scheme = dict(nbits_per_codebook=16, num_codebooks=1, out_group_size=1, in_group_size=8)
+    hf_cfg = {"model_type": "llama", "quantization_config": dict(scheme, quant_method="aqlm",
+                                                                linear_weights_not_to_quantize=["lm_head.weight"])}
+    legacy = {"model_type": "llama", "aqlm": dict(scheme)}      # benchmark_generate_cpu.py:68-73 style
+    assert quantization_config_from(hf_cfg) == quantization_config_from(legacy)
+    up = upgrade_legacy_config(legacy)
+    assert "aqlm" not in up and up["quantization_config"]["quant_method"] == "aqlm" and up["torch_dtype"] == "float16"
+    assert "aqlm" in legacy                                       # input untouched
+    assert upgrade_legacy_config(hf_cfg) == hf_cfg
+    with pytest.raises(ValueError):
+        quantization_config_from({"model_type": "llama"})
+    with pytest.raises(ValueError):
+        quantization_config_from({"quantization_config": {"quant_method": "gptq"}})
+    with pytest.raises(ValueError):
+        quantization_config_from({"aqlm": {"nbits_per_codebook": 16}})
+
+    m = aqlm.QuantizedLinear(64, 32, 8, 1, 1, 16, bias=True, dtype=torch.float16)
+    with torch.no_grad():
+        m.codes.zero_(); m.codebooks.normal_(); m.scales.fill_(1); m.bias.zero_()
+    sd = {f"model.layers.0.q.{k}": v.detach().clone() for k, v in m.state_dict().items()}
+    sd["lm_head.weight"] = torch.zeros(4, 4)
+    assert validate_quantized_state_dict(sd, hf_cfg) == []
+    assert validate_quantized_state_dict(sd, scheme) == []      # a bare scheme dict works too
+    bad = dict(sd)
+    bad["model.layers.0.q.codes"] = sd["model.layers.0.q.codes"].to(torch.int8)
+    bad["model.layers.0.q.scales"] = sd["model.layers.0.q.scales"].reshape(-1)
+    bad["model.layers.0.q.codebooks"] = sd["model.layers.0.q.codebooks"][:, :256]
+    bad["model.layers.0.q.weight"] = torch.zeros(32, 64)
+    probs = validate_quantized_state_dict(bad, hf_cfg)
+    assert len(probs) == 4 and any("dtype" in p for p in probs) and any("dense" in p for p in probs)
+    del bad["model.layers.0.q.scales"]
+    assert any("without scales" in p for p in validate_quantized_state_dict(bad, hf_cfg))
+    assert validate_quantized_state_dict({"w": torch.zeros(1)}, hf_cfg) == ["no `<name>.codes` tensors: not an AQLM checkpoint"]
+    # 12-bit codes live in int16 containers: out-of-range container values are caught
+    s12 = dict(scheme, nbits_per_codebook=12)
+    m12 = aqlm.QuantizedLinear(64, 16, 8, 1, 1, 12, bias=False, dtype=torch.float16)
+    with torch.no_grad():
+        m12.codes.fill_(2047); m12.codebooks.normal_(); m12.scales.fill_(1)
+    sd12 = {f"l.{k}": v.detach().clone() for k, v in m12.state_dict().items()}
+    assert validate_quantized_state_dict(sd12, s12) == []
+    sd12["l.codes"][0, 0, 0] = 2048
+    assert any("container range" in p for p in validate_quantized_state_dict(sd12, s12))
+    sd12["l.codebooks"][0, 0, 0, 0] = float("nan")
+    assert any("non-finite" in p for p in validate_quantized_state_dict(sd12, s12))
+    # memory report / eager repack: CPU models are refused loudly (no CPU kernels)
+    from aqlm.checkpoint import memory_report, prepack_model
+
+    rep = memory_report(torch.nn.Sequential(m))
+    assert rep["quantized_linears"] == 1 and rep["codes"] == 32 * 8 * 2 and rep["prepacked"] == 0
+    with pytest.raises(NotImplementedError):
+        prepack_model(torch.nn.Sequential(m))
