@@ -36,7 +36,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # 1x16 g8 layers with at least this many codes run the prepacked (slice-bucketed) decode kernel, like
 # aqlm_amd.inference.PREPACK_MIN_CODES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
-PACK_MIN_OUT = 3_000_000
+PACK_MIN_OUT = 2_000_000
 
 
 def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
@@ -402,8 +402,8 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": ("aqlm::gemv_kernel<F16,1x16,g8> (4096-row layers) + aqlm::gemv_1x16_packed_kernel<F16> "
-                           "(11008-row layers, prepacked codes)") if PACK_MIN_OUT else "aqlm::gemv_kernel<F16,1x16,g8,NB=1>",
+                "kernel": ("aqlm::gemv_1x16_packed_kernel<F16> (+ finalize; prepacked codes, both layer shapes)"
+                           if PACK_MIN_OUT else "aqlm::gemv_kernel<F16,1x16,g8,NB=1>"),
                 "avg_launch_us": avg_launch_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "launches_timed": launches,
                 "note": "one launch = one matvec (packed path: main + finalize kernel); duration = HIP-event time of the "
@@ -418,8 +418,8 @@ def main():
         "config": {"workload": "decode step = 32 blocks x {4096->4096, 4096->11008} 1x16g8 matvec, bs=1, 64 distinct "
                                "layers (own codes + codebook), 564 MB algorithmic bytes/step, hipGraph replay",
                    "scheme": "1x16g8", "batch": 1, "layers_per_step": step.n, "algorithmic_bytes_per_step": step.bytes,
-                   "kernels": ("direct L2-gather gemv below 3 M codes per layer (4096->4096), prepacked slice-bucketed gemv above (4096->11008)"
-                               if PACK_MIN_OUT else "direct L2-gather gemv"),
+                   "kernels": ("prepacked slice-bucketed gemv (layers of >= 2 M codes: both shapes); the direct L2-gather gemv "
+                               "serves smaller layers and --no-packed" if PACK_MIN_OUT else "direct L2-gather gemv"),
                    "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
         "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
         "roofline": roofline,
@@ -463,7 +463,9 @@ def main():
             "algorithmic_GBps": gf.bytes / msf * 1e-6, "speedup_vs_one_launch_per_layer": ms / msf}
         del gp, gf, fused, tok
         # q/k/v of a Llama-2-7B block (3 x 4096->4096): separate launches vs one launch, direct and prepacked
+        keep_min, PACK_MIN_OUT = PACK_MIN_OUT, 0   # start from canonical codes only: the direct kernel
         qkv = [Layer(4096, 4096, 1, 16, 8, 8000 + rank * 10000 + i, dev) for i in range(3 * 40)]
+        PACK_MIN_OUT = keep_min
         trio = {}
         gsep = GraphedPass(qkv, lib)
         trio["separate_direct_us"] = gsep.time_replays(reps) * 1e3 / 40
