@@ -159,6 +159,9 @@ struct PackedGemvParams {
   float* partial;  // [S][M]
   int M, in_groups, RG;
   uint32_t lo16_bytes, hi8_bytes;
+#ifdef AQLM_PACKED_TRACE
+  unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
+#endif
 };
 
 // one 24-bit entry -> fp32 contribution; lo = dword holding the entry's 16 low bits at bit LOSH, hi = dword holding
@@ -189,6 +192,13 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // slice = blockIdx % 8: blocks are observed to land on XCD blockIdx % 8, so each XCD's L2 serves ONE 128 KiB slice
   // (fetched once) instead of the whole codebook (speed only; any placement is correct).  Workgroups of one row-group
   // share nothing -- each walks its own bucket stream -- so they need not be co-located.
+#ifdef AQLM_PACKED_TRACE
+  unsigned long long tr[6];
+  tr[0] = wall_clock64();
+#define AQLM_TRACE(i) tr[i] = wall_clock64()
+#else
+#define AQLM_TRACE(i)
+#endif
   const int slice = block & 7;
   const int group = block >> 3;
   const int row_begin = group * p.RG;
@@ -222,38 +232,42 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_lo, idx * 2, 0, 0));
     hi = __builtin_amdgcn_raw_buffer_load_b32(rs_hi, idx, 0, 0);
   };
+  // Prologue, in dependency order.  Loads return in issue order (one vmcnt counter), so the bucket bounds go FIRST:
+  // the entry fetches that depend on them can then be issued while the 128 KiB codebook slice and x are still in
+  // flight, instead of the slice being requested only after the rowoff round trip (traced: 1.9 us from kernel entry to
+  // "all loads issued" before this ordering).
 #pragma unroll
   for (int k = 0; k < NB2; ++k) bounds(r0 + k * STRIDE, bst[k], ben[k]);
+  constexpr int PER = PK_SLICE_ENTRIES / NT;
+  static_assert(PK_SLICE_ENTRIES % NT == 0, "slice must split evenly over the workgroup");
+  static_assert(2 * NT >= 2040, "x is staged in one pass of two pieces per thread (in_features <= 16320)");
+  u32x4 stage[PER], xv[2];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebook) + (size_t)slice * PK_SLICE_ENTRIES;
+    // the 32 workgroups of an XCD copy the same slice at the same time: each starts at a different 16 KiB piece so that
+    // they do not all hit the same L2 lines (one channel) in lock step
 #pragma unroll
-  for (int k = 0; k < PD; ++k) {
+    for (int k = 0; k < PER; ++k) stage[k] = src[tid + ((k + group) % PER) * NT];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups - 1;
+      xv[k] = *reinterpret_cast<const u32x4*>(p.x + (size_t)q * 8);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PD; ++k) {  // needs the bounds only: vmcnt leaves the slice / x loads in flight
     fetch(bst[k], l16, lo_q[k], hi_q[k]);
     fetch(bst[k], l16 + 16, lo_q2[k], hi_q2[k]);
   }
-
-  for (int q0 = tid; q0 < p.in_groups; q0 += NT * 2) {  // x: staged loads (no load-wait-store round trips)
-    u32x4 v[2];
+  AQLM_TRACE(1);  // every load of the prologue has been issued
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int q = q0 + k * NT < p.in_groups ? q0 + k * NT : p.in_groups - 1;
-      v[k] = *reinterpret_cast<const u32x4*>(p.x + (size_t)q * 8);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-      if (q0 + k * NT < p.in_groups) xl[q0 + k * NT] = v[k];
-  }
+  for (int k = 0; k < 2; ++k)
+    if (tid + k * NT < p.in_groups) xl[tid + k * NT] = xv[k];
   if (tid == 0) xl[p.in_groups] = u32x4{0u, 0u, 0u, 0u};
-  {
-    // all loads of the 128 KiB slice are issued before the first LDS write (one memory round trip, not eight)
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebook) + (size_t)slice * PK_SLICE_ENTRIES;
-    constexpr int PER = PK_SLICE_ENTRIES / NT;
-    static_assert(PK_SLICE_ENTRIES % NT == 0, "slice must split evenly over the workgroup");
-    u32x4 stage[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) stage[k] = src[tid + k * NT];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) cbl[tid + k * NT] = stage[k];
-  }
+  for (int k = 0; k < PER; ++k) cbl[tid + ((k + group) % PER) * NT] = stage[k];
   __syncthreads();
+  AQLM_TRACE(2);  // LDS filled
 
   const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
   const unsigned char* const x_bytes = reinterpret_cast<const unsigned char*>(xl);
@@ -290,9 +304,19 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
       if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + r] = acc;
+#ifdef AQLM_PACKED_TRACE
+      if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived
+#endif
       r += STRIDE;
     }
   }
+  AQLM_TRACE(4);
+#ifdef AQLM_PACKED_TRACE
+  __syncthreads();
+  tr[5] = wall_clock64();
+  if (tid == 0 && p.trace)
+    for (int i = 0; i < 6; ++i) p.trace[(size_t)block * 8 + i] = tr[i];
+#endif
   // (An in-kernel finalize -- last-arriving slice workgroup of a row-group adds the eight partials -- was measured:
   // with __threadfence() it costs +80 us (the agent-scope buffer_inv throws away the L2 lines every other workgroup of
   // the XCD is streaming through); with write-through sc1 stores / sc1 loads and no fence it is correct but exactly as
@@ -480,6 +504,9 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   p.RG = L.RG;
   p.lo16_bytes = (uint32_t)((L.entries + PK_PAD) * 2);
   p.hi8_bytes = (uint32_t)(L.entries + PK_PAD);
+#ifdef AQLM_PACKED_TRACE
+  p.trace = workspace_bytes >= need + 256 * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+#endif
   const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 1) * 16;
   constexpr int NW = 16;
   auto launch = [&](auto kern) -> int {
@@ -487,7 +514,13 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
     hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
-  const int e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3>);
+  // rows per quarter-wave <= 2 (<= 4096-row layers): a shorter ring, so that the unrolled pipeline has fewer idle steps
+  const bool short_rows = L.RG <= 2 * NW * 4;
+  int e;
+  if (short_rows)
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 2>) : launch(gemv_1x16_packed_kernel<BF16, NW, 2>);
+  else
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3>);
   if (e) return e;
   PackedFinalizeParams f{};
   f.partial = (const float*)workspace;

@@ -406,6 +406,37 @@ static void bench_gemv(int argc, char** argv) {
   }
 }
 
+// ---------------------------------------------------------------- phase trace of the packed kernel (trace build only)
+// Needs the library built with -DAQLM_PACKED_TRACE (make trace): the kernel then stamps wall_clock64 (100 MHz) at
+// entry / loads issued / LDS filled / first row done / loop done / end into the workspace tail.
+static void bench_trace(int in, int out) {
+  const Scheme s{"1x16g8P", 1, 16, 8, false, true};
+  const size_t ab1 = algo_bytes(in, out, s, 1);
+  int n = (int)((600u << 20) / ab1) + 1;
+  auto layers = make_layers(s, in, out, 8, n);
+  const size_t need = (size_t)8 * out * 4;
+  unsigned long long* tr = (unsigned long long*)((char*)g_ws + need);
+  std::vector<unsigned long long> h(256 * 8);
+  const char* names[6] = {"entry", "loads issued", "LDS filled", "first row done", "loop done", "end"};
+  for (int rep = 0; rep < 3; ++rep) {
+    for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
+    CK(hipMemset(tr, 0, 256 * 8 * 8));
+    CK(hipDeviceSynchronize());
+    launch_layer(s, layers[0], in, out, 1, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < 256; ++b) t0 = std::min(t0, h[b * 8]);
+    printf("# packed %d->%d cold, run %d: per-phase time since the first workgroup's entry, us (min / mean / max over 256 workgroups)\n", in, out, rep);
+    for (int i = 0; i < 6; ++i) {
+      double mn = 1e9, mx = 0, sum = 0;
+      for (int b = 0; b < 256; ++b) { const double v = (double)(h[b * 8 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+      printf("  %-16s %7.2f %7.2f %7.2f\n", names[i], mn, sum / 256, mx);
+    }
+  }
+  free_layers(layers);
+}
+
 // ---------------------------------------------------------------- large-batch ops through the C ABI
 static void bench_gemm(bool nosync) {
   const int in = 4096, out = 4096;
@@ -487,5 +518,10 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "stream") || !strcmp(what, "all")) bench_stream();
   if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
+  if (!strcmp(what, "trace")) {
+    g_ws_bytes = (size_t)32 * 32768 * 4;
+    CK(hipMalloc(&g_ws, g_ws_bytes));
+    bench_trace(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 4096);
+  }
   return 0;
 }
