@@ -8,14 +8,17 @@
 // 512 codes to use 64.  Bucketing the codes by slice ONCE, when the layer is loaded, removes the scan.  (The
 // reference also re-lays codes out at load time for its CPU kernel, inference.py:78-83.)
 //
-// Packed format v2 (built by aqlm_hip_prepack_1x16, checked bit-for-bit against a numpy model in tests/):
+// Packed format v3 (built by aqlm_hip_prepack_1x16, checked bit-for-bit against a numpy model in tests/):
 //   rows are split into NG = 32 row-groups of RG rows; codes into S = 8 slices by (code >> 13);
-//   stream (g, s) = for each row of group g, in order: that row's codes of slice s in ascending input-group order j,
-//   each as a 24-bit entry  j << 13 | (code & 0x1fff), stored in two planes: lo16[] (low 16 bits) and hi8[] (j >> 3);
+//   stream (g, s) = for each row of group g, in order: that row's codes of slice s (in the bank-aware order of
+//   prepack_arrange_kernel below), each as ONE 32-bit entry  (8192 + j) << 16 | (code & 0x1fff): the two 16-bit halves, shifted left by 4, ARE the
+//   LDS byte addresses of the codebook vector (slice at LDS 0..128 KiB) and of x[j] (x at LDS 128 KiB + 16 j), so an
+//   entry costs two v_lshlrev_b32_sdwa instead of seven ALU ops of bit fiddling (the 24-bit two-plane format v2 did);
 //   every (row, slice) bucket is padded to a multiple of 4 entries with null entries (j = in_groups, whose x is a
-//   zero vector in LDS), so a lane fetches 4 consecutive entries with one aligned 8-B + one aligned 4-B load;
+//   zero vector in LDS; code 0), so a lane fetches 4 consecutive entries with one aligned 16-B load;
 //   rowoff[(g*S + s)*(RG+1) + r] = global index of the first entry of row r of stream (g, s); slot RG closes the
-//   stream.  ~3.07 bytes per code + 4 bytes per (row, slice): 1.55x the canonical 2 bytes per code.
+//   stream.  ~4.1 bytes per code + 4 bytes per (row, slice): 2.1x the canonical 2 bytes per code.  The extra bytes are
+//   free: the kernel runs at < 2 TB/s of HBM traffic, it is bound by LDS / ALU issue and latency, not by the stream.
 //
 // Kernel: grid = 256 workgroups = 32 groups x 8 slices (slice = bid % 8 = the XCD the block is observed to land on, so
 // each XCD's L2 holds one slice; for speed only).  Workgroup (g, s): slice s of the codebook and x go to LDS; each quarter-wave (16 lanes) owns one
@@ -31,13 +34,14 @@ namespace aqlm {
 constexpr int PK_S = 8;        // slices
 constexpr int PK_NG = 32;      // row groups  (PK_S * PK_NG == 256 workgroups == CUs)
 constexpr int PK_SLICE_ENTRIES = 8192;
-constexpr int PK_PAD = 128;    // entries of slack behind the planes (prefetch may run past the end)
+constexpr int PK_PAD = 128;    // entries of slack behind the stream (prefetch may run past the end)
+constexpr uint32_t PK_XBASE = 8192;  // x[j] lives at LDS slot 8192 + j (16-B slots), right behind the codebook slice
 
 struct PackedLayout {
   int M, in_groups, RG;
   size_t n_rowoff;   // NG * S * (RG + 1)
   size_t entries;    // capacity: M * in_groups real entries + up to 3 null entries per (row, slice)
-  size_t off_rowoff, off_lo16, off_hi8, total;
+  size_t off_rowoff, off_ent, total;
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -49,11 +53,10 @@ static bool packed_layout(int out_features, int in_features, int g, PackedLayout
   L.RG = ((out_features + PK_NG - 1) / PK_NG + 3) / 4 * 4;
   L.n_rowoff = (size_t)PK_NG * PK_S * (L.RG + 1);
   L.entries = (size_t)out_features * L.in_groups + (size_t)3 * PK_S * out_features;
-  if (L.entries + PK_PAD >= ((size_t)1 << 31)) return false;
+  if ((L.entries + PK_PAD) * 4 >= ((size_t)1 << 32)) return false;  // 32-bit buffer offsets
   L.off_rowoff = 256;  // header
-  L.off_lo16 = align_up(L.off_rowoff + L.n_rowoff * 4, 256);
-  L.off_hi8 = align_up(L.off_lo16 + (L.entries + PK_PAD) * 2, 256);
-  L.total = align_up(L.off_hi8 + (L.entries + PK_PAD), 256);
+  L.off_ent = align_up(L.off_rowoff + L.n_rowoff * 4, 256);
+  L.total = align_up(L.off_ent + (L.entries + PK_PAD) * 4, 256);
   return true;
 }
 
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(1024) void prepack_scan_kernel(uint32_t* rowoff, si
 }
 
 // K3: scatter the entries.  One wave per row; ascending j within each (row, slice) bucket.
-__global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* codes, const uint32_t* rowoff, uint16_t* lo16,
-                                                              uint8_t* hi8, int M, int in_groups, int RG) {
+__global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* codes, const uint32_t* rowoff, uint32_t* ent,
+                                                              int M, int in_groups, int RG) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -129,11 +132,7 @@ __global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* co
       const bool mine = sl == (uint32_t)s;
       const unsigned long long mask = __ballot(mine);
       const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
-      if (mine) {
-        const uint32_t e = ((uint32_t)j << 13) | (code & 0x1fffu);
-        lo16[base[s] + before] = (uint16_t)(e & 0xffffu);
-        hi8[base[s] + before] = (uint8_t)(e >> 16);
-      }
+      if (mine) ent[base[s] + before] = ((PK_XBASE + (uint32_t)j) << 16) | (code & 0x1fffu);
       base[s] += __popcll(mask);
     }
   }
@@ -141,39 +140,122 @@ __global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* co
 #pragma unroll
   for (int s = 0; s < PK_S; ++s) {
     const uint32_t pad = (0u - base[s]) & 3u;  // bucket starts are multiples of 4
-    if ((uint32_t)lane < pad) {
-      const uint32_t e = (uint32_t)in_groups << 13;
-      lo16[base[s] + lane] = (uint16_t)(e & 0xffffu);
-      hi8[base[s] + lane] = (uint8_t)(e >> 16);
-    }
+    if ((uint32_t)lane < pad) ent[base[s] + lane] = (PK_XBASE + (uint32_t)in_groups) << 16;
   }
+}
+
+// K4: bank-aware order of the entries inside every (row, slice) bucket.  In the gemv kernel lane l16 of a quarter-wave
+// reads entries 4*l16 + k (k = 0..3: "level" k) of its row's bucket, and the 16 lanes serviced together by one
+// ds_read_b128 pass are l16 in {0-3, 12-15} of one row plus l16 in {4-11} of its neighbour row (service groups of a
+// wave64 b128 read: lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} / +32).  With ascending-j order the x[j] reads of a
+// level hit random 16-B slots (~3-way bank conflicts; traced: the gather loop is LDS-bound).  Here every entry whose
+// x slot has residue rho = j mod 16 is sent to its "home" lane -- residues 0-7 to l16 {0-3, 12-15}, residues 8-15 to
+// l16 {4-11} -- at the next free level, so that the 16 lanes of a service group read 16 DIFFERENT slot residues
+// whatever the neighbour row is.  Entries that find their home lane full (or absent in a short bucket) fill the
+// remaining holes in index order.  The sum over a bucket is order-independent up to fp32 rounding; the order is fixed
+// by this kernel (and mirrored by the numpy model in tests/), so results stay deterministic.
+constexpr int PK_MAX_GROUPS = 2040;
+constexpr uint32_t PK_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ int pk_home_lane(uint32_t rho) { return rho < 4 ? (int)rho : (rho < 8 ? (int)rho + 8 : (int)rho - 4); }
+
+__global__ __launch_bounds__(128) void prepack_arrange_kernel(const uint32_t* rowoff, uint32_t* ent, int M, int in_groups, int RG) {
+  __shared__ uint32_t in_s[2][PK_MAX_GROUPS + 32];
+  __shared__ uint32_t out_s[2][PK_MAX_GROUPS + 32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 2 + w;
+  if (row >= M) return;  // whole wave exits together; no block barrier is used below
+  const int g = row / RG, r = row - g * RG;
+  uint32_t start[PK_S], len[PK_S], off[PK_S];
+  uint32_t run = 0;
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s) {
+    const size_t k = ((size_t)g * PK_S + s) * (RG + 1) + r;
+    start[s] = rowoff[k];
+    len[s] = rowoff[k + 1] - start[s];
+    off[s] = run;
+    run += len[s];
+  }
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s)
+    for (uint32_t i = lane; i < len[s]; i += 64) {
+      in_s[w][off[s] + i] = ent[start[s] + i];
+      out_s[w][off[s] + i] = PK_EMPTY;
+    }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane < PK_S) {  // lane s arranges bucket s (serial: load-time code, a few microseconds per layer in total)
+    uint32_t st = 0, ln = 0;
+#pragma unroll
+    for (int s = 0; s < PK_S; ++s)
+      if (lane == s) { st = off[s]; ln = len[s]; }
+    uint32_t* in = &in_s[w][st];
+    uint32_t* out = &out_s[w][st];
+    const uint32_t null_entry = (PK_XBASE + (uint32_t)in_groups) << 16;
+    uint32_t n = ln;  // real entries come first, the (< 4) null entries of the scatter pass last
+    while (n > 0 && in[n - 1] == null_entry) --n;
+    const int m = ln / 4 < 16 ? (int)(ln / 4) : 16;
+    unsigned long long cnt = 0;  // 16 x 3-bit level counters
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t e = in[i];
+      const int L = pk_home_lane((e >> 16) & 15u);
+      const uint32_t c = (uint32_t)(cnt >> (3 * L)) & 7u;
+      if (L < m && c < 4) {
+        out[4 * L + c] = e;
+        cnt += 1ull << (3 * L);
+        in[i] = PK_EMPTY;
+      }
+    }
+    uint32_t idx = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t e = in[i];
+      if (e == PK_EMPTY) continue;
+      while (out[idx] != PK_EMPTY) ++idx;
+      out[idx++] = e;
+    }
+    for (uint32_t i = 0; i < ln; ++i)
+      if (out[i] == PK_EMPTY) out[i] = null_entry;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+  for (int s = 0; s < PK_S; ++s)
+    for (uint32_t i = lane; i < len[s]; i += 64) ent[start[s] + i] = out_s[w][off[s] + i];
 }
 
 // ------------------------------------------------------------------------------------------------ gemv
 struct PackedGemvParams {
   const uint32_t* rowoff;
-  const uint16_t* lo16;
-  const uint8_t* hi8;
+  const uint32_t* ent;
   const uint8_t* codebook;
   const uint16_t* x;
   float* partial;  // [S][M]
   int M, in_groups, RG;
-  uint32_t lo16_bytes, hi8_bytes;
+  uint32_t ent_bytes;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
 #endif
 };
 
-// one 24-bit entry -> fp32 contribution; lo = dword holding the entry's 16 low bits at bit LOSH, hi = dword holding
-// its high byte at bit HISH
-template <class T, int LOSH, int HISH>
-__device__ __forceinline__ float packed_entry(uint32_t lo, uint32_t hi, const unsigned char* cb_bytes,
-                                              const unsigned char* x_bytes, float acc) {
-  const uint32_t cb_off = (LOSH == 0) ? ((lo << 4) & 0x1FFF0u) : ((lo >> 12) & 0x1FFF0u);          // (code & 0x1fff) * 16
-  const uint32_t jhi = (HISH >= 7) ? ((hi >> (HISH - 7)) & 0x7F80u) : ((hi << (7 - HISH)) & 0x7F80u);  // (j >> 3) * 128
-  const uint32_t x_off = ((lo >> (LOSH + 9)) & 0x70u) | jhi;                                           // j * 16
-  const u32x4 e = *reinterpret_cast<const u32x4*>(cb_bytes + cb_off);
-  const u32x4 xv = *reinterpret_cast<const u32x4*>(x_bytes + x_off);
+// LDS access by absolute byte address.  The kernel has no static LDS, so its dynamic LDS starts at address 0 (checked
+// at kernel entry): the codebook slice occupies [0, 128 KiB) and x slot j sits at (8192 + j) * 16.
+typedef __attribute__((address_space(3))) const u32x4* lds_u32x4_ptr;
+
+template <int WORD>
+__device__ __forceinline__ uint32_t half_shl4(uint32_t w, uint32_t four) {
+  uint32_t d;  // d = ((w >> 16*WORD) & 0xffff) << 4 in one instruction (sub-dword operand select)
+  if constexpr (WORD == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(four), "v"(w));
+  else
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(four), "v"(w));
+  return d;
+}
+
+// one 32-bit entry -> fp32 contribution
+template <class T>
+__device__ __forceinline__ float packed_entry(uint32_t w, uint32_t four, float acc) {
+  const u32x4 e = *(lds_u32x4_ptr)(size_t)half_shl4<0>(w, four);   // codebook vector of (code & 0x1fff)
+  const u32x4 xv = *(lds_u32x4_ptr)(size_t)half_shl4<1>(w, four);  // x[j]
   return dot8<T>(e, xv, acc);
 }
 
@@ -206,8 +288,8 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
   const uint32_t* const ro = p.rowoff + ((size_t)group * PK_S + slice) * (p.RG + 1);
 
-  __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.lo16, 0, p.lo16_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.hi8, 0, p.hi8_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();  // see lds_u32x4_ptr
 
   // Software pipeline over this quarter-wave's rows r0, r0+STRIDE, ...: bucket bounds run 2*PD rows ahead (ring of
   // 2*PD slots), the first two 4-entry chunks of each lane PD rows ahead (ring of PD slots).  Rings are indexed with
@@ -216,8 +298,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   constexpr int NB2 = 2 * PD;
   const int r0 = wave * 4 + quarter;
   uint32_t bst[NB2], ben[NB2];
-  u32x2 lo_q[PD], lo_q2[PD];            // chunk l16 and chunk l16 + 16 (buckets of 65..128 entries) of each row
-  uint32_t hi_q[PD], hi_q2[PD];
+  u32x4 e_q[PD], e_q2[PD];              // chunk l16 and chunk l16 + 16 (buckets of 65..128 entries) of each row
   // Every load below is UNCONDITIONAL (rows past the end are clamped to the closing rowoff slot = an empty bucket;
   // chunks past a bucket's end read neighbouring entries or, past the planes, zeros from the bounds-checked buffer
   // descriptor, and are never consumed).  Loads inside divergent branches make hipcc's s_waitcnt bookkeeping fall
@@ -227,10 +308,8 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     st = ro[a];
     en = ro[b];
   };
-  auto fetch = [&](uint32_t st, int chunk, u32x2& lo, uint32_t& hi) {
-    const uint32_t idx = st + 4u * (uint32_t)chunk;
-    lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_lo, idx * 2, 0, 0));
-    hi = __builtin_amdgcn_raw_buffer_load_b32(rs_hi, idx, 0, 0);
+  auto fetch = [&](uint32_t st, int chunk, u32x4& e) {
+    e = __builtin_amdgcn_raw_buffer_load_b128(rs_ent, (st + 4u * (uint32_t)chunk) * 4u, 0, 0);
   };
   // Prologue, in dependency order.  Loads return in issue order (one vmcnt counter), so the bucket bounds go FIRST:
   // the entry fetches that depend on them can then be issued while the 128 KiB codebook slice and x are still in
@@ -256,8 +335,8 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   }
 #pragma unroll
   for (int k = 0; k < PD; ++k) {  // needs the bounds only: vmcnt leaves the slice / x loads in flight
-    fetch(bst[k], l16, lo_q[k], hi_q[k]);
-    fetch(bst[k], l16 + 16, lo_q2[k], hi_q2[k]);
+    fetch(bst[k], l16, e_q[k]);
+    fetch(bst[k], l16 + 16, e_q2[k]);
   }
   AQLM_TRACE(1);  // every load of the prologue has been issued
 #pragma unroll
@@ -269,13 +348,13 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   __syncthreads();
   AQLM_TRACE(2);  // LDS filled
 
-  const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
-  const unsigned char* const x_bytes = reinterpret_cast<const unsigned char*>(xl);
-  auto consume = [&](const u32x2& lo, uint32_t hi, float acc) -> float {
-    acc = packed_entry<T, 0, 0>(lo.x, hi, cb_bytes, x_bytes, acc);
-    acc = packed_entry<T, 16, 8>(lo.x, hi, cb_bytes, x_bytes, acc);
-    acc = packed_entry<T, 0, 16>(lo.y, hi, cb_bytes, x_bytes, acc);
-    acc = packed_entry<T, 16, 24>(lo.y, hi, cb_bytes, x_bytes, acc);
+  uint32_t four = 4u;
+  asm volatile("" : "+v"(four));  // the SDWA shift count must sit in a VGPR
+  auto consume = [&](const u32x4& e, float acc) -> float {
+    acc = packed_entry<T>(e.x, four, acc);
+    acc = packed_entry<T>(e.y, four, acc);
+    acc = packed_entry<T>(e.z, four, acc);
+    acc = packed_entry<T>(e.w, four, acc);
     return acc;
   };
 
@@ -285,21 +364,20 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     for (int s6 = 0; s6 < NB2; ++s6) {  // no early exit: a single back-edge keeps every in-flight load in place
       const int es = s6 % PD;
       const uint32_t st = bst[s6], en = ben[s6];
-      const u32x2 lo = lo_q[es], lo2 = lo_q2[es];
-      const uint32_t hi = hi_q[es], hi2 = hi_q2[es];
+      const u32x4 e1 = e_q[es], e2 = e_q2[es];
       // refill: entries of row r + PD*STRIDE (its bounds sit PD slots further in the ring), bounds of row r + 2*PD*STRIDE
-      fetch(bst[(s6 + PD) % NB2], l16, lo_q[es], hi_q[es]);
-      fetch(bst[(s6 + PD) % NB2], l16 + 16, lo_q2[es], hi_q2[es]);
+      fetch(bst[(s6 + PD) % NB2], l16, e_q[es]);
+      fetch(bst[(s6 + PD) % NB2], l16 + 16, e_q2[es]);
       bounds(r + NB2 * STRIDE, bst[s6], ben[s6]);
 
       const int nchunks = (int)((en - st) >> 2);
       float acc = 0.f;
-      if (l16 < nchunks) acc = consume(lo, hi, acc);
-      if (l16 + 16 < nchunks) acc = consume(lo2, hi2, acc);
+      if (l16 < nchunks) acc = consume(e1, acc);
+      if (l16 + 16 < nchunks) acc = consume(e2, acc);
       for (int c = l16 + 32; __any(c < nchunks); c += 16) {  // buckets longer than 128 entries (rare): blocking loads
-        u32x2 lo3; uint32_t hi3;
-        fetch(st, c, lo3, hi3);
-        if (c < nchunks) acc = consume(lo3, hi3, acc);
+        u32x4 e3;
+        fetch(st, c, e3);
+        if (c < nchunks) acc = consume(e3, acc);
       }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
@@ -313,9 +391,17 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   AQLM_TRACE(4);
 #ifdef AQLM_PACKED_TRACE
   __syncthreads();
+  unsigned long long* wdone = reinterpret_cast<unsigned long long*>(smem_raw);  // the codebook slice is dead by now
+  if (lane == 0) wdone[wave] = tr[4];
+  __syncthreads();
   tr[5] = wall_clock64();
-  if (tid == 0 && p.trace)
+  if (tid == 0 && p.trace) {
     for (int i = 0; i < 6; ++i) p.trace[(size_t)block * 8 + i] = tr[i];
+    unsigned long long mn = ~0ull, mx = 0;
+    for (int w = 0; w < NWAVES; ++w) { mn = wdone[w] < mn ? wdone[w] : mn; mx = wdone[w] > mx ? wdone[w] : mx; }
+    p.trace[(size_t)block * 8 + 6] = mn;  // first / last wave of the workgroup to leave the loop
+    p.trace[(size_t)block * 8 + 7] = mx;
+  }
 #endif
   // (An in-kernel finalize -- last-arriving slice workgroup of a row-group adds the eight partials -- was measured:
   // with __threadfence() it costs +80 us (the agent-scope buffer_inv throws away the L2 lines every other workgroup of
@@ -332,12 +418,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
 // layer's workgroups start as CUs free up, so the first layer's tail and the second's LDS fill overlap.
 struct PackedSegment {
   const uint32_t* rowoff;
-  const uint16_t* lo16;
-  const uint8_t* hi8;
+  const uint32_t* ent;
   const uint8_t* codebook;
   float* partial;
   int M, RG;
-  uint32_t lo16_bytes, hi8_bytes;
+  uint32_t ent_bytes;
 };
 
 struct PackedMultiParams {
@@ -356,14 +441,12 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_multi_kernel(con
   for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
     if (k == 0 || sidx == k) {  // scalar select chain (no dynamic indexing of the kernel-argument struct)
       p.rowoff = mp.seg[k].rowoff;
-      p.lo16 = mp.seg[k].lo16;
-      p.hi8 = mp.seg[k].hi8;
+      p.ent = mp.seg[k].ent;
       p.codebook = mp.seg[k].codebook;
       p.partial = mp.seg[k].partial;
       p.M = mp.seg[k].M;
       p.RG = mp.seg[k].RG;
-      p.lo16_bytes = mp.seg[k].lo16_bytes;
-      p.hi8_bytes = mp.seg[k].hi8_bytes;
+      p.ent_bytes = mp.seg[k].ent_bytes;
     }
   }
   gemv_1x16_packed_body<T, NWAVES, PD>(p, (int)blockIdx.x & 255);
@@ -448,22 +531,22 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   }
   uint8_t* base = (uint8_t*)packed;
   // header (informational; the kernels take the layout from the shapes)
-  const uint32_t hdr[16] = {0x31505141u, 2u, (uint32_t)L.M, (uint32_t)L.in_groups, 8u, (uint32_t)PK_S, (uint32_t)PK_NG,
-                            (uint32_t)L.RG, (uint32_t)L.entries, (uint32_t)L.off_rowoff, (uint32_t)L.off_lo16,
-                            (uint32_t)L.off_hi8, (uint32_t)(L.total & 0xffffffffu), (uint32_t)(L.total >> 32), 0u, 0u};
-  if (int e = check_hip(hipMemsetAsync(base, 0, L.off_lo16, stream), "prepack memset")) return e;
+  const uint32_t hdr[16] = {0x31505141u, 3u, (uint32_t)L.M, (uint32_t)L.in_groups, 8u, (uint32_t)PK_S, (uint32_t)PK_NG,
+                            (uint32_t)L.RG, (uint32_t)L.entries, (uint32_t)L.off_rowoff, (uint32_t)L.off_ent,
+                            0u, (uint32_t)(L.total & 0xffffffffu), (uint32_t)(L.total >> 32), 0u, 0u};
+  if (int e = check_hip(hipMemsetAsync(base, 0, L.off_ent, stream), "prepack memset")) return e;
   if (int e = check_hip(hipMemcpyAsync(base, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream), "prepack header")) return e;
   if (int e = check_hip(hipStreamSynchronize(stream), "prepack header sync")) return e;  // hdr is on the stack
   uint32_t* rowoff = (uint32_t*)(base + L.off_rowoff);
-  uint16_t* lo16 = (uint16_t*)(base + L.off_lo16);
-  uint8_t* hi8 = base + L.off_hi8;
-  if (int e = check_hip(hipMemsetAsync(lo16, 0, L.total - L.off_lo16, stream), "prepack memset planes")) return e;
+  uint32_t* ent = (uint32_t*)(base + L.off_ent);
+  if (int e = check_hip(hipMemsetAsync(ent, 0, L.total - L.off_ent, stream), "prepack memset entries")) return e;
   const int blocks = (L.M + 3) / 4;
   hipLaunchKernelGGL(prepack_count_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, L.M,
                      L.in_groups, L.RG);
   hipLaunchKernelGGL(prepack_scan_kernel, dim3(1), dim3(1024), 0, stream, rowoff, L.n_rowoff);
-  hipLaunchKernelGGL(prepack_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, lo16,
-                     hi8, L.M, L.in_groups, L.RG);
+  hipLaunchKernelGGL(prepack_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, ent, L.M,
+                     L.in_groups, L.RG);
+  hipLaunchKernelGGL(prepack_arrange_kernel, dim3((L.M + 1) / 2), dim3(128), 0, stream, rowoff, ent, L.M, L.in_groups, L.RG);
   return check_hip(hipGetLastError(), "prepack launch");
 }
 
@@ -494,16 +577,14 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   const uint8_t* base = (const uint8_t*)packed;
   PackedGemvParams p{};
   p.rowoff = (const uint32_t*)(base + L.off_rowoff);
-  p.lo16 = (const uint16_t*)(base + L.off_lo16);
-  p.hi8 = base + L.off_hi8;
+  p.ent = (const uint32_t*)(base + L.off_ent);
   p.codebook = (const uint8_t*)codebook;
   p.x = (const uint16_t*)x;
   p.partial = (float*)workspace;
   p.M = L.M;
   p.in_groups = L.in_groups;
   p.RG = L.RG;
-  p.lo16_bytes = (uint32_t)((L.entries + PK_PAD) * 2);
-  p.hi8_bytes = (uint32_t)(L.entries + PK_PAD);
+  p.ent_bytes = (uint32_t)((L.entries + PK_PAD) * 4);
 #ifdef AQLM_PACKED_TRACE
   p.trace = workspace_bytes >= need + 256 * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
 #endif
@@ -571,14 +652,12 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     const uint8_t* base = (const uint8_t*)sg.codes;
     PackedSegment& ps = mp.seg[k];
     ps.rowoff = (const uint32_t*)(base + L.off_rowoff);
-    ps.lo16 = (const uint16_t*)(base + L.off_lo16);
-    ps.hi8 = base + L.off_hi8;
+    ps.ent = (const uint32_t*)(base + L.off_ent);
     ps.codebook = (const uint8_t*)sg.codebook;
     ps.partial = (float*)((uint8_t*)workspace + need);
     ps.M = L.M;
     ps.RG = L.RG;
-    ps.lo16_bytes = (uint32_t)((L.entries + PK_PAD) * 2);
-    ps.hi8_bytes = (uint32_t)(L.entries + PK_PAD);
+    ps.ent_bytes = (uint32_t)((L.entries + PK_PAD) * 4);
     mp.in_groups = L.in_groups;
     PackedFinalizeSegment& fs = fm.seg[k];
     fs.f.partial = ps.partial;

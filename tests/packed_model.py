@@ -1,8 +1,9 @@
-"""numpy model of the packed 1x16 format v2 (aqlm_amd/csrc/gemv_packed.hip): the bit-exact oracle for
+"""numpy model of the packed 1x16 format v3 (aqlm_amd/csrc/gemv_packed.hip): the bit-exact oracle for
 aqlm_hip_prepack_1x16.  Test infrastructure only."""
 import numpy as np
 
 S, NG, PAD = 8, 32, 128
+XBASE = 8192   # x[j] sits at LDS slot XBASE + j: the high half of an entry is that slot index
 
 
 def align_up(v, a):
@@ -15,15 +16,14 @@ def layout(out_features, in_features):
     n_rowoff = NG * S * (RG + 1)
     entries = out_features * in_groups + 3 * S * out_features  # capacity incl. null padding
     off_rowoff = 256
-    off_lo16 = align_up(off_rowoff + n_rowoff * 4, 256)
-    off_hi8 = align_up(off_lo16 + (entries + PAD) * 2, 256)
-    total = align_up(off_hi8 + entries + PAD, 256)
+    off_ent = align_up(off_rowoff + n_rowoff * 4, 256)
+    total = align_up(off_ent + (entries + PAD) * 4, 256)
     return dict(in_groups=in_groups, RG=RG, n_rowoff=n_rowoff, entries=entries, off_rowoff=off_rowoff,
-                off_lo16=off_lo16, off_hi8=off_hi8, total=total)
+                off_ent=off_ent, total=total)
 
 
 def pack(codes_unsigned):
-    """codes_unsigned: [M, in_groups] ints in [0, 65536).  Returns (rowoff u32, lo16 u16, hi8 u8) of `entries` length."""
+    """codes_unsigned: [M, in_groups] ints in [0, 65536).  Returns (rowoff u32, entries u32 of `entries` length, layout)."""
     M, in_groups = codes_unsigned.shape
     L = layout(M, in_groups * 8)
     RG = L["RG"]
@@ -35,18 +35,46 @@ def pack(codes_unsigned):
             counts[r // RG, s, r % RG] = c[r]
     flat = counts.reshape(-1)
     rowoff = np.concatenate([[0], np.cumsum(flat)[:-1]]).astype(np.uint32)
-    lo16 = np.zeros(L["entries"], dtype=np.uint16)
-    hi8 = np.zeros(L["entries"], dtype=np.uint8)
+    ent = np.zeros(L["entries"], dtype=np.uint32)
     ro = rowoff.reshape(NG, S, RG + 1)
     for r in range(M):
         g, rl = divmod(r, RG)
         row = codes_unsigned[r]
         for s in range(S):
             js = np.nonzero((row >> 13) == s)[0]
-            e = (js.astype(np.uint32) << 13) | (row[js].astype(np.uint32) & 0x1FFF)
+            e = ((js.astype(np.uint32) + XBASE) << 16) | (row[js].astype(np.uint32) & 0x1FFF)
             b = int(ro[g, s, rl])
             pad = (-len(js)) % 4
-            e = np.concatenate([e, np.full(pad, in_groups << 13, dtype=np.uint32)])  # null entries: j = in_groups
-            lo16[b:b + len(e)] = (e & 0xFFFF).astype(np.uint16)
-            hi8[b:b + len(e)] = (e >> 16).astype(np.uint8)
-    return rowoff, lo16, hi8, L
+            null = np.uint32((in_groups + XBASE) << 16)  # j = in_groups, code 0
+            ent[b:b + len(e) + pad] = arrange(e, len(e) + pad, null)
+    return rowoff, ent, L
+
+
+def home_lane(rho):
+    return rho if rho < 4 else (rho + 8 if rho < 8 else rho - 4)
+
+
+def arrange(entries, slots, null):
+    """Bank-aware order inside a bucket (prepack_arrange_kernel): an entry whose x slot has residue rho = j mod 16 goes
+    to its home lane (index 4*lane + level) while that lane exists and has a free level; the others fill the holes in
+    index order; what is left is null padding."""
+    EMPTY = 0xFFFFFFFF
+    out = np.full(slots, EMPTY, dtype=np.uint32)
+    m = min(16, slots // 4)
+    cnt = [0] * 16
+    rest = []
+    for e in entries:
+        L = home_lane((int(e) >> 16) & 15)
+        if L < m and cnt[L] < 4:
+            out[4 * L + cnt[L]] = e
+            cnt[L] += 1
+        else:
+            rest.append(e)
+    idx = 0
+    for e in rest:
+        while out[idx] != EMPTY:
+            idx += 1
+        out[idx] = e
+        idx += 1
+    out[out == EMPTY] = null
+    return out

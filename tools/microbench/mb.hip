@@ -417,7 +417,7 @@ static void bench_trace(int in, int out) {
   const size_t need = (size_t)8 * out * 4;
   unsigned long long* tr = (unsigned long long*)((char*)g_ws + need);
   std::vector<unsigned long long> h(256 * 8);
-  const char* names[6] = {"entry", "loads issued", "LDS filled", "first row done", "loop done", "end"};
+  const char* names[8] = {"entry", "loads issued", "LDS filled", "first row done", "loop done (wave 0)", "end", "first wave out", "last wave out"};
   for (int rep = 0; rep < 3; ++rep) {
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
     CK(hipMemset(tr, 0, 256 * 8 * 8));
@@ -428,7 +428,7 @@ static void bench_trace(int in, int out) {
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 256; ++b) t0 = std::min(t0, h[b * 8]);
     printf("# packed %d->%d cold, run %d: per-phase time since the first workgroup's entry, us (min / mean / max over 256 workgroups)\n", in, out, rep);
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 8; ++i) {
       double mn = 1e9, mx = 0, sum = 0;
       for (int b = 0; b < 256; ++b) { const double v = (double)(h[b * 8 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
       printf("  %-16s %7.2f %7.2f %7.2f\n", names[i], mn, sum / 256, mx);
