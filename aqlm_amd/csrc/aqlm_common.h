@@ -66,10 +66,32 @@ __device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float acc)
   return acc;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// Reductions on the VALU (DPP): __shfl_xor compiles to ds_bpermute_b32, i.e. every step of a shuffle tree is an LDS
+// instruction with LDS latency -- in the gather kernels that is 4-6 extra LDS round trips per output row on the unit
+// that is already the bottleneck.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15); every lane of the row receives the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror: the other quad of each group of 8
+  v += dpp_f32<0x140>(v);  // row_mirror: the other half of the row
   return v;
+}
+
+// sum over the wave; every lane receives the total
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // compile-time extraction of code #idx from the dwords of one code word

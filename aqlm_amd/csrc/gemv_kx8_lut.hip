@@ -116,8 +116,7 @@ __global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
         acc += my[6 * 256 + ((cw.y >> 16) & 0xffu)];
         acc += my[7 * 256 + (cw.y >> 24)];
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+      acc = row16_sum(acc);
       if (l16 == 0 && r < nrows) out[r] = acc;
     }
   }

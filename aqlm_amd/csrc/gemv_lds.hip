@@ -47,8 +47,7 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
   float w = odd16 ? u : v;
   w = __shfl_xor(w, 16, WAVE);
   float keep = (odd16 ? v : u) + w;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) keep += __shfl_xor(keep, o, WAVE);
+  keep = row16_sum(keep);
   return keep;  // lanes 0-15: a, 16-31: b, 32-47: c, 48-63: d
 }
 

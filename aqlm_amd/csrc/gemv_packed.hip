@@ -379,8 +379,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
         fetch(st, c, e3);
         if (c < nchunks) acc = consume(e3, acc);
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+      acc = row16_sum(acc);  // DPP: no LDS traffic
       if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + r] = acc;
 #ifdef AQLM_PACKED_TRACE
       if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived

@@ -195,6 +195,17 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
         check_close(y_single.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "lut vs batched")
         with_gather = hk._gemv(T1["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "kx8")[0]
         assert torch.equal(with_gather, y[2])
+    elif nbits == 8:
+        # single rows of big 1x8 / 2x8 layers take the replicated-LDS kernel (another reduction tree): close to the
+        # batched result, and the plain LDS kernel (forced) reproduces the batched row bit for bit
+        from aqlm_amd import _native
+
+        check_close(y_single.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "replicated vs batched")
+        _native.set_tuning("kx8_replicas", 0)
+        try:
+            assert torch.equal(run_forward(hk, K, nbits, g, T1)[0], y[2])
+        finally:
+            _native.set_tuning("kx8_replicas", 1)
     else:
         assert torch.equal(y_single, y[2])
     # (3) zero input -> exactly the bias
