@@ -21,7 +21,7 @@ GEMV_MAX_ROWS = 6
 
 # Single-row 1x16 g8 matvecs of layers with at least this many codes (out_features * in_features / 8) run on
 # slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): 1.7-3x faster than the direct L2-gather kernel on
-# MI355X for large layers, at the price of a one-off repack at first use and 1.55x the code bytes kept next to the
+# MI355X for large layers, at the price of a one-off repack at first use and 2.1x the code bytes kept next to the
 # original codes.  0 disables.  Measured: the packed path has ~7 us more fixed cost per call than the direct kernel and
 # costs ~3.2 ps less per code: 4096x4096 (2.1 M codes) is 4 % faster (11.6 vs 12.1 us in a decode stack; q/k/v in one
 # prepacked launch 28.7 vs 31.4 us), 4096->11008 and 14336->4096 are 1.9x faster; below 2 M codes the direct kernel wins.

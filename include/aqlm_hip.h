@@ -167,7 +167,7 @@ int aqlm_hip_gemv_1x16_lds(const void* codes_i16, const void* codebook, const vo
 
 /*
  * Load-time repack of 1x16 g8 codes into the slice-bucketed format consumed by aqlm_hip_gemv_1x16_packed
- * (layout documented in aqlm_amd/csrc/gemv_packed.hip and DESIGN.md; 3 bytes per code + 4 bytes per (row, slice)).
+ * (layout documented in aqlm_amd/csrc/gemv_packed.hip and DESIGN.md; ~4.1 bytes per code + 4 bytes per (row, slice)).
  * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
  * (inference.py:78-83).  aqlm_hip_prepack_1x16_bytes returns 0 for shapes the packed path does not cover
  * (in_group_size != 8, in_features % 64 != 0, in_features > 16320).  aqlm_hip_prepack_1x16 synchronises `stream`
