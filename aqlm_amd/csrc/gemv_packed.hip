@@ -275,7 +275,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // (fetched once) instead of the whole codebook (speed only; any placement is correct).  Workgroups of one row-group
   // share nothing -- each walks its own bucket stream -- so they need not be co-located.
 #ifdef AQLM_PACKED_TRACE
-  unsigned long long tr[6];
+  unsigned long long tr[7];
   tr[0] = wall_clock64();
 #define AQLM_TRACE(i) tr[i] = wall_clock64()
 #else
@@ -339,12 +339,18 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     fetch(bst[k], l16 + 16, e_q2[k]);
   }
   AQLM_TRACE(1);  // every load of the prologue has been issued
+  // unconditional LDS writes (threads past the end write a dump slot): with the store under a branch hipcc sinks the
+  // x load into the branch and guards it with vmcnt(0), i.e. the whole LDS fill then waits for the entry prefetch
+  // (traced: workgroup barrier 2 us after the first wave had its data)
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
-    if (tid + k * NT < p.in_groups) xl[tid + k * NT] = xv[k];
+  for (int k = 0; k < 2; ++k) xl[tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups + 1] = xv[k];
   if (tid == 0) xl[p.in_groups] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int k = 0; k < PER; ++k) cbl[tid + ((k + group) % PER) * NT] = stage[k];
+#ifdef AQLM_PACKED_TRACE
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes (hence its slice data) are done
+  AQLM_TRACE(6);
+#endif
   __syncthreads();
   AQLM_TRACE(2);  // LDS filled
 
@@ -391,15 +397,20 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #ifdef AQLM_PACKED_TRACE
   __syncthreads();
   unsigned long long* wdone = reinterpret_cast<unsigned long long*>(smem_raw);  // the codebook slice is dead by now
-  if (lane == 0) wdone[wave] = tr[4];
+  if (lane == 0) { wdone[wave] = tr[4]; wdone[NWAVES + wave] = tr[0]; wdone[2 * NWAVES + wave] = tr[6]; }
   __syncthreads();
   tr[5] = wall_clock64();
   if (tid == 0 && p.trace) {
     for (int i = 0; i < 6; ++i) p.trace[(size_t)block * 8 + i] = tr[i];
-    unsigned long long mn = ~0ull, mx = 0;
-    for (int w = 0; w < NWAVES; ++w) { mn = wdone[w] < mn ? wdone[w] : mn; mx = wdone[w] > mx ? wdone[w] : mx; }
-    p.trace[(size_t)block * 8 + 6] = mn;  // first / last wave of the workgroup to leave the loop
-    p.trace[(size_t)block * 8 + 7] = mx;
+    unsigned long long mx = 0, me = 0, ms = 0;
+    for (int w = 0; w < NWAVES; ++w) {
+      mx = wdone[w] > mx ? wdone[w] : mx;
+      me = wdone[NWAVES + w] > me ? wdone[NWAVES + w] : me;
+      ms = wdone[2 * NWAVES + w] > ms ? wdone[2 * NWAVES + w] : ms;
+    }
+    p.trace[(size_t)block * 8 + 5] = me;  // last wave of the workgroup to START
+    p.trace[(size_t)block * 8 + 6] = ms;  // last wave to have its share of the slice in LDS
+    p.trace[(size_t)block * 8 + 7] = mx;  // last wave to leave the loop
   }
 #endif
   // (An in-kernel finalize -- last-arriving slice workgroup of a row-group adds the eight partials -- was measured:
@@ -587,7 +598,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
 #ifdef AQLM_PACKED_TRACE
   p.trace = workspace_bytes >= need + 256 * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
 #endif
-  const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 1) * 16;
+  const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 2) * 16;  // slice, x, zero slot, dump slot
   constexpr int NW = 16;
   auto launch = [&](auto kern) -> int {
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
@@ -672,7 +683,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     set_last_error("aqlm_hip_gemv_1x16_packed_multi: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
   }
-  const size_t lds = (size_t)(PK_SLICE_ENTRIES + mp.in_groups + 1) * 16;
+  const size_t lds = (size_t)(PK_SLICE_ENTRIES + mp.in_groups + 2) * 16;  // slice, x, zero slot, dump slot
   constexpr int NW = 16;
   auto launch = [&](auto kern) -> int {
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;

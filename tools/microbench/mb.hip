@@ -417,7 +417,7 @@ static void bench_trace(int in, int out) {
   const size_t need = (size_t)8 * out * 4;
   unsigned long long* tr = (unsigned long long*)((char*)g_ws + need);
   std::vector<unsigned long long> h(256 * 8);
-  const char* names[8] = {"entry", "loads issued", "LDS filled", "first row done", "loop done (wave 0)", "end", "first wave out", "last wave out"};
+  const char* names[8] = {"entry", "loads issued", "LDS filled", "first row done", "loop done (wave 0)", "last wave entry", "last wave slice in LDS", "last wave out"};
   for (int rep = 0; rep < 3; ++rep) {
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
     CK(hipMemset(tr, 0, 256 * 8 * 8));
