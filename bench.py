@@ -408,7 +408,7 @@ def main():
                 "launches_timed": launches,
                 "note": "one launch = one matvec (packed path: main + finalize kernel); duration = HIP-event time of the "
                         "timed region / matvecs; achieved uses ALGORITHMIC bytes (2 B per code) even where the prepacked "
-                        "path really reads ~3.1 B per code; rocprofv3 per-kernel durations are in profiles/"}
+                        "path really reads ~4.1 B per code (32-bit entries); rocprofv3 per-kernel durations are in profiles/"}
 
     result = {
         "metric": "QuantizedLinear 1x16g8 matvec algorithmic GB/s (bs=1, Llama-3-8B shapes 4096->4096/11008)",
