@@ -16,7 +16,11 @@
 //   entry costs two v_lshlrev_b32_sdwa instead of seven ALU ops of bit fiddling (the 24-bit two-plane format v2 did);
 //   every (row, slice) bucket is padded to a multiple of 4 entries with null entries (j = in_groups, whose x is a
 //   zero vector in LDS; code 0), so a lane fetches 4 consecutive entries with one aligned 16-B load;
-//   rowoff[(g*S + s)*(RG+1) + r] = global index of the first entry of row r of stream (g, s); slot RG closes the
+//   inside a stream the rows are ordered by bucket size, largest first (stable): the four rows a wave processes in one
+//   step then have similar sizes, so a wave whose rows all fit the first 64-entry pass skips the second pass entirely
+//   (with the natural row order 94 % of the wave-steps of a 4096-wide layer execute a second, nearly empty pass);
+//   rowperm[(g*S + s)*RG + p] = row (within the group) whose bucket sits at position p,
+//   rowoff[(g*S + s)*(RG+1) + p] = global index of the first entry of the bucket at position p; slot RG closes the
 //   stream.  ~4.1 bytes per code + 4 bytes per (row, slice): 2.1x the canonical 2 bytes per code.  The extra bytes are
 //   free: the kernel runs at < 2 TB/s of HBM traffic, it is bound by LDS / ALU issue and latency, not by the stream.
 //
@@ -35,13 +39,15 @@ constexpr int PK_S = 8;        // slices
 constexpr int PK_NG = 32;      // row groups  (PK_S * PK_NG == 256 workgroups == CUs)
 constexpr int PK_SLICE_ENTRIES = 8192;
 constexpr int PK_PAD = 128;    // entries of slack behind the stream (prefetch may run past the end)
+constexpr int PK_MAX_RG = 4096;  // rows per row-group the load-time sort handles (out_features <= 131072)
 constexpr uint32_t PK_XBASE = 8192;  // x[j] lives at LDS slot 8192 + j (16-B slots), right behind the codebook slice
 
 struct PackedLayout {
   int M, in_groups, RG;
   size_t n_rowoff;   // NG * S * (RG + 1)
   size_t entries;    // capacity: M * in_groups real entries + up to 3 null entries per (row, slice)
-  size_t off_rowoff, off_ent, total;
+  size_t n_perm;     // NG * S * RG
+  size_t off_rowoff, off_perm, off_ent, total;
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -54,8 +60,11 @@ static bool packed_layout(int out_features, int in_features, int g, PackedLayout
   L.n_rowoff = (size_t)PK_NG * PK_S * (L.RG + 1);
   L.entries = (size_t)out_features * L.in_groups + (size_t)3 * PK_S * out_features;
   if ((L.entries + PK_PAD) * 4 >= ((size_t)1 << 32)) return false;  // 32-bit buffer offsets
+  if (L.RG > PK_MAX_RG) return false;
+  L.n_perm = (size_t)PK_NG * PK_S * L.RG;
   L.off_rowoff = 256;  // header
-  L.off_ent = align_up(L.off_rowoff + L.n_rowoff * 4, 256);
+  L.off_perm = align_up(L.off_rowoff + L.n_rowoff * 4, 256);
+  L.off_ent = align_up(L.off_perm + L.n_perm * 2, 256);
   L.total = align_up(L.off_ent + (L.entries + PK_PAD) * 4, 256);
   return true;
 }
@@ -112,16 +121,56 @@ __global__ __launch_bounds__(1024) void prepack_scan_kernel(uint32_t* rowoff, si
   }
 }
 
+// K1b: per stream (g, s): rank the rows by bucket size (descending, ties by row index) and put the counts in that
+// order.  rank[] (row -> position) is kept in the rowperm array until the scatter / arrange passes are done; K5 inverts it.
+__global__ __launch_bounds__(1024) void prepack_sort_kernel(uint32_t* rowoff, uint16_t* rank, int RG) {
+  __shared__ uint32_t c[PK_MAX_RG];
+  uint32_t* cnt = rowoff + (size_t)blockIdx.x * (RG + 1);
+  uint16_t* rk = rank + (size_t)blockIdx.x * RG;
+  for (int r = threadIdx.x; r < RG; r += 1024) c[r] = cnt[r];
+  __syncthreads();
+  uint32_t mine[PK_MAX_RG / 1024], pos[PK_MAX_RG / 1024];
+#pragma unroll
+  for (int i = 0; i < PK_MAX_RG / 1024; ++i) {
+    const int r = threadIdx.x + i * 1024;
+    mine[i] = r < RG ? c[r] : 0u;
+    uint32_t k = 0;
+    if (r < RG)
+      for (int r2 = 0; r2 < RG; ++r2) k += (c[r2] > mine[i]) || (c[r2] == mine[i] && r2 < r);
+    pos[i] = k;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PK_MAX_RG / 1024; ++i) {
+    const int r = threadIdx.x + i * 1024;
+    if (r < RG) {
+      cnt[pos[i]] = mine[i];
+      rk[r] = (uint16_t)pos[i];
+    }
+  }
+}
+
+// K5: rank (row -> position) -> rowperm (position -> row), in place.
+__global__ __launch_bounds__(1024) void prepack_invert_kernel(uint16_t* rank, int RG) {
+  __shared__ uint16_t t[PK_MAX_RG];
+  uint16_t* rk = rank + (size_t)blockIdx.x * RG;
+  for (int r = threadIdx.x; r < RG; r += 1024) t[r] = rk[r];
+  __syncthreads();
+  for (int r = threadIdx.x; r < RG; r += 1024) rk[t[r]] = (uint16_t)r;
+}
+
 // K3: scatter the entries.  One wave per row; ascending j within each (row, slice) bucket.
-__global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* codes, const uint32_t* rowoff, uint32_t* ent,
-                                                              int M, int in_groups, int RG) {
+__global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* codes, const uint32_t* rowoff,
+                                                              const uint16_t* rank, uint32_t* ent, int M, int in_groups,
+                                                              int RG) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int g = row / RG, r = row - g * RG;
   uint32_t base[PK_S];
 #pragma unroll
-  for (int s = 0; s < PK_S; ++s) base[s] = rowoff[((size_t)g * PK_S + s) * (RG + 1) + r];
+  for (int s = 0; s < PK_S; ++s)
+    base[s] = rowoff[((size_t)g * PK_S + s) * (RG + 1) + rank[((size_t)g * PK_S + s) * RG + r]];
   for (int j0 = 0; j0 < in_groups; j0 += 64) {
     const int j = j0 + lane;
     const bool ok = j < in_groups;
@@ -159,7 +208,8 @@ constexpr uint32_t PK_EMPTY = 0xffffffffu;
 
 __device__ __forceinline__ int pk_home_lane(uint32_t rho) { return rho < 4 ? (int)rho : (rho < 8 ? (int)rho + 8 : (int)rho - 4); }
 
-__global__ __launch_bounds__(128) void prepack_arrange_kernel(const uint32_t* rowoff, uint32_t* ent, int M, int in_groups, int RG) {
+__global__ __launch_bounds__(128) void prepack_arrange_kernel(const uint32_t* rowoff, const uint16_t* rank, uint32_t* ent, int M,
+                                                              int in_groups, int RG) {
   __shared__ uint32_t in_s[2][PK_MAX_GROUPS + 32];
   __shared__ uint32_t out_s[2][PK_MAX_GROUPS + 32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -170,7 +220,7 @@ __global__ __launch_bounds__(128) void prepack_arrange_kernel(const uint32_t* ro
   uint32_t run = 0;
 #pragma unroll
   for (int s = 0; s < PK_S; ++s) {
-    const size_t k = ((size_t)g * PK_S + s) * (RG + 1) + r;
+    const size_t k = ((size_t)g * PK_S + s) * (RG + 1) + rank[((size_t)g * PK_S + s) * RG + r];
     start[s] = rowoff[k];
     len[s] = rowoff[k + 1] - start[s];
     off[s] = run;
@@ -226,6 +276,7 @@ __global__ __launch_bounds__(128) void prepack_arrange_kernel(const uint32_t* ro
 // ------------------------------------------------------------------------------------------------ gemv
 struct PackedGemvParams {
   const uint32_t* rowoff;
+  const uint16_t* rowperm;
   const uint32_t* ent;
   const uint8_t* codebook;
   const uint16_t* x;
@@ -287,6 +338,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
   const uint32_t* const ro = p.rowoff + ((size_t)group * PK_S + slice) * (p.RG + 1);
+  const uint16_t* const pm = p.rowperm + ((size_t)group * PK_S + slice) * p.RG;  // position -> row of the group
 
   __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();  // see lds_u32x4_ptr
@@ -298,15 +350,17 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   constexpr int NB2 = 2 * PD;
   const int r0 = wave * 4 + quarter;
   uint32_t bst[NB2], ben[NB2];
+  uint16_t brow[NB2];
   u32x4 e_q[PD], e_q2[PD];              // chunk l16 and chunk l16 + 16 (buckets of 65..128 entries) of each row
   // Every load below is UNCONDITIONAL (rows past the end are clamped to the closing rowoff slot = an empty bucket;
   // chunks past a bucket's end read neighbouring entries or, past the planes, zeros from the bounds-checked buffer
   // descriptor, and are never consumed).  Loads inside divergent branches make hipcc's s_waitcnt bookkeeping fall
   // back to vmcnt(0) at every use, which serialises the whole prefetch pipeline (measured: 0.85 us per step).
-  auto bounds = [&](int r, uint32_t& st, uint32_t& en) {
+  auto bounds = [&](int r, uint32_t& st, uint32_t& en, uint16_t& row) {  // r is a POSITION in the sorted stream
     const int a = r < p.RG ? r : p.RG, b = r + 1 < p.RG ? r + 1 : p.RG;
     st = ro[a];
     en = ro[b];
+    row = pm[r < p.RG ? r : p.RG - 1];
   };
   auto fetch = [&](uint32_t st, int chunk, u32x4& e) {
     e = __builtin_amdgcn_raw_buffer_load_b128(rs_ent, (st + 4u * (uint32_t)chunk) * 4u, 0, 0);
@@ -316,7 +370,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // flight, instead of the slice being requested only after the rowoff round trip (traced: 1.9 us from kernel entry to
   // "all loads issued" before this ordering).
 #pragma unroll
-  for (int k = 0; k < NB2; ++k) bounds(r0 + k * STRIDE, bst[k], ben[k]);
+  for (int k = 0; k < NB2; ++k) bounds(r0 + k * STRIDE, bst[k], ben[k], brow[k]);
   constexpr int PER = PK_SLICE_ENTRIES / NT;
   static_assert(PK_SLICE_ENTRIES % NT == 0, "slice must split evenly over the workgroup");
   static_assert(2 * NT >= 2040, "x is staged in one pass of two pieces per thread (in_features <= 16320)");
@@ -370,11 +424,12 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     for (int s6 = 0; s6 < NB2; ++s6) {  // no early exit: a single back-edge keeps every in-flight load in place
       const int es = s6 % PD;
       const uint32_t st = bst[s6], en = ben[s6];
+      const uint32_t out_row = brow[s6];
       const u32x4 e1 = e_q[es], e2 = e_q2[es];
       // refill: entries of row r + PD*STRIDE (its bounds sit PD slots further in the ring), bounds of row r + 2*PD*STRIDE
       fetch(bst[(s6 + PD) % NB2], l16, e_q[es]);
       fetch(bst[(s6 + PD) % NB2], l16 + 16, e_q2[es]);
-      bounds(r + NB2 * STRIDE, bst[s6], ben[s6]);
+      bounds(r + NB2 * STRIDE, bst[s6], ben[s6], brow[s6]);
 
       const int nchunks = (int)((en - st) >> 2);
       float acc = 0.f;
@@ -386,7 +441,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
         if (c < nchunks) acc = consume(e3, acc);
       }
       acc = row16_sum(acc);  // DPP: no LDS traffic
-      if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + r] = acc;
+      if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + out_row] = acc;  // positions < nrows are the valid rows
 #ifdef AQLM_PACKED_TRACE
       if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived
 #endif
@@ -428,6 +483,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const Pac
 // layer's workgroups start as CUs free up, so the first layer's tail and the second's LDS fill overlap.
 struct PackedSegment {
   const uint32_t* rowoff;
+  const uint16_t* rowperm;
   const uint32_t* ent;
   const uint8_t* codebook;
   float* partial;
@@ -451,6 +507,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_multi_kernel(con
   for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
     if (k == 0 || sidx == k) {  // scalar select chain (no dynamic indexing of the kernel-argument struct)
       p.rowoff = mp.seg[k].rowoff;
+      p.rowperm = mp.seg[k].rowperm;
       p.ent = mp.seg[k].ent;
       p.codebook = mp.seg[k].codebook;
       p.partial = mp.seg[k].partial;
@@ -541,22 +598,26 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   }
   uint8_t* base = (uint8_t*)packed;
   // header (informational; the kernels take the layout from the shapes)
-  const uint32_t hdr[16] = {0x31505141u, 3u, (uint32_t)L.M, (uint32_t)L.in_groups, 8u, (uint32_t)PK_S, (uint32_t)PK_NG,
+  const uint32_t hdr[16] = {0x31505141u, 4u, (uint32_t)L.M, (uint32_t)L.in_groups, 8u, (uint32_t)PK_S, (uint32_t)PK_NG,
                             (uint32_t)L.RG, (uint32_t)L.entries, (uint32_t)L.off_rowoff, (uint32_t)L.off_ent,
-                            0u, (uint32_t)(L.total & 0xffffffffu), (uint32_t)(L.total >> 32), 0u, 0u};
+                            (uint32_t)L.off_perm, (uint32_t)(L.total & 0xffffffffu), (uint32_t)(L.total >> 32), 0u, 0u};
   if (int e = check_hip(hipMemsetAsync(base, 0, L.off_ent, stream), "prepack memset")) return e;
   if (int e = check_hip(hipMemcpyAsync(base, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream), "prepack header")) return e;
   if (int e = check_hip(hipStreamSynchronize(stream), "prepack header sync")) return e;  // hdr is on the stack
   uint32_t* rowoff = (uint32_t*)(base + L.off_rowoff);
+  uint16_t* perm = (uint16_t*)(base + L.off_perm);
   uint32_t* ent = (uint32_t*)(base + L.off_ent);
   if (int e = check_hip(hipMemsetAsync(ent, 0, L.total - L.off_ent, stream), "prepack memset entries")) return e;
   const int blocks = (L.M + 3) / 4;
   hipLaunchKernelGGL(prepack_count_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, L.M,
                      L.in_groups, L.RG);
+  hipLaunchKernelGGL(prepack_sort_kernel, dim3(PK_NG * PK_S), dim3(1024), 0, stream, rowoff, perm, L.RG);
   hipLaunchKernelGGL(prepack_scan_kernel, dim3(1), dim3(1024), 0, stream, rowoff, L.n_rowoff);
-  hipLaunchKernelGGL(prepack_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, ent, L.M,
-                     L.in_groups, L.RG);
-  hipLaunchKernelGGL(prepack_arrange_kernel, dim3((L.M + 1) / 2), dim3(128), 0, stream, rowoff, ent, L.M, L.in_groups, L.RG);
+  hipLaunchKernelGGL(prepack_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, perm, ent,
+                     L.M, L.in_groups, L.RG);
+  hipLaunchKernelGGL(prepack_arrange_kernel, dim3((L.M + 1) / 2), dim3(128), 0, stream, rowoff, perm, ent, L.M, L.in_groups,
+                     L.RG);
+  hipLaunchKernelGGL(prepack_invert_kernel, dim3(PK_NG * PK_S), dim3(1024), 0, stream, perm, L.RG);
   return check_hip(hipGetLastError(), "prepack launch");
 }
 
@@ -587,6 +648,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   const uint8_t* base = (const uint8_t*)packed;
   PackedGemvParams p{};
   p.rowoff = (const uint32_t*)(base + L.off_rowoff);
+  p.rowperm = (const uint16_t*)(base + L.off_perm);
   p.ent = (const uint32_t*)(base + L.off_ent);
   p.codebook = (const uint8_t*)codebook;
   p.x = (const uint16_t*)x;
@@ -662,6 +724,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     const uint8_t* base = (const uint8_t*)sg.codes;
     PackedSegment& ps = mp.seg[k];
     ps.rowoff = (const uint32_t*)(base + L.off_rowoff);
+    ps.rowperm = (const uint16_t*)(base + L.off_perm);
     ps.ent = (const uint32_t*)(base + L.off_ent);
     ps.codebook = (const uint8_t*)sg.codebook;
     ps.partial = (float*)((uint8_t*)workspace + need);

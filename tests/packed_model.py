@@ -1,4 +1,4 @@
-"""numpy model of the packed 1x16 format v3 (aqlm_amd/csrc/gemv_packed.hip): the bit-exact oracle for
+"""numpy model of the packed 1x16 format v4 (aqlm_amd/csrc/gemv_packed.hip): the bit-exact oracle for
 aqlm_hip_prepack_1x16.  Test infrastructure only."""
 import numpy as np
 
@@ -16,14 +16,17 @@ def layout(out_features, in_features):
     n_rowoff = NG * S * (RG + 1)
     entries = out_features * in_groups + 3 * S * out_features  # capacity incl. null padding
     off_rowoff = 256
-    off_ent = align_up(off_rowoff + n_rowoff * 4, 256)
+    n_perm = NG * S * RG
+    off_perm = align_up(off_rowoff + n_rowoff * 4, 256)
+    off_ent = align_up(off_perm + n_perm * 2, 256)
     total = align_up(off_ent + (entries + PAD) * 4, 256)
-    return dict(in_groups=in_groups, RG=RG, n_rowoff=n_rowoff, entries=entries, off_rowoff=off_rowoff,
-                off_ent=off_ent, total=total)
+    return dict(in_groups=in_groups, RG=RG, n_rowoff=n_rowoff, n_perm=n_perm, entries=entries, off_rowoff=off_rowoff,
+                off_perm=off_perm, off_ent=off_ent, total=total)
 
 
 def pack(codes_unsigned):
-    """codes_unsigned: [M, in_groups] ints in [0, 65536).  Returns (rowoff u32, entries u32 of `entries` length, layout)."""
+    """codes_unsigned: [M, in_groups] ints in [0, 65536).  Returns (rowoff u32, rowperm u16, entries u32, layout).
+    Inside a stream (g, s) the buckets are ordered by padded size, largest first, ties by row index."""
     M, in_groups = codes_unsigned.shape
     L = layout(M, in_groups * 8)
     RG = L["RG"]
@@ -33,6 +36,14 @@ def pack(codes_unsigned):
         c = ((sl == s).sum(axis=1) + 3) // 4 * 4  # buckets padded to multiples of 4 entries
         for r in range(M):
             counts[r // RG, s, r % RG] = c[r]
+    perm = np.zeros((NG, S, RG), dtype=np.uint16)   # position -> row
+    rank = np.zeros((NG, S, RG), dtype=np.int64)    # row -> position
+    for g in range(NG):
+        for s in range(S):
+            order = sorted(range(RG), key=lambda r: (-counts[g, s, r], r))
+            perm[g, s] = order
+            rank[g, s, order] = np.arange(RG)
+            counts[g, s, :RG] = counts[g, s, order]
     flat = counts.reshape(-1)
     rowoff = np.concatenate([[0], np.cumsum(flat)[:-1]]).astype(np.uint32)
     ent = np.zeros(L["entries"], dtype=np.uint32)
@@ -43,11 +54,11 @@ def pack(codes_unsigned):
         for s in range(S):
             js = np.nonzero((row >> 13) == s)[0]
             e = ((js.astype(np.uint32) + XBASE) << 16) | (row[js].astype(np.uint32) & 0x1FFF)
-            b = int(ro[g, s, rl])
+            b = int(ro[g, s, rank[g, s, rl]])
             pad = (-len(js)) % 4
             null = np.uint32((in_groups + XBASE) << 16)  # j = in_groups, code 0
             ent[b:b + len(e) + pad] = arrange(e, len(e) + pad, null)
-    return rowoff, ent, L
+    return rowoff, perm.reshape(-1), ent, L
 
 
 def home_lane(rho):

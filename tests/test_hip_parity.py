@@ -396,22 +396,30 @@ def test_prepack_is_bit_exact(hk, fin, fout):
     codes = torch.from_numpy(L["codes"]).to(DEV)
     packed = hk.prepack_1x16(codes)
     assert packed is not None
-    rowoff, ent, lay = pm.pack(L["codes_unsigned"][:, :, 0])
+    rowoff, perm, ent, lay = pm.pack(L["codes_unsigned"][:, :, 0])
     assert packed.numel() == lay["total"]
     raw = packed.cpu().numpy()
     got_rowoff = raw[lay["off_rowoff"]:lay["off_rowoff"] + lay["n_rowoff"] * 4].view(np.uint32)
+    got_perm = raw[lay["off_perm"]:lay["off_perm"] + lay["n_perm"] * 2].view(np.uint16)
     got_ent = raw[lay["off_ent"]:lay["off_ent"] + lay["entries"] * 4].view(np.uint32)
     np.testing.assert_array_equal(got_rowoff, rowoff)
+    np.testing.assert_array_equal(got_perm, perm)
     np.testing.assert_array_equal(got_ent, ent)
     hdr = raw[:64].view(np.uint32)
-    assert hdr[0] == 0x31505141 and hdr[1] == 3 and hdr[2] == fout and hdr[3] == fin // 8 and hdr[7] == lay["RG"]
+    assert hdr[0] == 0x31505141 and hdr[1] == 4 and hdr[2] == fout and hdr[3] == fin // 8 and hdr[7] == lay["RG"]
     # lossless: the entries reproduce the original codes
     RG = lay["RG"]
     ro = rowoff.reshape(pm.NG, pm.S, RG + 1)
+    pr = got_perm.reshape(pm.NG, pm.S, RG)
     rec = np.full((fout, fin // 8), -1, dtype=np.int64)
+    for g in range(pm.NG):
+        for s in range(pm.S):
+            sizes = np.diff(ro[g, s].astype(np.int64))
+            assert (sizes[:-1] >= sizes[1:]).all() and sorted(pr[g, s].tolist()) == list(range(RG))  # largest first, a permutation
     for r in range(fout):
         for s in range(pm.S):
-            b, e = int(ro[r // RG, s, r % RG]), int(ro[r // RG, s, r % RG + 1])
+            p = int(np.nonzero(pr[r // RG, s] == r % RG)[0][0])   # position of this row in stream (group, s)
+            b, e = int(ro[r // RG, s, p]), int(ro[r // RG, s, p + 1])
             en = got_ent[b:e].astype(np.int64)
             j = (en >> 16) - pm.XBASE
             en = en[j < fin // 8]  # drop the null padding entries
