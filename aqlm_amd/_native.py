@@ -52,6 +52,7 @@ SIGNATURES = {
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_dequant_1x16": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_dequant_kx8": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "aqlm_hip_dequant_generic": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_gemm_1x16_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
     "aqlm_hip_set_tuning": (_ci, [ctypes.c_char_p, _ci]),

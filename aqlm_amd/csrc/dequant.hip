@@ -234,3 +234,19 @@ extern "C" int aqlm_hip_dequant_kx8(const void* codes, const void* codebooks, co
   if (K == 2) return launch_dequant<BF16, 1, 2, 8, true, 256>(p, stream);
   return launch_dequant<BF16, 1, 8, 32, true, 1024>(p, stream);
 }
+
+extern "C" int aqlm_hip_dequant_generic(const void* codes, const void* codebooks, const void* scales, void* W,
+                                        int out_features, int in_features, int num_codebooks, int nbits,
+                                        int in_group_size, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = validate_dequant(codes, codebooks, W, out_features, in_features, in_group_size, dtype,
+                               "aqlm_hip_dequant_generic"))
+    return e;
+  if (num_codebooks < 1 || nbits < 1 || nbits > 16) {
+    set_last_error("aqlm_hip_dequant_generic: num_codebooks %d / nbits %d outside what the code containers hold",
+                   num_codebooks, nbits);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  return run_dequant_generic(codes, codebooks, scales, W, out_features, in_features, num_codebooks, nbits,
+                             in_group_size, dtype, stream);
+}

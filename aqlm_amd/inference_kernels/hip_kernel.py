@@ -359,6 +359,11 @@ def _dequant(codes, codebooks, scales, kind):
         if kind == "1x16":
             rc = _lib.aqlm_hip_dequant_1x16(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
                                             out_features, in_features, in_group_size, dt, _stream_ptr())
+        elif kind == "generic":
+            nbits = int(codebook_size).bit_length() - 1
+            rc = _lib.aqlm_hip_dequant_generic(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
+                                               out_features, in_features, num_codebooks, nbits, in_group_size, dt,
+                                               _stream_ptr())
         else:
             rc = _lib.aqlm_hip_dequant_kx8(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
                                            out_features, in_features, num_codebooks, in_group_size, dt, _stream_ptr())
@@ -454,6 +459,25 @@ def _matmat_dequant_transposed(input, codes, codebooks, scales, bias, kind):
     return out
 
 
+def generic_dequant(codes, codebooks, scales):
+    """W[out, in] for any scheme (aqlm_hip_dequant_generic) -- the reference's `_dequantize_weight` (utils.py:43-70)."""
+    return _dequant(codes, codebooks, scales.reshape(-1) if scales is not None else None, "generic")
+
+
+def generic_matmat_dequant(input, codes, codebooks, scales, bias=None):
+    """Large-batch forward of a scheme without a tuned kernel: generic dequant + library GEMM (dequantize_gemm,
+    dequantization.py:9-21).  W is kept unscaled (exact); y is scaled afterwards."""
+    _dtype_id(input)
+    W = _dequant(codes, codebooks, None, "generic")
+    y = F.linear(input, W) * scales.reshape(1, -1).to(input.dtype)
+    return y if bias is None else y + bias
+
+
+def generic_matmat_dequant_transposed(input, codes, codebooks, scales, bias=None):
+    """Backward of any scheme: grad_input = (grad_output * scales) @ W (kernel_selector.py:145-161)."""
+    return _matmat_dequant_transposed(input, codes, codebooks, scales, bias, "generic")
+
+
 def code1x16_matmat_dequant_transposed(input, codes, codebooks, scales, bias=None):
     return _matmat_dequant_transposed(input, codes, codebooks, scales, bias, "1x16")
 
@@ -495,6 +519,8 @@ _OPS = {
     # additions (no reference counterpart: the reference sends these schemes to Triton)
     "codekx8_matmat": (codekx8_matmat, _fake_forward),
     "generic_matmat": (generic_matmat, _fake_forward),
+    "generic_matmat_dequant": (generic_matmat_dequant, _fake_forward),
+    "generic_matmat_dequant_transposed": (generic_matmat_dequant_transposed, _fake_transposed),
 }
 
 for _name, (_impl, _fake) in _OPS.items():
@@ -530,6 +556,9 @@ HIP_KERNEL = SimpleNamespace(
     code1x8_matmat_dequant_transposed=code1x8_matmat_dequant_transposed,
     codekx8_matmat=codekx8_matmat,
     generic_matmat=generic_matmat,
+    generic_dequant=generic_dequant,
+    generic_matmat_dequant=generic_matmat_dequant,
+    generic_matmat_dequant_transposed=generic_matmat_dequant_transposed,
     code1x16_matmat_multi=code1x16_matmat_multi,
     codekx8_matmat_multi=codekx8_matmat_multi,
 )

@@ -59,13 +59,8 @@ def get_forward_pass_kernel(
     if codebook_size == 256 and in_group_size % 8 == 0 and num_codebooks <= 16:
         return hip_kernel.code2x8_matmat_dequant if optimize_for_training else ops.codekx8_matmat
     if optimize_for_training:
-        return _generic_dequant_gemm
+        return ops.generic_matmat_dequant  # generic dequant + library GEMM (the reference's dequantize_gemm)
     return ops.generic_matmat
-
-
-def _generic_dequant_gemm(input, codes, codebooks, scales, bias):
-    """Large-batch path for schemes without a tuned kernel: chunks of 8 rows through the generic gemv."""
-    return torch.ops.aqlm.generic_matmat(input, codes, codebooks, scales, bias)
 
 
 def get_backward_pass_kernel(
@@ -87,12 +82,10 @@ def get_backward_pass_kernel(
         kern = ops.code2x8_matmat_dequant_transposed
     elif (num_codebooks, codebook_size, in_group_size) == (1, 256, 8):
         kern = ops.code1x8_matmat_dequant_transposed
-    elif codebook_size == 256:
+    elif codebook_size == 256 and in_group_size % 8 == 0:
         kern = hip_kernel.code2x8_matmat_dequant_transposed
-    else:
-        raise NotImplementedError(
-            f"no backward kernel for {num_codebooks}x{codebook_size.bit_length() - 1} g{in_group_size} on MI355X yet"
-        )
+    else:  # any other scheme: generic dequant + GEMM (the reference transposes the tensors and reuses its forward kernel)
+        kern = ops.generic_matmat_dequant_transposed
 
     def _backward(grad_output, codes, codebooks, scales, bias):
         # the layer's bias does not enter grad_input (reference kernel_selector.py:160 passes None as well)

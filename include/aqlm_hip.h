@@ -142,6 +142,15 @@ int aqlm_hip_dequant_kx8(const void* codes_i8, const void* codebooks, const void
                          void* stream);
 
 /*
+ * The same for ANY scheme (num_codebooks, nbits <= 16 in 8- / 16-bit containers, any in_group_size): the role of the
+ * reference's torch fallback `_dequantize_weight` (utils.py:43-70) for schemes without a tuned kernel -- used by the
+ * large-batch and backward ops of such schemes.
+ */
+int aqlm_hip_dequant_generic(const void* codes, const void* codebooks, const void* scales /* nullable */, void* W,
+                             int out_features, int in_features, int num_codebooks, int nbits, int in_group_size,
+                             int dtype, void* stream);
+
+/*
  * Large-batch path: Y[B][out] = (X[B][in] @ W^T) * scales + bias with W dequantised tile-by-tile into LDS and
  * contracted on the matrix cores (v_mfma_f32_32x32x16_f16/bf16); W never touches HBM.
  * Replaces: code1x16_matmat_dequant = Code1x16Dequant + F::linear(cuBLAS) + epilogue (cuda_kernel.cpp:249-301).

@@ -777,3 +777,43 @@ def test_prepack_model_runs_the_load_time_repack_eagerly(hk):
         T = to_dev(Ls[n], torch.float16)
         y64 = orc.dequantize_gemm(Ls[n]["x"], Ls[n]["codes"], Ls[n]["codebooks"], Ls[n]["scales"], Ls[n]["bias"])
         check_close(m(T["x"]).float().cpu().numpy(), y64, torch.float16, f"prepack_model {n}")
+
+
+# ------------------------------------------------------------------ randomized shapes (seeded): every route, odd sizes
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_layer_against_oracle(hk, seed):
+    """Random scheme / shape / batch / dtype / bias per seed, module-level forward (so the gemv rule, the large-batch
+    op, the prepacked route -- threshold lowered -- and the generic kernels all get hit) against the fp64 oracle."""
+    import aqlm_amd.inference as inf
+
+    rng = np.random.default_rng(1000 + seed)
+    K, nbits, g = [(1, 16, 8), (1, 16, 16), (2, 8, 8), (1, 8, 8), (8, 8, 32), (4, 8, 16), (1, 12, 8), (2, 8, 4)][seed % 8]
+    unit = g * int(rng.choice([1, 8, 8, 16]))            # in_features: sometimes not a multiple of 8 groups
+    fin = unit * int(rng.integers(1, 24))
+    fout = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 700)), 1024]))
+    rows = int(rng.choice([1, 1, 2, 5, 6, 7, 13, 40]))
+    dt = "float16" if rng.random() < 0.7 else "bfloat16"
+    bias = bool(rng.random() < 0.5)
+    dtype = tdtype(dt)
+    L = orc.make_layer(2000 + seed, fin, fout, K, nbits, g, batch=rows, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    old, inf.PREPACK_MIN_CODES = inf.PREPACK_MIN_CODES, 20_000
+    try:
+        m, T = _module_from(L, K, nbits, g, fin, fout, dtype)
+        with torch.no_grad():
+            y = m(T["x"])
+            y_again = m(T["x"])
+    finally:
+        inf.PREPACK_MIN_CODES = old
+    assert y.shape == (rows, fout) and torch.equal(y, y_again)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, f"seed {seed}: {K}x{nbits}g{g} {fin}->{fout} rows={rows} {dt} bias={bias}")
+    if seed % 2 == 0:   # backward through the module (every scheme has a route): grad_input = grad_output @ W
+        xg = T["x"].clone().requires_grad_(True)
+        go = torch.randn(rows, fout, generator=torch.Generator().manual_seed(seed)).to(dtype).to(DEV)
+        m(xg).backward(go)
+        W64 = orc.dequantize_weight(L["codes_unsigned"], L["codebooks"], L["scales"])
+        g64 = go.double().cpu().numpy() @ W64
+        got = xg.grad.float().cpu().numpy()
+        rel = np.mean(np.abs(got - g64)) / np.mean(np.abs(g64))
+        assert rel <= (2e-3 if dtype == torch.float16 else 1.2e-2), f"seed {seed}: grad_input mean-rel {rel:.3e}"
