@@ -397,6 +397,15 @@ def code1x8_dequant(codes, codebooks, scales):
 FUSED_MFMA_MAX_ROWS = 128
 
 
+def _scale_bias_fp32(y, scales, bias):
+    """y * scales + bias for the dequant + library-GEMM routes, in fp32 with one final rounding (the fused kernels do
+    the same in registers; the reference does it in the output dtype, cuda_kernel.cpp:95-111)."""
+    out = y.float() * scales.reshape(1, -1).float()
+    if bias is not None:
+        out = out + bias.float()
+    return out.to(y.dtype)
+
+
 def _fused_mfma_ok(x, in_features):
     return in_features % 64 == 0 and x.shape[0] <= FUSED_MFMA_MAX_ROWS
 
@@ -415,8 +424,7 @@ def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
     if not _fused_mfma_ok(x, in_features):
         # unscaled W is exact in the storage dtype (it IS the codebook entries); scaling W instead of y would round it
         W = _dequant(codes, codebooks, None, "1x16")
-        y = torch.addcmul(bias, F.linear(x, W), scales.reshape(1, -1)) if bias is not None else F.linear(x, W) * scales.reshape(1, -1)
-        return y.reshape(input.shape[:-1] + (out_features,))
+        return _scale_bias_fp32(F.linear(x, W), scales, bias).reshape(input.shape[:-1] + (out_features,))
     codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
     if bias is not None:
         bias = _c(bias)
@@ -433,11 +441,13 @@ def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
 
 
 def _matmat_dequant_kx8(input, codes, codebooks, scales, bias):
-    """Reference pipeline for the 8-bit schemes (cuda_kernel.cpp:450-484, 615-649): dequantise (our kernel, scales
-    folded in) then one library GEMM."""
+    """Reference pipeline for the 8-bit schemes (cuda_kernel.cpp:450-484, 615-649): dequantise (our kernel), one
+    library GEMM, scale + bias."""
     _dtype_id(input)
-    W = _dequant(codes, codebooks, scales, "kx8")
-    return F.linear(input, W, bias)
+    # W without the scales: exact for one codebook, one rounding of the K-term sum otherwise (as in the reference, which
+    # also scales y after the GEMM, cuda_kernel.cpp:478-483); folding the scales into W would round every weight again
+    W = _dequant(codes, codebooks, None, "kx8")
+    return _scale_bias_fp32(F.linear(input, W), scales, bias)
 
 
 def code2x8_matmat_dequant(input, codes, codebooks, scales, bias=None):
@@ -469,8 +479,7 @@ def generic_matmat_dequant(input, codes, codebooks, scales, bias=None):
     dequantization.py:9-21).  W is kept unscaled (exact); y is scaled afterwards."""
     _dtype_id(input)
     W = _dequant(codes, codebooks, None, "generic")
-    y = F.linear(input, W) * scales.reshape(1, -1).to(input.dtype)
-    return y if bias is None else y + bias
+    return _scale_bias_fp32(F.linear(input, W), scales, bias)
 
 
 def generic_matmat_dequant_transposed(input, codes, codebooks, scales, bias=None):

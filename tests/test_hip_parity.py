@@ -50,12 +50,13 @@ def ulp(y, dtype):
     return 2.0 ** (e - mant)
 
 
-def check_close(y, y64, dtype, what=""):
+def check_close(y, y64, dtype, what="", el_scale=1.0):
     y = np.asarray(y, dtype=np.float64)
     y64 = np.asarray(y64, dtype=np.float64)
     assert y.shape == y64.shape, (y.shape, y64.shape)
     assert np.isfinite(y).all(), f"{what}: non-finite output"
     mean_tol, el_tol = (1e-3, 2e-3) if dtype == torch.float16 else (8e-3, 1.6e-2)
+    el_tol *= el_scale
     m = np.mean(np.abs(y - y64)) / np.mean(np.abs(y64))
     assert m <= mean_tol, f"{what}: mean-rel {m:.3e} > {mean_tol}"
     bound = el_tol * np.mean(np.abs(y64)) + 4 * ulp(y64, dtype)
@@ -780,7 +781,7 @@ def test_prepack_model_runs_the_load_time_repack_eagerly(hk):
 
 
 # ------------------------------------------------------------------ randomized shapes (seeded): every route, odd sizes
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_randomized_layer_against_oracle(hk, seed):
     """Random scheme / shape / batch / dtype / bias per seed, module-level forward (so the gemv rule, the large-batch
     op, the prepacked route -- threshold lowered -- and the generic kernels all get hit) against the fp64 oracle."""
@@ -791,6 +792,9 @@ def test_randomized_layer_against_oracle(hk, seed):
     unit = g * int(rng.choice([1, 8, 8, 16]))            # in_features: sometimes not a multiple of 8 groups
     fin = unit * int(rng.integers(1, 24))
     fout = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 700)), 1024]))
+    if seed >= 24:                                       # second half: larger layers
+        fin = g * 8 * int(rng.integers(8, 8192 // (g * 8) + 1))
+        fout = int(rng.integers(700, 5000))
     rows = int(rng.choice([1, 1, 2, 5, 6, 7, 13, 40]))
     dt = "float16" if rng.random() < 0.7 else "bfloat16"
     bias = bool(rng.random() < 0.5)
@@ -800,14 +804,29 @@ def test_randomized_layer_against_oracle(hk, seed):
     old, inf.PREPACK_MIN_CODES = inf.PREPACK_MIN_CODES, 20_000
     try:
         m, T = _module_from(L, K, nbits, g, fin, fout, dtype)
+        x_in = T["x"]
+        if seed % 3 == 1:      # non-contiguous rows: a column slice of a wider tensor
+            wide = torch.zeros(rows, fin + 24, dtype=dtype, device=DEV)
+            wide[:, 8:8 + fin] = T["x"]
+            x_in = wide[:, 8:8 + fin]
         with torch.no_grad():
-            y = m(T["x"])
+            y = m(x_in)
             y_again = m(T["x"])
+            if seed % 3 == 2 and rows % 2 == 0:   # leading dimensions are flattened and restored
+                y3 = m(T["x"].reshape(2, rows // 2, fin))
+                assert y3.shape == (2, rows // 2, fout) and torch.equal(y3.reshape(rows, fout), y)
     finally:
         inf.PREPACK_MIN_CODES = old
     assert y.shape == (rows, fout) and torch.equal(y, y_again)
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-    check_close(y.float().cpu().numpy(), y64, dtype, f"seed {seed}: {K}x{nbits}g{g} {fin}->{fout} rows={rows} {dt} bias={bias}")
+    # routes that materialise W in the storage dtype (large batch, several codebooks) round the K-term sum of every
+    # weight once -- exactly what the reference's dequant + GEMM path does; with 10^5 outputs the 4.5-sigma tail of that
+    # noise needs a slightly wider per-element bound (the mean bound is unchanged)
+    wide = 1.0
+    if rows > 6 and K > 1:
+        wide = 1.6 if dtype == torch.float16 else 3.0   # bf16: the GEMM output itself is rounded to 8 bits before bias
+    check_close(y.float().cpu().numpy(), y64, dtype, f"seed {seed}: {K}x{nbits}g{g} {fin}->{fout} rows={rows} {dt} bias={bias}",
+                el_scale=wide)
     if seed % 2 == 0:   # backward through the module (every scheme has a route): grad_input = grad_output @ W
         xg = T["x"].clone().requires_grad_(True)
         go = torch.randn(rows, fout, generator=torch.Generator().manual_seed(seed)).to(dtype).to(DEV)
