@@ -836,3 +836,47 @@ def test_randomized_layer_against_oracle(hk, seed):
         got = xg.grad.float().cpu().numpy()
         rel = np.mean(np.abs(got - g64)) / np.mean(np.abs(g64))
         assert rel <= (2e-3 if dtype == torch.float16 else 1.2e-2), f"seed {seed}: grad_input mean-rel {rel:.3e}"
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomized_shared_input_groups(hk, seed):
+    """Random member count / scheme / shapes / rows for shared-input groups; 1x16 outputs must equal the unfused
+    modules bit for bit, K x 8 outputs within the parity bound; both against the oracle."""
+    import aqlm
+    import aqlm_amd.inference as inf
+
+    rng = np.random.default_rng(3000 + seed)
+    K, nbits, g = [(1, 16, 8), (2, 8, 8), (1, 16, 16), (1, 8, 8)][seed % 4]
+    n = int(rng.integers(2, 5))
+    fin = g * 8 * int(rng.integers(2, 40))
+    fouts = [int(rng.choice([int(rng.integers(8, 200)), int(rng.integers(200, 3000))])) for _ in range(n)]
+    rows = int(rng.choice([1, 1, 2, 6]))
+    dt = "float16" if seed % 3 else "bfloat16"
+    dtype = tdtype(dt)
+    fd = np.float16 if dtype == torch.float16 else "bfloat16"
+    old, inf.PREPACK_MIN_CODES = inf.PREPACK_MIN_CODES, (30_000 if seed % 2 else 0)
+    try:
+        holder = torch.nn.Module()
+        Ls, x = [], None
+        names = ["q_proj", "k_proj", "v_proj", "gate_proj", "up_proj"]
+        pats = [tuple(names[:n])]
+        for k in range(n):
+            L = orc.make_layer(3100 + 10 * seed + k, fin, fouts[k], K, nbits, g, batch=rows, bias=bool(k % 2), float_dtype=fd)
+            m, T = _module_from(L, K, nbits, g, fin, fouts[k], dtype)
+            setattr(holder, names[k], m)
+            Ls.append(L)
+            x = T["x"] if x is None else x
+        with torch.no_grad():
+            ref = [getattr(holder, names[k])(x) for k in range(n)]
+            groups = aqlm.fuse_shared_input_linears(holder, patterns=pats)
+            assert len(groups) == 1 and len(groups[0].members) == n
+            got = [getattr(holder, names[k])(x) for k in range(n)]
+            assert (groups[0].launches, groups[0].served) == (1, n - 1)
+            aqlm.unfuse_shared_input_linears(holder)
+    finally:
+        inf.PREPACK_MIN_CODES = old
+    for k in range(n):
+        y64 = orc.dequantize_gemm(Ls[0]["x"], Ls[k]["codes"], Ls[k]["codebooks"], Ls[k]["scales"], Ls[k]["bias"])
+        check_close(got[k].float().cpu().numpy(), y64, dtype, f"seed {seed} member {k}")
+        if nbits == 16:
+            assert torch.equal(got[k], ref[k]), f"seed {seed} member {k}: fused 1x16 output differs from the unfused module"
