@@ -51,6 +51,7 @@ struct GemmParams {
   int ksplit;
   long xs;
   int cb_bytes;
+  uint32_t x_bytes;  // extent of the X slab (rows >= B read as zeros through the bounds-checked descriptor)
 };
 
 constexpr int BK = 64;  // k depth of one LDS chunk of X
@@ -89,27 +90,36 @@ __global__ __launch_bounds__(256) void gemm_1x16_mfma_kernel(const GemmParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // global -> register staging of one X chunk (zero beyond B or K)
-  u32x4 xr[PER_THREAD];
-  auto load_x = [&](int chunk) {
-    const int k0 = k_begin + chunk * BK;
+  // global -> register staging of one X chunk.  The loads are UNCONDITIONAL buffer loads (rows >= B and k >= k_end
+  // read as zeros through the bounds-checked descriptor / an out-of-range offset): with the load under a branch hipcc
+  // emitted vmcnt(0) right behind it, i.e. every chunk step first waited ~1 us for X and only then issued the
+  // codebook gathers of the next chunk (traced through the ISA: one L2 latency + one gather latency per 64-deep chunk).
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+  static_assert(PIECES % 256 == 0, "the X chunk splits evenly over the block");
+  u32x4 xr[2][PER_THREAD];  // X chunks run two ahead in registers, one ahead in LDS
+  uint32_t xoff[PER_THREAD];
+#pragma unroll
+  for (int s = 0; s < PER_THREAD; ++s) {
+    const int q = tid + s * 256;
+    xoff[s] = (uint32_t)(((long)(q >> 3) * p.xs + k_begin + (q & 7) * 8) * 2);
+  }
+  auto load_x = [&](int chunk, u32x4 (&dst)[PER_THREAD]) {
+#pragma unroll
+    for (int s = 0; s < PER_THREAD; ++s) {
+      const bool in_k = k_begin + chunk * BK + (int)((tid + s * 256) & 7) * 8 < k_end;
+      dst[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, in_k ? xoff[s] + (uint32_t)chunk * (BK * 2) : 0xfffffff0u, 0, 0);
+    }
+  };
+  auto store_x = [&](int buf, const u32x4 (&src)[PER_THREAD]) {
 #pragma unroll
     for (int s = 0; s < PER_THREAD; ++s) {
       const int q = tid + s * 256;
-      const int b = q >> 3, c = q & 7;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (q < PIECES && b < p.B && k0 + c * 8 < k_end) v = *reinterpret_cast<const u32x4*>(p.X + (long)b * p.xs + k0 + c * 8);
-      xr[s] = v;
+      xl[buf][xswz(q >> 3, q & 7)] = src[s];
     }
   };
-  auto store_x = [&](int buf) {
-#pragma unroll
-    for (int s = 0; s < PER_THREAD; ++s) {
-      const int q = tid + s * 256;
-      if (q < PIECES) xl[buf][xswz(q >> 3, q & 7)] = xr[s];
-    }
-  };
-  auto load_codes = [&](int chunk, uint32_t (&cw)[CWN]) {
+  const int last_chunk = nchunks - 1;
+  auto load_codes = [&](int chunk, uint32_t (&cw)[CWN]) {  // unconditional: chunks past the slice re-read the last one
+    chunk = chunk < last_chunk ? chunk : last_chunk;
     const int k0 = k_begin + chunk * BK;
     const uint8_t* src = code_row + (long)(k0 / G) * 2;
     if constexpr (CWN == 4) {
@@ -137,26 +147,17 @@ __global__ __launch_bounds__(256) void gemm_1x16_mfma_kernel(const GemmParams p)
     }
   };
 
-  // Software pipeline: codes run two chunks ahead, codebook gathers one chunk ahead of the MFMAs that consume them.
-  // The loop is unrolled by two with ping-pong roles (A/B) so that no register with a load in flight is ever copied
-  // (a copy forces hipcc to wait for the load it was just issued for: measured 3.3 us per chunk).
-  uint32_t cw_a[CWN], cw_b[CWN];
-  u32x4 af_a[4], af_b[4];
-  load_x(0);
-  load_codes(0, cw_a);
-  if (nchunks > 1) load_codes(1, cw_b);
-  gather(cw_a, af_a);
-  store_x(0);
-  __syncthreads();
-
-  auto step = [&](int ch, uint32_t (&cw_free)[CWN], const uint32_t (&cw_next)[CWN], const u32x4 (&af_cur)[4], u32x4 (&af_nxt)[4]) {
-    const int buf = ch & 1;
-    const bool more = ch + 1 < nchunks;
-    if (more) {
-      load_x(ch + 1);
-      gather(cw_next, af_nxt);                             // chunk ch+1's entries fly during this chunk's MFMAs
-      if (ch + 2 < nchunks) load_codes(ch + 2, cw_free);   // cw_free's gathers were issued one step ago
-    }
+  // Software pipeline, in batches of NBATCH chunks.  Inside a batch the code is straight-line (fully unrolled, static
+  // ring slots): all code words of the batch are requested up front, codebook gathers run GD-1 = 3 chunks ahead of
+  // the MFMAs that consume them (one 64-deep chunk of MFMAs is ~0.3 us, an L2 gather ~1.5 us under load: a distance of
+  // one chunk left every step waiting for its own gathers), X runs two chunks ahead in registers and one in LDS, and
+  // NOTHING is in flight across the loop back-edge: hipcc's wait-count pass merges the prologue and back-edge states at
+  // a loop header and then waits with vmcnt(0) for every register loaded in the previous iteration.  A batch pays one
+  // pipeline refill instead (none at all for K slices of <= NBATCH chunks, e.g. 4096 x 4096 with the 8-way K split).
+  constexpr int NBATCH = 8, GD = 4;
+  uint32_t cw[NBATCH][CWN];
+  u32x4 af[GD][4];
+  auto mfmas = [&](int buf, const u32x4 (&af_cur)[4]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -165,12 +166,25 @@ __global__ __launch_bounds__(256) void gemm_1x16_mfma_kernel(const GemmParams p)
         acc[t] = mfma32<T>(af_cur[kk], bfrag, acc[t]);
       }
     }
-    if (more) store_x(buf ^ 1);
-    __syncthreads();
   };
-  for (int ch = 0; ch < nchunks; ch += 2) {
-    step(ch, cw_a, cw_b, af_a, af_b);
-    if (ch + 1 < nchunks) step(ch + 1, cw_b, cw_a, af_b, af_a);
+  for (int base = 0; base < nchunks; base += NBATCH) {
+#pragma unroll
+    for (int c = 0; c < NBATCH; ++c) load_codes(base + c, cw[c]);
+    load_x(base, xr[0]);
+    load_x(base + 1, xr[1]);
+#pragma unroll
+    for (int c = 0; c < GD - 1; ++c) gather(cw[c], af[c]);
+    store_x(0, xr[0]);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NBATCH; ++s) {
+      const int buf = s & 1;  // NBATCH is even: the first chunk of every batch uses buffer 0
+      if (s + GD - 1 < NBATCH) gather(cw[s + GD - 1], af[(s + GD - 1) % GD]);   // compile-time conditions only
+      if (s + 2 < NBATCH) load_x(base + s + 2, xr[s % 2]);                       // slot of chunk s: already in LDS
+      mfmas(buf, af[s % GD]);
+      if (s + 1 < NBATCH) store_x(buf ^ 1, xr[(s + 1) % 2]);
+      __syncthreads();
+    }
   }
 
   // fp32 partials: C layout col = lane&31 (batch), row = (r&3) + 8*(r>>2) + 4*half
@@ -511,6 +525,7 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
     p.ksplit = g.ksplit;
     p.xs = xs;
     p.cb_bytes = 65536 * in_group_size * 2;
+    p.x_bytes = (uint32_t)std::min<long>(((long)(nb - 1) * xs + in_features) * 2, 0xffffffffL);
     int e;
     if (dtype == AQLM_HIP_F16)
       e = in_group_size == 8 ? launch_gemm<F16, 8>(p, g.nbt, stream) : launch_gemm<F16, 16>(p, g.nbt, stream);
