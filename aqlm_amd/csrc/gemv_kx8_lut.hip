@@ -43,15 +43,16 @@ struct LutParams {
   int M, in_groups, nslabs, nranges, rows_per_range;
 };
 
+// `block` = the workgroup's index within its own layer (== blockIdx.x for a single-layer launch)
 template <class T, int G>
-__global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
+__device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* const lut = reinterpret_cast<float*>(smem_raw);  // [16 groups][8 codebooks][256]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, quarter = lane >> 4;
-  const int slab = blockIdx.x % p.nslabs, range = blockIdx.x / p.nslabs;
+  const int slab = block % p.nslabs, range = block / p.nslabs;
   const int j0 = slab * LUT_JS;
   const int row_begin = range * p.rows_per_range;
   int nrows = p.M - row_begin;
@@ -122,6 +123,47 @@ __global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
   }
 }
 
+template <class T, int G>
+__global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
+  gemv_8x8_lut_body<T, G>(p, blockIdx.x);
+}
+
+// shared-input launch: up to AQLM_HIP_MAX_SEGMENTS layers (own codes / codebooks / partials) times one x
+struct LutSegment {
+  const uint8_t* codes;
+  const uint16_t* codebooks;
+  float* partial;
+  int M, nranges, rows_per_range, block_begin;
+};
+
+struct LutMultiParams {
+  const uint16_t* x;
+  int in_groups, nslabs, nseg;
+  LutSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+template <class T, int G>
+__global__ __launch_bounds__(1024) void gemv_8x8_lut_multi_kernel(const LutMultiParams mp) {
+  LutParams p{};
+  p.x = mp.x;
+  p.in_groups = mp.in_groups;
+  p.nslabs = mp.nslabs;
+  int begin = 0;
+#pragma unroll
+  for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
+    if (k == 0 || (k < mp.nseg && (int)blockIdx.x >= mp.seg[k].block_begin)) {  // scalar select chain
+      p.codes = mp.seg[k].codes;
+      p.codebooks = mp.seg[k].codebooks;
+      p.partial = mp.seg[k].partial;
+      p.M = mp.seg[k].M;
+      p.nranges = mp.seg[k].nranges;
+      p.rows_per_range = mp.seg[k].rows_per_range;
+      begin = mp.seg[k].block_begin;
+    }
+  }
+  gemv_8x8_lut_body<T, G>(p, (int)blockIdx.x - begin);
+}
+
 struct LutFinalizeParams {
   const float* partial;
   const uint16_t* scales;
@@ -133,6 +175,36 @@ struct LutFinalizeParams {
 template <class T>
 __global__ __launch_bounds__(256) void gemv_8x8_lut_finalize(const LutFinalizeParams p) {
   const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.M) return;
+  float s = 0.f;
+  for (int k = 0; k < p.nslabs; ++k) s += p.partial[(size_t)k * p.M + row];
+  const float scale = T::to_float(p.scales[row]);
+  const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
+}
+
+struct LutFinalizeSegment {
+  LutFinalizeParams f;
+  int block_begin;
+};
+
+struct LutFinalizeMultiParams {
+  int nseg;
+  LutFinalizeSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gemv_8x8_lut_finalize_multi(const LutFinalizeMultiParams mp) {
+  LutFinalizeParams p = mp.seg[0].f;
+  int begin = 0;
+#pragma unroll
+  for (int k = 1; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
+    if (k < mp.nseg && (int)blockIdx.x >= mp.seg[k].block_begin) {
+      p = mp.seg[k].f;
+      begin = mp.seg[k].block_begin;
+    }
+  }
+  const int row = ((int)blockIdx.x - begin) * 256 + threadIdx.x;
   if (row >= p.M) return;
   float s = 0.f;
   for (int k = 0; k < p.nslabs; ++k) s += p.partial[(size_t)k * p.M + row];
@@ -193,9 +265,112 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
   return check_hip(hipGetLastError(), "gemv_8x8_lut_finalize launch");
 }
 
+template <class T, int G>
+static int launch_lut_multi(const LutMultiParams& mp, int blocks, hipStream_t stream) {
+  auto kern = gemv_8x8_lut_multi_kernel<T, G>;
+  const size_t lds = (size_t)LUT_ENTRIES * 4;
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, mp);
+  return check_hip(hipGetLastError(), "gemv_8x8_lut_multi launch");
+}
+
+// Shared-input variant: the ~256 workgroups are dealt to the segments in proportion to their rows.  Bit-identical to
+// gemv_8x8_lut per segment only when the row ranges coincide; in general equal to fp32 rounding (same table, same
+// per-row summation order -- only the slab partials are the same, so in fact results ARE identical: a row's value does
+// not depend on its range).  workspace: sum over segments of gemv_8x8_lut_workspace(...).
+int gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                       int in_group_size, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int G = in_group_size;
+  if (G != 8 && G != 16 && G != 32) return AQLM_HIP_E_UNSUPPORTED;
+  LutMultiParams mp{};
+  LutFinalizeMultiParams fm{};
+  mp.x = (const uint16_t*)x;
+  mp.in_groups = in_features / G;
+  mp.nslabs = (mp.in_groups + LUT_JS - 1) / LUT_JS;
+  mp.nseg = fm.nseg = num_segments;
+  long total = 0;
+  for (int k = 0; k < num_segments; ++k) total += segments[k].out_features;
+  const int total_ranges = std::max(num_segments, 256 / mp.nslabs);
+  size_t need = 0;
+  int blocks = 0, fblocks = 0;
+  for (int k = 0; k < num_segments; ++k) {
+    const aqlm_hip_segment& sg = segments[k];
+    LutSegment& ls = mp.seg[k];
+    ls.codes = (const uint8_t*)sg.codes;
+    ls.codebooks = (const uint16_t*)sg.codebook;
+    ls.partial = (float*)((uint8_t*)workspace + need);
+    ls.M = sg.out_features;
+    ls.nranges = std::max(1, (int)(((long)total_ranges * sg.out_features + total / 2) / total));
+    ls.rows_per_range = (sg.out_features + ls.nranges - 1) / ls.nranges;
+    ls.nranges = (sg.out_features + ls.rows_per_range - 1) / ls.rows_per_range;
+    ls.block_begin = blocks;
+    blocks += mp.nslabs * ls.nranges;
+    LutFinalizeSegment& fs = fm.seg[k];
+    fs.f.partial = ls.partial;
+    fs.f.scales = (const uint16_t*)sg.scales;
+    fs.f.bias = (const uint16_t*)sg.bias;
+    fs.f.y = (uint16_t*)sg.y;
+    fs.f.M = sg.out_features;
+    fs.f.nslabs = mp.nslabs;
+    fs.block_begin = fblocks;
+    fblocks += (sg.out_features + 255) / 256;
+    need += (size_t)mp.nslabs * sg.out_features * sizeof(float);
+  }
+  if (!workspace || workspace_bytes < need) return AQLM_HIP_E_INVALID;
+  int e;
+  if (dtype == AQLM_HIP_F16)
+    e = G == 8 ? launch_lut_multi<F16, 8>(mp, blocks, stream) : G == 16 ? launch_lut_multi<F16, 16>(mp, blocks, stream)
+                                                                         : launch_lut_multi<F16, 32>(mp, blocks, stream);
+  else
+    e = G == 8 ? launch_lut_multi<BF16, 8>(mp, blocks, stream) : G == 16 ? launch_lut_multi<BF16, 16>(mp, blocks, stream)
+                                                                          : launch_lut_multi<BF16, 32>(mp, blocks, stream);
+  if (e) return e;
+  if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(gemv_8x8_lut_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);
+  else hipLaunchKernelGGL(gemv_8x8_lut_finalize_multi<BF16>, dim3(fblocks), dim3(256), 0, stream, fm);
+  return check_hip(hipGetLastError(), "gemv_8x8_lut_finalize_multi launch");
+}
+
 }  // namespace aqlm
 
 using namespace aqlm;
+
+extern "C" int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                           int in_features, int in_group_size, int dtype, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (!segments || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS || !x) {
+    set_last_error("aqlm_hip_gemv_8x8_lut_multi: 1..%d segments and a non-null x required (got %d)", AQLM_HIP_MAX_SEGMENTS,
+                   num_segments);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (in_features <= 0 || in_group_size <= 0 || in_features % in_group_size != 0) {
+    set_last_error("aqlm_hip_gemv_8x8_lut_multi: bad sizes in=%d g=%d", in_features, in_group_size);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
+    set_last_error("aqlm_hip_gemv_8x8_lut_multi: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)", dtype);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  for (int k = 0; k < num_segments; ++k) {
+    const aqlm_hip_segment& sg = segments[k];
+    if (!sg.codes || !sg.codebook || !sg.scales || !sg.y || sg.out_features <= 0) {
+      set_last_error("aqlm_hip_gemv_8x8_lut_multi: null pointer or non-positive size in segment %d", k);
+      return AQLM_HIP_E_INVALID;
+    }
+    if (!aligned16(sg.codebook) || (reinterpret_cast<uintptr_t>(sg.codes) & 7u)) {
+      set_last_error("aqlm_hip_gemv_8x8_lut_multi: misaligned buffer in segment %d", k);
+      return AQLM_HIP_E_UNSUPPORTED;
+    }
+  }
+  if (!aligned16(x)) {
+    set_last_error("aqlm_hip_gemv_8x8_lut_multi: misaligned x");
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  const int e = gemv_8x8_lut_multi(segments, num_segments, x, in_features, in_group_size, dtype, workspace, workspace_bytes,
+                                   (hipStream_t)stream);
+  if (e == AQLM_HIP_E_UNSUPPORTED) set_last_error("aqlm_hip_gemv_8x8_lut_multi: in_group_size %d not in {8,16,32}", in_group_size);
+  if (e == AQLM_HIP_E_INVALID) set_last_error("aqlm_hip_gemv_8x8_lut_multi: workspace too small (sum of aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_8X8_LUT, ...) over the segments)");
+  return e;
+}
 
 extern "C" int aqlm_hip_gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias,
                                      const void* x, void* y, int out_features, int in_features, int in_group_size,

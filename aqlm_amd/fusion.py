@@ -32,8 +32,8 @@ def _version(t: torch.Tensor) -> int:
 
 
 class SharedInputGroup:
-    """2..4 ``QuantizedLinear`` modules of one scheme -- 1x16 (g 8 / 16) or K x 8-bit with K in {1, 2}, g 8 -- with equal
-    in_features / dtype / device, that are always applied to the same input."""
+    """2..4 ``QuantizedLinear`` modules of one scheme -- 1x16 (g 8 / 16), 1x8 / 2x8 (g 8) or 8x8 (g 8 / 16 / 32) -- with
+    equal in_features / dtype / device, that are always applied to the same input."""
 
     def __init__(self, members: Sequence[QuantizedLinear]):
         members = list(members)
@@ -44,9 +44,10 @@ class SharedInputGroup:
             if not isinstance(m, QuantizedLinear):
                 raise TypeError(f"shared-input groups hold QuantizedLinear modules, got {type(m).__name__}")
             scheme = (m.num_codebooks, m.nbits_per_codebook, m.in_group_size)
-            ok = (scheme[:2] == (1, 16) and scheme[2] in (8, 16)) or (scheme[1] == 8 and scheme[0] in (1, 2) and scheme[2] == 8)
+            ok = ((scheme[:2] == (1, 16) and scheme[2] in (8, 16)) or (scheme[1] == 8 and scheme[0] in (1, 2) and scheme[2] == 8)
+                  or (scheme[:2] == (8, 8) and scheme[2] in (8, 16, 32)))
             if not ok or m.out_group_size != 1:
-                raise NotImplementedError("shared-input launches cover 1x16 (g 8 / 16) and 1x8 / 2x8 (g 8)")
+                raise NotImplementedError("shared-input launches cover 1x16 (g 8 / 16), 1x8 / 2x8 (g 8) and 8x8 (g 8 / 16 / 32)")
             if (m.in_features,) + scheme != (first.in_features, first.num_codebooks, first.nbits_per_codebook, first.in_group_size):
                 raise ValueError("members of a shared-input group must agree on in_features and scheme")
             if m.codebooks.dtype != first.codebooks.dtype or m.codebooks.device != first.codebooks.device:

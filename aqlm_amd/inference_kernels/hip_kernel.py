@@ -229,12 +229,51 @@ def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
     return _gemv_multi(input, codes, codebooks, scales, bias, "1x16")
 
 
+def _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias):
+    """Several 8-codebook layers times one single input row through per-token look-up tables in ONE launch
+    (aqlm_hip_gemv_8x8_lut_multi); bit-identical to _gemv_8x8_lut per layer."""
+    n = len(codes)
+    dt = _dtype_id(input)
+    g = codebooks[0].shape[3]
+    in_features = codes[0].shape[1] * g
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layers expect {in_features}")
+    x = _flat_rows(input)
+    segs = (_native.Segment * n)()
+    keep, outs = [], []
+    ws_bytes = 0
+    for k in range(n):
+        if tuple(codebooks[k].shape) != tuple(codebooks[0].shape) or codes[k].shape[1] * g != in_features:
+            raise ValueError("all layers of a shared-input launch must have the same scheme and in_features")
+        c, cb, sc = _c(codes[k]), _c(codebooks[k]), _c(scales[k])
+        bi = None if bias[k] is None else _c(bias[k])
+        out_features = c.shape[0]
+        y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
+        keep += [c, cb, sc, bi]
+        outs.append(y)
+        segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = c.data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
+        segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), out_features, out_features
+        ws_bytes += _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
+    ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.aqlm_hip_gemv_8x8_lut_multi(segs, n, x.data_ptr(), in_features, g, dt, ws.data_ptr(), ws_bytes,
+                                              _stream_ptr())
+    if rc:
+        _native.check(rc, "aqlm gemv_8x8_lut_multi")
+    return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
+
+
 def codekx8_matmat_multi(input, codes, codebooks, scales, bias):
-    """Several K x 8-bit layers of one scheme applied to the same input (aqlm_hip_gemv_kx8_multi): one launch for
-    1x8 / 2x8 g8, one launch per layer for other schemes.  Outputs agree with codekx8_matmat to fp32 rounding."""
+    """Several K x 8-bit layers of one scheme applied to the same input: one launch for 1x8 / 2x8 g8
+    (aqlm_hip_gemv_kx8_multi) and for single rows of 8-codebook schemes (look-up tables, aqlm_hip_gemv_8x8_lut_multi),
+    one launch per layer otherwise.  Outputs agree with codekx8_matmat to fp32 rounding (8x8: bit for bit)."""
     for cb in codebooks:
         if cb.shape[1] != 256:
             raise NotImplementedError(f"codekx8_matmat_multi needs codebooks [K, 256, 1, g], got {tuple(cb.shape)}")
+    cb0 = codebooks[0]
+    if (USE_8X8_LUT and 1 <= len(codes) <= _native.MAX_SEGMENTS and cb0.shape[0] == 8 and cb0.shape[2] == 1
+            and cb0.shape[3] in (8, 16, 32) and input.numel() == input.shape[-1] and input.dtype == cb0.dtype):
+        return _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias)
     return _gemv_multi(input, codes, codebooks, scales, bias, "kx8")
 
 

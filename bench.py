@@ -140,7 +140,14 @@ class FusedLayers:
     def launch(self, lib, stream, batch=1):
         from aqlm_amd import _native
 
-        if self.members[0].nbits == 8:
+        if self.members[0].nbits == 8 and self.members[0].K == 8 and batch == 1:
+            m0 = self.members[0]
+            if getattr(self, "lut_ws", None) is None:
+                n = sum(lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, m.g, m.fout, m.fin) for m in self.members)
+                self.lut_ws = torch.empty((n // 4,), dtype=torch.float32, device=self.x.device)
+            rc = lib.aqlm_hip_gemv_8x8_lut_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g, _native.F16,
+                                                 self.lut_ws.data_ptr(), self.lut_ws.numel() * 4, stream)
+        elif self.members[0].nbits == 8:
             m0 = self.members[0]
             rc = lib.aqlm_hip_gemv_kx8_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, m0.K, self.g, batch,
                                              self.fin, _native.F16, stream)
@@ -486,7 +493,7 @@ def main():
             detail[f"llama2_7b_{sname}_linear_stack"] = {"launches": gp.n, "ms_per_token": ms, "tokens_per_s": 1e3 / ms,
                                                         "algorithmic_GBps": gp.bytes / ms * 1e-6,
                                                         "frac_of_8TBps": gp.bytes / ms * 1e-6 / HBM_PEAK_GBPS}
-            if sname == "2x8g8":  # [q,k,v] and [gate,up] in one launch each (aqlm_hip_gemv_kx8_multi)
+            if True:  # [q,k,v] and [gate,up] in one launch each (aqlm_hip_gemv_kx8_multi / aqlm_hip_gemv_8x8_lut_multi)
                 fused = []
                 for b in range(32):
                     q, k, v, o, gate, up, down = tok[7 * b: 7 * b + 7]

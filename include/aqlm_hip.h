@@ -217,6 +217,15 @@ int aqlm_hip_gemv_8x8_lut(const void* codes_i8, const void* codebooks, const voi
                           const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * aqlm_hip_gemv_8x8_lut for up to AQLM_HIP_MAX_SEGMENTS 8-codebook layers that share x (batch 1) in one launch
+ * (+ one finalize).  workspace: the sum over segments of
+ * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_8X8_LUT, in_group_size, out_features_s, in_features).  A row's value does
+ * not depend on how the rows are dealt to workgroups, so results equal separate aqlm_hip_gemv_8x8_lut calls bit for bit.
+ */
+int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                                int in_group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_LDS 2
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3

@@ -626,8 +626,25 @@ def test_gemv_kx8_multi_matches_separate_launches(hk, K, fin, fouts, dt, batch):
     assert all(torch.equal(a, b) for a, b in zip(outs, again))
 
 
+@pytest.mark.parametrize("g,fin,fouts,dt", [(32, 4096, (4096, 1024, 1024), "float16"), (32, 1024, (300, 77), "bfloat16"),
+                                           (8, 512, (256, 256, 256, 40), "float16"), (16, 2048, (1000, 1000), "float16")])
+def test_gemv_8x8_lut_multi_is_bit_identical_to_separate_launches(hk, g, fin, fouts, dt):
+    dtype = tdtype(dt)
+    fd = np.float16 if dtype == torch.float16 else "bfloat16"
+    Ls = [orc.make_layer(6600 + fin + 7 * k, fin, fo, 8, 8, g, batch=1, bias=(k % 2 == 0), float_dtype=fd)
+          for k, fo in enumerate(fouts)]
+    Ts = [to_dev(L, dtype) for L in Ls]
+    x = Ts[0]["x"]
+    outs = torch.ops.aqlm.codekx8_matmat_multi(x, [T["codes"] for T in Ts], [T["codebooks"] for T in Ts],
+                                               [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    for L, T, y in zip(Ls, Ts, outs):
+        assert torch.equal(y, hk.codekx8_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"]))
+        y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y.float().cpu().numpy(), y64, dtype, f"lut multi 8x8g{g} {fin}->{L['codes'].shape[0]}")
+
+
 def test_gemv_kx8_multi_other_schemes_fall_back_per_segment(hk):
-    Ls = [orc.make_layer(6500 + k, 1024, fo, 8, 8, 32, batch=2, bias=True) for k, fo in enumerate((128, 320))]
+    Ls = [orc.make_layer(6500 + k, 1024, fo, 4, 8, 16, batch=2, bias=True) for k, fo in enumerate((128, 320))]
     Ts = [to_dev(L, torch.float16) for L in Ls]
     outs = torch.ops.aqlm.codekx8_matmat_multi(Ts[0]["x"], [T["codes"] for T in Ts], [T["codebooks"] for T in Ts],
                                                [T["scales"] for T in Ts], [T["bias"] for T in Ts])

@@ -158,10 +158,10 @@ def test_shared_input_grouping_rules_on_meta_modules():
             self.gate_proj, self.up_proj = ql(512, 1024), ql(256, 1024)
             self.q_proj, self.k_proj, self.v_proj = ql(512, 512), nn.Linear(8, 8), ql(512, 512)
 
-    class Mlp8x8(nn.Module):  # 8x8 g32: no shared-input kernel
+    class Mlp8x8(nn.Module):  # 4x8 g16: no shared-input kernel
         def __init__(self):
             super().__init__()
-            self.gate_proj, self.up_proj = ql(512, 1024, 8, 8, 32), ql(512, 1024, 8, 8, 32)
+            self.gate_proj, self.up_proj = ql(512, 1024, 4, 8, 16), ql(512, 1024, 4, 8, 16)
 
     model = nn.ModuleList([Attn(), Mlp(), Mlp(2, 8), Odd(), Mlp8x8()])
     keys_before = list(model.state_dict().keys()) if False else [n for n, _ in model.named_parameters()]
@@ -169,7 +169,7 @@ def test_shared_input_grouping_rules_on_meta_modules():
     assert [[m.out_features for m in g.members] for g in groups] == [[512, 128, 128], [1024, 1024], [1024, 1024]]
     assert groups[2].members[0].nbits_per_codebook == 8      # 2x8 g8 siblings share a launch too
     assert model[0].o_proj._shared_input_group is None and model[1].down_proj._shared_input_group is None
-    assert model[4].gate_proj._shared_input_group is None      # 8x8: not covered by the shared-input kernels
+    assert model[4].gate_proj._shared_input_group is None      # 4x8 g16: not covered by the shared-input kernels
     assert model[3].gate_proj._shared_input_group is None and model[3].q_proj._shared_input_group is None
     assert [n for n, _ in model.named_parameters()] == keys_before   # no parameters added or renamed
     assert aqlm.fuse_shared_input_linears(model) == []
