@@ -53,6 +53,8 @@ class SharedInputGroup:
             if m.codebooks.dtype != first.codebooks.dtype or m.codebooks.device != first.codebooks.device:
                 raise ValueError("members of a shared-input group must share dtype and device")
         self.members: List[QuantizedLinear] = members
+        # parameter lists, resolved once (re-resolved by _launch if a parameter object was replaced, e.g. by .to())
+        self._codes = self._codebooks = self._scales = self._biases = None
         self._input: Optional[torch.Tensor] = None
         self._version = -1
         self._pending: Dict[int, torch.Tensor] = {}
@@ -87,12 +89,19 @@ class SharedInputGroup:
         for m in ms:
             if m.gemv_op is None:
                 m.prepare_matmul_op(input)
+        if self._codes is None or any(a is not m.codes for a, m in zip(self._codes, ms)):
+            self._codes = [m.codes for m in ms]
+            self._codebooks = [m.codebooks for m in ms]
+            self._scales = [m.scales for m in ms]
+            self._biases = [m.bias for m in ms]
         if input.numel() == ms[0].in_features and all(getattr(m, "_packed_codes", None) is not None for m in ms):
             return hip_kernel.code1x16_matmat_packed_multi(
                 input, [m._packed_codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms],
                 [m.bias for m in ms], [m.out_features for m in ms])
-        op = torch.ops.aqlm.code1x16_matmat_multi if ms[0].nbits_per_codebook == 16 else torch.ops.aqlm.codekx8_matmat_multi
-        return op(input, [m.codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms], [m.bias for m in ms])
+        # direct call of the op implementations: the group never runs under torch.compile tracing (applicable()), and the
+        # dispatcher costs ~15 us per call for Tensor[] arguments -- as much as the launch itself in eager decode loops
+        op = hip_kernel.code1x16_matmat_multi if ms[0].nbits_per_codebook == 16 else hip_kernel.codekx8_matmat_multi
+        return op(input, self._codes, self._codebooks, self._scales, self._biases)
 
 
 def fuse_shared_input_linears(model: nn.Module,

@@ -35,3 +35,17 @@ with torch.no_grad():
     xb = torch.randn(1, 4096, dtype=torch.float16, device=dev)
     big(xb)
     print(f"QuantizedLinear 4096->8192 (prepacked) {t(lambda: big(xb), 500):7.1f} us/call")
+
+# shared-input group: host cost of one fused launch vs three separate module calls (tiny layers)
+import aqlm
+with torch.no_grad():
+    holder = torch.nn.Module()
+    for n in ("q_proj", "k_proj", "v_proj"):
+        setattr(holder, n, mk(1, 16, 8))
+    def three():
+        holder.q_proj(x); holder.k_proj(x); holder.v_proj(x)
+    three()
+    print(f"3 separate QuantizedLinear calls      {t(three, 1000):7.1f} us")
+    aqlm.fuse_shared_input_linears(holder)
+    three()
+    print(f"same through a shared-input group     {t(three, 1000):7.1f} us")
