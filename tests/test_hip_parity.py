@@ -897,3 +897,55 @@ def test_randomized_shared_input_groups(hk, seed):
         check_close(got[k].float().cpu().numpy(), y64, dtype, f"seed {seed} member {k}")
         if nbits == 16:
             assert torch.equal(got[k], ref[k]), f"seed {seed} member {k}: fused 1x16 output differs from the unfused module"
+
+
+# ------------------------------------------------------------------ sharded layer on the HIP ops
+def test_sharded_layer_world1_nccl_and_emulated_split(hk):
+    """ShardedQuantizedLinear with the real per-shard kernels: (a) a world_size-1 RCCL process group (the code path the
+    8-GPU run takes, minus the wire), (b) an 8-way split emulated on one GPU: in-split partial outputs must add up to
+    the unsharded result, out-split slices must concatenate to it bit for bit."""
+    import socket
+
+    import torch.distributed as dist
+
+    from aqlm_amd.sharded import ShardedQuantizedLinear, shard_bounds
+
+    fin, fout, g = 8192, 1536, 8
+    L = orc.make_layer(515, fin, fout, 1, 16, g, batch=2, bias=True)
+    T = to_dev(L, torch.float16)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    full = hk.code1x16_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    # (a) world_size 1 over RCCL
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+    try:
+        for mode in ("in", "out"):
+            m = ShardedQuantizedLinear.from_full(T["codes"], T["codebooks"], T["scales"].reshape(-1, 1, 1, 1), T["bias"], mode=mode)
+            y = m(T["x"])
+            assert torch.equal(y, full), mode
+        t = torch.ones(4, device=DEV)
+        dist.all_reduce(t)          # the collective itself works on this box
+        assert float(t.sum()) == 4.0
+    finally:
+        if created:
+            dist.destroy_process_group()
+    # (b) 8-way split emulated on one device
+    world = 8
+    acc = torch.zeros(2, fout, dtype=torch.float32, device=DEV)
+    for r in range(world):
+        j0, j1 = shard_bounds(fin // g, world, r, multiple=8)
+        part = hk.code1x16_matmat(T["x"][:, j0 * g:j1 * g], T["codes"][:, j0:j1].contiguous(), T["codebooks"], T["scales"],
+                                  T["bias"] if r == 0 else None)
+        acc += part.float()
+    check_close(acc.cpu().numpy(), y64, torch.float16, "in-split x8 (sum of per-shard outputs)")
+    outs = []
+    for r in range(world):
+        i0, i1 = shard_bounds(fout, world, r)
+        outs.append(hk.code1x16_matmat(T["x"], T["codes"][i0:i1].contiguous(), T["codebooks"], T["scales"][i0:i1].contiguous(),
+                                       T["bias"][i0:i1].contiguous()))
+    assert torch.equal(torch.cat(outs, dim=-1), full)
