@@ -150,6 +150,55 @@ __global__ __launch_bounds__(1024) void prepack_sort_kernel(uint32_t* rowoff, ui
   }
 }
 
+// K4b: order of a lane's four entries over the four levels, chosen per PAIR of neighbouring buckets so that the
+// codebook reads collide as little as possible.  The 16 lanes one ds_read_b128 pass services are l16 in {0-3,12-15} of
+// the even position of a pair plus l16 in {4-11} of the odd one ("group A"), and the complementary halves ("group B");
+// the x slots of those lanes are distinct by construction (K4), the codebook slots (code mod 16) are random: ~2.9
+// passes per read, and the gather loop is LDS-bound (traced: 0.55 us per 64-row step = the LDS cycles of 8 reads per
+// lane).  Greedy, deterministic: lanes are visited in order (even bucket, then odd bucket, lane by lane); each picks the
+// first of the 24 orders of its entries that adds the fewest collisions to the levels of its group.  Moving an entry to
+// another level of the SAME lane keeps K4's x property.  Only the two prefetched passes (entries 0-127) are treated.
+__device__ __forceinline__ bool pk_lane_in_x_half(int l16) { return l16 < 4 || l16 >= 12; }
+
+__global__ __launch_bounds__(64) void prepack_level_kernel(const uint32_t* rowoff, uint32_t* ent, int RG) {
+  const int stream = blockIdx.y;
+  const int pair = blockIdx.x * 64 + threadIdx.x;
+  if (pair >= RG / 2) return;  // RG is a multiple of 4: every position has a partner
+  const uint32_t* ro = rowoff + (size_t)stream * (RG + 1) + 2 * pair;
+  const uint32_t beg[2] = {ro[0], ro[1]};
+  const uint32_t len[2] = {ro[1] - ro[0], ro[2] - ro[1]};
+  // the 24 orders of four items, lexicographic: entry perm[k] of the lane goes to level k
+  const unsigned char P[24][4] = {{0,1,2,3},{0,1,3,2},{0,2,1,3},{0,2,3,1},{0,3,1,2},{0,3,2,1},{1,0,2,3},{1,0,3,2},
+                                  {1,2,0,3},{1,2,3,0},{1,3,0,2},{1,3,2,0},{2,0,1,3},{2,0,3,1},{2,1,0,3},{2,1,3,0},
+                                  {2,3,0,1},{2,3,1,0},{3,0,1,2},{3,0,2,1},{3,1,0,2},{3,1,2,0},{3,2,0,1},{3,2,1,0}};
+  for (uint32_t region = 0; region < 128; region += 64) {
+    uint32_t used[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // [group A / B][level]: bit r = codebook residue r taken
+    for (int l = 0; l < 16; ++l) {
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t off = region + 4u * (uint32_t)l;
+        if (off + 4u > len[b]) continue;  // this lane has no chunk in this bucket
+        u32x4* slot = reinterpret_cast<u32x4*>(ent + beg[b] + off);
+        const u32x4 e = *slot;
+        const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
+        const int grp = (pk_lane_in_x_half(l) == (b == 0)) ? 0 : 1;
+        int best = 0, best_cost = 5;
+        for (int q = 0; q < 24; ++q) {
+          int cost = 0;
+          for (int k = 0; k < 4; ++k) cost += (int)((used[grp][k] >> (ev[P[q][k]] & 15u)) & 1u);
+          if (cost < best_cost) { best_cost = cost; best = q; }
+        }
+        u32x4 o;
+        o.x = ev[P[best][0]]; o.y = ev[P[best][1]]; o.z = ev[P[best][2]]; o.w = ev[P[best][3]];
+        *slot = o;
+        used[grp][0] |= 1u << (o.x & 15u);
+        used[grp][1] |= 1u << (o.y & 15u);
+        used[grp][2] |= 1u << (o.z & 15u);
+        used[grp][3] |= 1u << (o.w & 15u);
+      }
+    }
+  }
+}
+
 // K5: rank (row -> position) -> rowperm (position -> row), in place.
 __global__ __launch_bounds__(1024) void prepack_invert_kernel(uint16_t* rank, int RG) {
   __shared__ uint16_t t[PK_MAX_RG];
@@ -444,6 +493,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
       if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + out_row] = acc;  // positions < nrows are the valid rows
 #ifdef AQLM_PACKED_TRACE
       if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived
+      if (p.trace && tid == 0 && r >= r0 && s6 < 6 && r < r0 + 6 * STRIDE) p.trace[256 * 8 + (size_t)block * 8 + s6] = wall_clock64();
 #endif
       r += STRIDE;
     }
@@ -617,6 +667,7 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
                      L.M, L.in_groups, L.RG);
   hipLaunchKernelGGL(prepack_arrange_kernel, dim3((L.M + 1) / 2), dim3(128), 0, stream, rowoff, perm, ent, L.M, L.in_groups,
                      L.RG);
+  hipLaunchKernelGGL(prepack_level_kernel, dim3((L.RG / 2 + 63) / 64, PK_NG * PK_S), dim3(64), 0, stream, rowoff, ent, L.RG);
   hipLaunchKernelGGL(prepack_invert_kernel, dim3(PK_NG * PK_S), dim3(1024), 0, stream, perm, L.RG);
   return check_hip(hipGetLastError(), "prepack launch");
 }
@@ -658,7 +709,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   p.RG = L.RG;
   p.ent_bytes = (uint32_t)((L.entries + PK_PAD) * 4);
 #ifdef AQLM_PACKED_TRACE
-  p.trace = workspace_bytes >= need + 256 * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+  p.trace = workspace_bytes >= need + 2 * 256 * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
 #endif
   const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 2) * 16;  // slice, x, zero slot, dump slot
   constexpr int NW = 16;

@@ -58,7 +58,42 @@ def pack(codes_unsigned):
             pad = (-len(js)) % 4
             null = np.uint32((in_groups + XBASE) << 16)  # j = in_groups, code 0
             ent[b:b + len(e) + pad] = arrange(e, len(e) + pad, null)
+    # K4b: per pair of neighbouring positions, order each lane's four entries over the levels (codebook bank conflicts)
+    for g in range(NG):
+        for s in range(S):
+            for i in range(RG // 2):
+                order_levels(ent, [int(ro[g, s, 2 * i]), int(ro[g, s, 2 * i + 1])],
+                             [int(ro[g, s, 2 * i + 1] - ro[g, s, 2 * i]), int(ro[g, s, 2 * i + 2] - ro[g, s, 2 * i + 1])])
     return rowoff, perm.reshape(-1), ent, L
+
+
+import itertools  # noqa: E402
+
+PERMS = list(itertools.permutations(range(4)))  # lexicographic, like the table in prepack_level_kernel
+
+
+def order_levels(ent, beg, length):
+    """prepack_level_kernel for one pair of buckets: greedy choice, lane by lane (even bucket, then odd), of the first of
+    the 24 orders of a lane's entries that adds the fewest codebook-residue collisions to its service group."""
+    for region in (0, 64):
+        used = [[0] * 4, [0] * 4]
+        for lane in range(16):
+            for b in range(2):
+                off = region + 4 * lane
+                if off + 4 > length[b]:
+                    continue
+                ev = [int(v) for v in ent[beg[b] + off: beg[b] + off + 4]]
+                in_x = lane < 4 or lane >= 12
+                grp = 0 if (in_x == (b == 0)) else 1
+                best, best_cost = 0, 5
+                for q, pm in enumerate(PERMS):
+                    cost = sum((used[grp][k] >> (ev[pm[k]] & 15)) & 1 for k in range(4))
+                    if cost < best_cost:
+                        best, best_cost = q, cost
+                o = [ev[PERMS[best][k]] for k in range(4)]
+                ent[beg[b] + off: beg[b] + off + 4] = o
+                for k in range(4):
+                    used[grp][k] |= 1 << (o[k] & 15)
 
 
 def home_lane(rho):

@@ -420,7 +420,7 @@ static void bench_trace(int in, int out) {
   const char* names[8] = {"entry", "loads issued", "LDS filled", "first row done", "loop done (wave 0)", "last wave entry", "last wave slice in LDS", "last wave out"};
   for (int rep = 0; rep < 3; ++rep) {
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
-    CK(hipMemset(tr, 0, 256 * 8 * 8));
+    CK(hipMemset(tr, 0, 2 * 256 * 8 * 8));
     CK(hipDeviceSynchronize());
     launch_layer(s, layers[0], in, out, 1, nullptr);
     CK(hipDeviceSynchronize());
@@ -428,6 +428,13 @@ static void bench_trace(int in, int out) {
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 256; ++b) t0 = std::min(t0, h[b * 8]);
     printf("# packed %d->%d cold, run %d: per-phase time since the first workgroup's entry, us (min / mean / max over 256 workgroups)\n", in, out, rep);
+    {
+      std::vector<unsigned long long> st(256 * 8);
+      CK(hipMemcpy(st.data(), tr + 256 * 8, st.size() * 8, hipMemcpyDeviceToHost));
+      printf("  wave-0 step completion (mean over workgroups, us):");
+      for (int i = 0; i < 6; ++i) { double sum = 0; int n = 0; for (int b = 0; b < 256; ++b) if (st[b * 8 + i] > t0) { sum += (double)(st[b * 8 + i] - t0) * 0.01; ++n; } printf(" %.2f", n ? sum / n : 0.0); }
+      printf("\n");
+    }
     for (int i = 0; i < 8; ++i) {
       double mn = 1e9, mx = 0, sum = 0;
       for (int b = 0; b < 256; ++b) { const double v = (double)(h[b * 8 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
