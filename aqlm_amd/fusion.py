@@ -87,7 +87,7 @@ class SharedInputGroup:
 
         ms = self.members
         for m in ms:
-            if m.gemv_op is None:
+            if m.gemv_op is None or m._derived_state_is_stale():
                 m.prepare_matmul_op(input)
         if self._codes is None or any(a is not m.codes for a, m in zip(self._codes, ms)):
             self._codes = [m.codes for m in ms]

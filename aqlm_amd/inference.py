@@ -68,6 +68,8 @@ class QuantizedLinear(nn.Module):
         self.gemm_op = None
         self.use_gemv_rule = None
         self._packed_codes = None  # derived, never saved: rebuilt from `codes` at first use
+        self._packed_version = 0
+        self._prepack_deferred = False
         self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
 
     def extra_repr(self) -> str:
@@ -78,7 +80,7 @@ class QuantizedLinear(nn.Module):
         group = self._shared_input_group
         if group is not None and group.applicable(input):
             return group.forward(self, input)  # one launch for all projections of this input (fusion.py)
-        if self.gemv_op is None:
+        if self.gemv_op is None or self._derived_state_is_stale():
             self.prepare_matmul_op(input)
         if self._packed_codes is not None and input.numel() == self.in_features and not (
             torch.is_grad_enabled() and input.requires_grad
@@ -89,6 +91,27 @@ class QuantizedLinear(nn.Module):
                                                      self.out_features)
         op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
         return op.apply(input, self.codes, self.codebooks, self.scales, self.bias)
+
+    def _derived_state_is_stale(self) -> bool:
+        """The prepacked buffer is derived from ``codes``: rebuild it when ``codes`` was written in place
+        (``load_state_dict`` / ``copy_`` after the first forward) or when a repack was postponed during graph capture."""
+        if self._prepack_deferred:
+            return not torch.cuda.is_current_stream_capturing()
+        if self._packed_codes is None:
+            return False
+        try:
+            return self.codes._version != self._packed_version
+        except RuntimeError:  # inference tensors carry no version counter
+            return False
+
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()`` / ``.half()`` / ``.cuda()`` replace the parameters: drop everything derived from them (kernel
+        choice, prepacked codes); it is rebuilt at the next forward."""
+        out = super()._apply(fn, *args, **kwargs)
+        self.gemv_op = self.gemm_op = self.use_gemv_rule = None
+        self._packed_codes = None
+        self._prepack_deferred = False
+        return out
 
     def prepare_matmul_op(self, input: torch.Tensor):
         """Resolve the decode (gemv) and batch (gemm) operators once (reference inference.py:77-96).  Unlike the
@@ -103,12 +126,22 @@ class QuantizedLinear(nn.Module):
         # load-time re-layout of the codes for the decode kernel (the reference does the analogous thing for its CPU
         # kernel here, inference.py:78-83 -- but in place; we keep `codes` untouched and add a derived buffer)
         self._packed_codes = None
+        self._prepack_deferred = False
         if (PREPACK_MIN_CODES and self.out_features * (self.in_features // 8) >= PREPACK_MIN_CODES and self.num_codebooks == 1
                 and self.nbits_per_codebook == 16 and self.in_group_size == 8 and self.out_group_size == 1
                 and self.codes.is_cuda and self.codebooks.dtype in (torch.float16, torch.bfloat16)):
+            if torch.cuda.is_current_stream_capturing():
+                # the repack synchronises its stream: not allowed inside a hipGraph capture.  This call runs on the
+                # direct kernel; the repack happens at the first forward outside a capture.
+                self._prepack_deferred = True
+                return
             from .inference_kernels import hip_kernel
 
             self._packed_codes = hip_kernel.prepack_1x16(self.codes, 8)
+            try:
+                self._packed_version = self.codes._version
+            except RuntimeError:
+                self._packed_version = 0
 
 
 def _get_autograd_matmul_op(forward_pass_kernel, backward_pass_kernel):

@@ -949,3 +949,51 @@ def test_sharded_layer_world1_nccl_and_emulated_split(hk):
         outs.append(hk.code1x16_matmat(T["x"], T["codes"][i0:i1].contiguous(), T["codebooks"], T["scales"][i0:i1].contiguous(),
                                        T["bias"][i0:i1].contiguous()))
     assert torch.equal(torch.cat(outs, dim=-1), full)
+
+
+def test_derived_state_follows_the_parameters(hk):
+    """The prepacked buffer must track `codes`: in-place reloads, .to()/.half() conversions and a first forward inside
+    a hipGraph capture (where the repack is postponed) all have to give the right answer."""
+    import aqlm_amd.inference as inf
+
+    fin, fout = 2048, 640
+    La = orc.make_layer(7001, fin, fout, 1, 16, 8, batch=1, bias=True)
+    Lb = orc.make_layer(7002, fin, fout, 1, 16, 8, batch=1, bias=True)
+    old, inf.PREPACK_MIN_CODES = inf.PREPACK_MIN_CODES, 100_000
+    try:
+        m, Ta = _module_from(La, 1, 16, 8, fin, fout, torch.float16)
+        Tb = to_dev(Lb, torch.float16)
+        ya = m(Ta["x"])
+        assert m._packed_codes is not None
+        check_close(ya.float().cpu().numpy(), orc.dequantize_gemm(La["x"], La["codes"], La["codebooks"], La["scales"], La["bias"]),
+                    torch.float16, "before reload")
+        # in-place reload of other weights (what load_state_dict does)
+        m.load_state_dict({"codes": Tb["codes"], "codebooks": Tb["codebooks"], "scales": Tb["scales"].reshape(-1, 1, 1, 1),
+                           "bias": Tb["bias"]})
+        yb = m(Tb["x"])
+        check_close(yb.float().cpu().numpy(), orc.dequantize_gemm(Lb["x"], Lb["codes"], Lb["codebooks"], Lb["scales"], Lb["bias"]),
+                    torch.float16, "after load_state_dict")
+        # dtype conversion drops and rebuilds the derived state
+        m.to(torch.bfloat16)
+        assert m._packed_codes is None and m.gemv_op is None
+        yc = m(Tb["x"].to(torch.bfloat16))
+        assert m._packed_codes is not None and yc.dtype == torch.bfloat16
+        rel = (yc.float() - yb.float()).abs().mean() / yb.float().abs().mean()
+        assert rel < 2e-2
+        # first forward inside a capture: repack postponed, direct kernel captured, result correct on replay
+        m2, _ = _module_from(La, 1, 16, 8, fin, fout, torch.float16)
+        static_x = Ta["x"].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(graph, stream=s):
+                y_static = m2(static_x)
+        assert m2._packed_codes is None and m2._prepack_deferred
+        graph.replay()
+        torch.cuda.synchronize()
+        check_close(y_static.float().cpu().numpy(), ya.float().cpu().numpy().astype(np.float64), torch.float16, "captured first call")
+        y_later = m2(Ta["x"])                      # outside the capture: now the repack happens
+        assert m2._packed_codes is not None and torch.equal(y_later, ya)
+    finally:
+        inf.PREPACK_MIN_CODES = old
