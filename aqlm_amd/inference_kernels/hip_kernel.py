@@ -41,8 +41,10 @@ def _dtype_id(t: torch.Tensor) -> int:
         ) from None
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None) -> int:
+    """The current stream of ``device`` (default: the current device).  Always pass the tensor's device when the call
+    is not inside ``torch.cuda.device(...)``: with accelerate's device_map the current device is not the layer's."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -80,7 +82,7 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
         bias = _c(bias)
     B = x.shape[0]
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
-    stream = _stream_ptr()
+    stream = _stream_ptr(input.device)
     with torch.cuda.device(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
@@ -202,7 +204,7 @@ def _gemv_multi(input, codes, codebooks, scales, bias, kind):
         outs.append(y)
         segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = c.data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), out_features, out_features
-    stream = _stream_ptr()
+    stream = _stream_ptr(input.device)
     with torch.cuda.device(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
