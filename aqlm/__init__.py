@@ -47,3 +47,5 @@ from aqlm_amd import SharedInputGroup, fuse_shared_input_linears, unfuse_shared_
 inference = importlib.import_module(__name__ + ".inference")
 utils = importlib.import_module(__name__ + ".utils")
 inference_kernels = importlib.import_module(__name__ + ".inference_kernels")
+checkpoint = importlib.import_module(__name__ + ".checkpoint")
+fusion = importlib.import_module(__name__ + ".fusion")
