@@ -83,6 +83,20 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// sum over aligned groups of 4 lanes; every lane of the group receives the total
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  return v;
+}
+
+// sum over aligned groups of 8 lanes; every lane of the group receives the total
+__device__ __forceinline__ float oct_sum(float v) {
+  v = quad_sum(v);
+  v += dpp_f32<0x141>(v);  // row_half_mirror
+  return v;
+}
+
 // sum over the wave; every lane receives the total
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);

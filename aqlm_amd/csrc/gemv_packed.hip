@@ -360,17 +360,21 @@ __device__ __forceinline__ float packed_entry(uint32_t w, uint32_t four, float a
 }
 
 // `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
-template <class T, int NWAVES, int PD>
+// LPR = lanes per row: 16 (a quarter-wave per row: layers whose (row, slice) buckets hold ~64 entries and more), 8 or 4
+// (16 rows per wave step: narrow layers, e.g. the 1024-wide shards of a row-parallel 70B layer, whose buckets hold ~16
+// entries -- with 16 lanes per row three quarters of the lanes would idle and the loop would need 4x the steps).
+template <class T, int NWAVES, int PD, int LPR = 16>
 __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
   constexpr int NT = NWAVES * 64;
-  constexpr int STRIDE = NWAVES * 4;  // rows between two consecutive rows of one quarter-wave
+  constexpr int RPW = 64 / LPR;          // rows per wave and step
+  constexpr int STRIDE = NWAVES * RPW;   // rows between two consecutive rows of one lane group
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* const cbl = reinterpret_cast<u32x4*>(smem_raw);   // [8192] codebook slice
   u32x4* const xl = cbl + PK_SLICE_ENTRIES;                  // [in_groups + 1] x, 16 B per input group, then zeros
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l16 = lane & 15, quarter = lane >> 4;
+  const int l16 = lane & (LPR - 1), quarter = lane / LPR;  // lane within its row's group, group within the wave
   // slice = blockIdx % 8: blocks are observed to land on XCD blockIdx % 8, so each XCD's L2 serves ONE 128 KiB slice
   // (fetched once) instead of the whole codebook (speed only; any placement is correct).  Workgroups of one row-group
   // share nothing -- each walks its own bucket stream -- so they need not be co-located.
@@ -397,7 +401,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // compile-time slots only (main loop unrolled 2*PD times) and never copied, so no in-flight register is touched
   // before its row is consumed.  Everything below is issued before the LDS fill (HBM latency overlaps it).
   constexpr int NB2 = 2 * PD;
-  const int r0 = wave * 4 + quarter;
+  const int r0 = wave * RPW + quarter;
   uint32_t bst[NB2], ben[NB2];
   uint16_t brow[NB2];
   u32x4 e_q[PD], e_q2[PD];              // chunk l16 and chunk l16 + 16 (buckets of 65..128 entries) of each row
@@ -439,7 +443,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #pragma unroll
   for (int k = 0; k < PD; ++k) {  // needs the bounds only: vmcnt leaves the slice / x loads in flight
     fetch(bst[k], l16, e_q[k]);
-    fetch(bst[k], l16 + 16, e_q2[k]);
+    fetch(bst[k], l16 + LPR, e_q2[k]);
   }
   AQLM_TRACE(1);  // every load of the prologue has been issued
   // unconditional LDS writes (threads past the end write a dump slot): with the store under a branch hipcc sinks the
@@ -477,19 +481,19 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
       const u32x4 e1 = e_q[es], e2 = e_q2[es];
       // refill: entries of row r + PD*STRIDE (its bounds sit PD slots further in the ring), bounds of row r + 2*PD*STRIDE
       fetch(bst[(s6 + PD) % NB2], l16, e_q[es]);
-      fetch(bst[(s6 + PD) % NB2], l16 + 16, e_q2[es]);
+      fetch(bst[(s6 + PD) % NB2], l16 + LPR, e_q2[es]);
       bounds(r + NB2 * STRIDE, bst[s6], ben[s6], brow[s6]);
 
       const int nchunks = (int)((en - st) >> 2);
       float acc = 0.f;
       if (l16 < nchunks) acc = consume(e1, acc);
-      if (l16 + 16 < nchunks) acc = consume(e2, acc);
-      for (int c = l16 + 32; __any(c < nchunks); c += 16) {  // buckets longer than 128 entries (rare): blocking loads
+      if (l16 + LPR < nchunks) acc = consume(e2, acc);
+      for (int c = l16 + 2 * LPR; __any(c < nchunks); c += LPR) {  // buckets longer than 128 entries (rare): blocking loads
         u32x4 e3;
         fetch(st, c, e3);
         if (c < nchunks) acc = consume(e3, acc);
       }
-      acc = row16_sum(acc);  // DPP: no LDS traffic
+      acc = LPR == 16 ? row16_sum(acc) : (LPR == 8 ? oct_sum(acc) : quad_sum(acc));  // DPP: no LDS traffic
       if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + out_row] = acc;  // positions < nrows are the valid rows
 #ifdef AQLM_PACKED_TRACE
       if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived
@@ -524,9 +528,9 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // slow as the separate finalize launch, +-0.3 us on every shape.  Hence the plain two-kernel form.)
 }
 
-template <class T, int NWAVES, int PD>
+template <class T, int NWAVES, int PD, int LPR = 16>
 __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
-  gemv_1x16_packed_body<T, NWAVES, PD>(p, blockIdx.x);
+  gemv_1x16_packed_body<T, NWAVES, PD, LPR>(p, blockIdx.x);
 }
 
 // Several prepacked layers that multiply the same x (gate/up) in one launch of 256 workgroups per layer; the second
@@ -547,7 +551,7 @@ struct PackedMultiParams {
   PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
-template <class T, int NWAVES, int PD>
+template <class T, int NWAVES, int PD, int LPR = 16>
 __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_multi_kernel(const PackedMultiParams mp) {
   const int sidx = (int)blockIdx.x >> 8;
   PackedGemvParams p{};
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_multi_kernel(con
       p.ent_bytes = mp.seg[k].ent_bytes;
     }
   }
-  gemv_1x16_packed_body<T, NWAVES, PD>(p, (int)blockIdx.x & 255);
+  gemv_1x16_packed_body<T, NWAVES, PD, LPR>(p, (int)blockIdx.x & 255);
 }
 
 struct PackedFinalizeParams {
@@ -721,7 +725,11 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
   // rows per quarter-wave <= 2 (<= 4096-row layers): a shorter ring, so that the unrolled pipeline has fewer idle steps
   const bool short_rows = L.RG <= 2 * NW * 4;
   int e;
-  if (short_rows)
+  if (L.in_groups <= 128)  // ~16 entries per bucket: 4 lanes per row
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3, 4>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3, 4>);
+  else if (L.in_groups <= 256)  // ~32 entries per bucket: 8 lanes per row
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3, 8>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3, 8>);
+  else if (short_rows)
     e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 2>) : launch(gemv_1x16_packed_kernel<BF16, NW, 2>);
   else
     e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3>);
@@ -804,8 +812,16 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     hipLaunchKernelGGL(kern, dim3(256 * num_segments), dim3(NW * 64), lds, stream, mp);
     return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
   };
-  const int e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3>)
-                                      : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3>);
+  int e;
+  if (mp.in_groups <= 128)  // same lanes-per-row choice as the single-layer launch: results stay bit-identical
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3, 4>)
+                              : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3, 4>);
+  else if (mp.in_groups <= 256)
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3, 8>)
+                              : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3, 8>);
+  else
+    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3>)
+                              : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3>);
   if (e) return e;
   if (dtype == AQLM_HIP_F16)
     hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);

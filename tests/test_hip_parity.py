@@ -437,6 +437,9 @@ def test_prepack_is_bit_exact(hk, fin, fout):
     (11008, 640, "float16", True),
     (14336, 1024, "bfloat16", True),
     (64, 256, "float16", True),
+    (1024, 3000, "float16", True),       # <= 128 input groups: the 4-lanes-per-row variant (16 rows per wave step)
+    (512, 7168, "bfloat16", False),
+    (2048, 1500, "float16", True),       # <= 256 input groups: 8 lanes per row
 ])
 def test_gemv_1x16_packed(hk, fin, fout, dt, bias):
     dtype = tdtype(dt)
