@@ -361,7 +361,8 @@ __device__ __forceinline__ float packed_entry(uint32_t w, uint32_t four, float a
 
 // `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
 // LPR = lanes per row: 16 (a quarter-wave per row: layers whose (row, slice) buckets hold ~64 entries and more), 8 or 4
-// (16 rows per wave step: narrow layers, e.g. the 1024-wide shards of a row-parallel 70B layer, whose buckets hold ~16
+// (16 rows per wave step: narrow layers,  [32 / 64 lanes per row for wide layers were measured slower: 14336->4096
+// 16.3 vs 15.6 us, 8192->28672 39 vs 35 us -- more steps outweigh the avoided third-pass loop] e.g. the 1024-wide shards of a row-parallel 70B layer, whose buckets hold ~16
 // entries -- with 16 lanes per row three quarters of the lanes would idle and the loop would need 4x the steps).
 template <class T, int NWAVES, int PD, int LPR = 16>
 __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
@@ -493,7 +494,10 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
         fetch(st, c, e3);
         if (c < nchunks) acc = consume(e3, acc);
       }
-      acc = LPR == 16 ? row16_sum(acc) : (LPR == 8 ? oct_sum(acc) : quad_sum(acc));  // DPP: no LDS traffic
+      // reduction over the row's lanes on the VALU (DPP / readlane): no LDS traffic
+      if constexpr (LPR == 16) acc = row16_sum(acc);
+      else if constexpr (LPR == 8) acc = oct_sum(acc);
+      else acc = quad_sum(acc);
       if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + out_row] = acc;  // positions < nrows are the valid rows
 #ifdef AQLM_PACKED_TRACE
       if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived
