@@ -1,0 +1,41 @@
+"""CPU smoke tests of the measurement tools (so that they do not rot between GPU runs)."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_decode_benchmark_loop_runs_on_cpu():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "decode_benchmark.py"), "--model", "tiny",
+                                   "--dense-only", "--device", "cpu", "--tokens", "4", "--prompt", "4"], cwd=ROOT, timeout=600)
+    res = json.loads(out.decode().strip().splitlines()[-1])
+    assert res["model"] == "tiny" and res["dense_fp16_eager"]["tokens_per_s"] > 0
+    assert len(res["dense_fp16_eager"]["first_tokens"]) == 4
+
+
+def test_make_pmc_traffic_applies_the_gfx950_correction(tmp_path):
+    cols = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id",
+            "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+            "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    main = "void aqlm::gemv_1x16_packed_kernel<aqlm::F16, 16, 3>(aqlm::PackedGemvParams)"
+    fin = "void aqlm::gemv_1x16_packed_finalize<aqlm::F16>(aqlm::PackedFinalizeParams)"
+    rows = {"pmc_fetch": [(main, "FETCH_SIZE", 1000.0), (main, "FETCH_SIZE", 3000.0), (fin, "FETCH_SIZE", 10.0),
+                          (fin, "FETCH_SIZE", 10.0), ("aqlm::prepack_count_kernel(...)", "FETCH_SIZE", 9e9)],
+            "pmc_write": [(main, "WRITE_SIZE", 100.0), (main, "WRITE_SIZE", 100.0), (fin, "WRITE_SIZE", 4.0), (fin, "WRITE_SIZE", 4.0)]}
+    for d, rs in rows.items():
+        os.makedirs(tmp_path / d)
+        with open(tmp_path / d / "bench_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(cols)
+            for name, counter, val in rs:
+                w.writerow([1, 1, "Agent 2", 1, 1, 1, 1, 1, name, 1024, 0, 0, 98, 0, 48, counter, val, 0, 1])
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "make_pmc_traffic.py"), str(tmp_path)], cwd=ROOT)
+    t = json.loads(out)
+    k = t["per_kernel"][main]
+    assert k["FETCH_SIZE_KB"] == 2000.0 and k["hbm_bytes"] == 2 * 2000.0 * 1024 + 100.0 * 1024 and k["launches"] == 2
+    assert not any("prepack" in name for name in t["per_kernel"])
+    per_matvec = (2 * k["hbm_bytes"] + 2 * (2 * 10.0 * 1024 + 4.0 * 1024)) / 2     # main + finalize per matvec
+    assert abs(t["gemv_1x16_hbm_bytes_per_launch"] - per_matvec) < 1e-6
