@@ -11,13 +11,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaqlm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
 MAX_GEMV_BATCH = 8
 OP_GEMM_1X16_MFMA = 1
-OP_GEMV_1X16_LDS = 2
 OP_GEMV_1X16_PACKED = 3
 OP_GEMV_8X8_LUT = 4
 
@@ -35,19 +34,41 @@ class Segment(ctypes.Structure):
 
 _segp = ctypes.POINTER(Segment)
 
+
+class PackedDesc(ctypes.Structure):
+    """aqlm_hip_packed_desc (include/aqlm_hip.h): what the kernels need to know about a prepacked 1x16 buffer."""
+
+    _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint32), ("out_features", ctypes.c_int32),
+                ("in_features", ctypes.c_int32), ("slices_log2", ctypes.c_int32), ("waves", ctypes.c_int32),
+                ("steps", ctypes.c_int32), ("entry_bytes", ctypes.c_int32), ("used_bytes", ctypes.c_uint64),
+                ("reserved", ctypes.c_uint64)]
+
+    def as_ints(self):
+        return [int(self.magic), int(self.version), int(self.out_features), int(self.in_features),
+                int(self.slices_log2), int(self.waves), int(self.steps), int(self.entry_bytes), int(self.used_bytes)]
+
+    @classmethod
+    def from_ints(cls, v):
+        return cls(*[int(x) for x in v[:9]], 0)
+
+
+_descp = ctypes.POINTER(PackedDesc)
+_descpp = ctypes.POINTER(_descp)
+
 # name -> (restype, argtypes); mirrors include/aqlm_hip.h one to one
 SIGNATURES = {
     "aqlm_hip_abi_version": (_ci, []),
     "aqlm_hip_last_error": (ctypes.c_char_p, []),
     "aqlm_hip_gemv_1x16": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _cl, _ci, _vp]),
-    "aqlm_hip_gemv_1x16_packed_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_1x16_packed_multi": (_ci, [_segp, _descpp, _ci, _vp, _ci, _ci, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_kx8_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
-    "aqlm_hip_gemv_1x16_lds": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_prepack_1x16_bytes": (_sz, [_ci, _ci, _ci]),
-    "aqlm_hip_prepack_1x16": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _vp]),
-    "aqlm_hip_gemv_1x16_packed": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_prepack_1x16": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _descp, _vp]),
+    "aqlm_hip_packed_desc_read": (_ci, [_vp, _sz, _descp]),
+    "aqlm_hip_unpack_1x16": (_ci, [_descp, _vp, _vp, _vp]),
+    "aqlm_hip_gemv_1x16_packed": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_8x8_lut": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_8x8_lut_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),

@@ -98,14 +98,17 @@ def validate_quantized_state_dict(state_dict: Mapping[str, torch.Tensor], config
     return problems
 
 
-def memory_report(model: torch.nn.Module) -> Dict[str, int]:
-    """Bytes held by the QuantizedLinear modules of ``model``: checkpoint tensors and the derived prepacked buffers."""
+def memory_report(model: torch.nn.Module) -> Dict[str, float]:
+    """Bytes held by the QuantizedLinear modules of ``model``: checkpoint tensors and the derived prepacked buffers,
+    plus the resulting bits per weight of the code storage (canonical 1x16 g8 = 2.0) and of everything."""
     from .inference import QuantizedLinear
 
-    rep = {"quantized_linears": 0, "codes": 0, "codebooks": 0, "scales_bias": 0, "prepacked_layers": 0, "prepacked": 0}
+    rep = {"quantized_linears": 0, "codes": 0, "codebooks": 0, "scales_bias": 0, "prepacked_layers": 0, "prepacked": 0,
+           "codes_dropped_layers": 0, "weights": 0}
     for m in model.modules():
         if isinstance(m, QuantizedLinear):
             rep["quantized_linears"] += 1
+            rep["weights"] += m.in_features * m.out_features
             rep["codes"] += m.codes.numel() * m.codes.element_size()
             rep["codebooks"] += m.codebooks.numel() * m.codebooks.element_size()
             rep["scales_bias"] += m.scales.numel() * m.scales.element_size()
@@ -114,12 +117,19 @@ def memory_report(model: torch.nn.Module) -> Dict[str, int]:
             if m._packed_codes is not None:
                 rep["prepacked_layers"] += 1
                 rep["prepacked"] += m._packed_codes.numel()
+            if m._codes_dropped:
+                rep["codes_dropped_layers"] += 1
+    if rep["weights"]:
+        rep["code_bits_per_weight"] = 8.0 * (rep["codes"] + rep["prepacked"]) / rep["weights"]
+        rep["total_bits_per_weight"] = 8.0 * (rep["codes"] + rep["prepacked"] + rep["codebooks"] + rep["scales_bias"]) / rep["weights"]
     return rep
 
 
-def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None) -> Dict[str, int]:
+def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_canonical: bool = False) -> Dict[str, float]:
     """Resolve the kernels and run the load-time repack of every eligible QuantizedLinear now (GPU-resident modules
     only) instead of at its first forward; ``min_codes`` overrides ``inference.PREPACK_MIN_CODES`` for this call.
+    ``drop_canonical=True`` (inference-only deployments) frees the checkpoint-layout ``codes`` of every repacked layer:
+    the packed buffer is lossless, ``state_dict()`` / large-batch / backward rebuild them on demand.
     Returns ``memory_report(model)``."""
     from . import inference
     from .inference import QuantizedLinear
@@ -131,9 +141,10 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None) -> Di
         for m in model.modules():
             if isinstance(m, QuantizedLinear):
                 if not m.codes.is_cuda:
-                    raise NotImplementedError("prepack_model needs the model on an MI355X (`model.to('cuda')` first); "
-                                              "aqlm_amd has no CPU kernels")
+                    raise NotImplementedError("prepack_model needs the model on an MI355X (`model.to('cuda')` first)")
                 m.prepare_matmul_op(m.codebooks)
+                if drop_canonical:
+                    m.drop_canonical_codes()
     finally:
         inference.PREPACK_MIN_CODES = old
     return memory_report(model)

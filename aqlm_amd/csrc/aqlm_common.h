@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/aqlm_hip.h"
 
@@ -134,6 +135,9 @@ struct Tuning {
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
   int gemm_splitk_free = 0;      // 1: large-batch 1x16 op uses the split-K-free 16x16x32 kernel when in % 256 == 0
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
+  int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
+  int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel), 0 = ascending j
+  int packed_prefetch = 0;       // packed 1x16 kernel: steps of the entry stream in flight per wave (4 / 8); 0 = heuristic
 };
 Tuning& tuning();
 

@@ -445,7 +445,8 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   if (op == AQLM_HIP_OP_GEMV_8X8_LUT && batch > 0 && out_features > 0 && in_features > 0 && in_features % batch == 0)
     return aqlm::gemv_8x8_lut_workspace(out_features, in_features, /*in_group_size=*/batch);
   if (batch <= 0 || out_features <= 0 || in_features <= 0) return 0;
-  if (op == AQLM_HIP_OP_GEMV_1X16_LDS || op == AQLM_HIP_OP_GEMV_1X16_PACKED) return (size_t)8 * out_features * sizeof(float);
+  if (op == AQLM_HIP_OP_GEMV_1X16_PACKED)  // fp32 partials [16 slices][rows of x][out]
+    return (size_t)16 * std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * out_features * sizeof(float);
   if (op != AQLM_HIP_OP_GEMM_1X16_MFMA) return 0;
   const GemmPlan g = plan_gemm(batch, out_features, in_features);
   return (size_t)g.ksplit * out_features * g.Bpad * sizeof(float);

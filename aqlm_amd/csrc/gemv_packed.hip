@@ -1,78 +1,97 @@
-// 1x16 g8 matvec on slice-bucketed ("prepacked") codes, gfx950.
+// 1x16 g8 matvec (1..8 input rows) on slice-bucketed ("prepacked") codes, gfx950.  Packed format v5.
 //
 // Why a load-time repack: on MI355X a random 16-B codebook gather that hits L2 costs a whole 128-B line of the CU's
 // L1-fill path (0.43 lane-gathers/clk/CU measured, profiles/r01_call1_mb_l2gather.log), which pins the direct kernel
-// (gemv.hip) at ~5.5 % of the HBM roofline.  LDS gathers are >10x cheaper but only 160 KiB fit per CU, so the
-// codebook has to be cut into 8 slices of 8192 entries with one slice per CU -- and then every CU must find "its"
-// codes.  Scanning the canonical [out][in/8] code matrix for them (gemv_lds.hip) spends ~95 vector instructions per
-// 512 codes to use 64.  Bucketing the codes by slice ONCE, when the layer is loaded, removes the scan.  (The
-// reference also re-lays codes out at load time for its CPU kernel, inference.py:78-83.)
+// (gemv.hip) at ~5.5 % of the HBM roofline.  LDS gathers are >10x cheaper but only 160 KiB fit per CU, so the codebook is
+// cut into S = 16 slices of 4096 entries (64 KiB), one slice per workgroup -- and every workgroup must find "its" codes.
+// Bucketing the codes by slice ONCE, when the layer is loaded, removes that search.  (The reference also re-lays codes
+// out at load time for its CPU kernel, inference.py:78-83.)
 //
-// Packed format v3 (built by aqlm_hip_prepack_1x16, checked bit-for-bit against a numpy model in tests/):
-//   rows are split into NG = 32 row-groups of RG rows; codes into S = 8 slices by (code >> 13);
-//   stream (g, s) = for each row of group g, in order: that row's codes of slice s (in the bank-aware order of
-//   prepack_arrange_kernel below), each as ONE 32-bit entry  (8192 + j) << 16 | (code & 0x1fff): the two 16-bit halves, shifted left by 4, ARE the
-//   LDS byte addresses of the codebook vector (slice at LDS 0..128 KiB) and of x[j] (x at LDS 128 KiB + 16 j), so an
-//   entry costs two v_lshlrev_b32_sdwa instead of seven ALU ops of bit fiddling (the 24-bit two-plane format v2 did);
-//   every (row, slice) bucket is padded to a multiple of 4 entries with null entries (j = in_groups, whose x is a
-//   zero vector in LDS; code 0), so a lane fetches 4 consecutive entries with one aligned 16-B load;
-//   inside a stream the rows are ordered by bucket size, largest first (stable): the four rows a wave processes in one
-//   step then have similar sizes, so a wave whose rows all fit the first 64-entry pass skips the second pass entirely
-//   (with the natural row order 94 % of the wave-steps of a 4096-wide layer execute a second, nearly empty pass);
-//   rowperm[(g*S + s)*RG + p] = row (within the group) whose bucket sits at position p,
-//   rowoff[(g*S + s)*(RG+1) + p] = global index of the first entry of the bucket at position p; slot RG closes the
-//   stream.  ~4.1 bytes per code + 4 bytes per (row, slice): 2.1x the canonical 2 bytes per code.  The extra bytes are
-//   free: the kernel runs at < 2 TB/s of HBM traffic, it is bound by LDS / ALU issue and latency, not by the stream.
+// Format v5 (built by aqlm_hip_prepack_1x16; specification + simulation: tests/packed_model.py):
+//   rows -> NG = 16 row-groups of RG rows; codes -> S = 16 slices by (code >> 12); workgroup (g, s) owns stream (g, s).
+//   In a stream every row's codes of the slice are rounded up to whole LANE-STEPS of 4 entries (>= 1; null entries pad)
+//   and the lane-steps of rows 0, 1, 2, ... are laid end to end.  The sequence is cut into NW wave ranges of 64*T
+//   lane-steps, a wave range into 64 lane COLUMNS of T lane-steps: lane l of wave w walks lane-steps
+//   [(w*64 + l)*T, +T).  Entry (w, t, l, k) is stored at (((st*NW + w)*T + t)*64 + l)*4 + k, so step t of a wave is ONE
+//   contiguous KiB at an address that depends on nothing but (st, w, t): no bucket table, no dependent round trip
+//   before the first code arrives (format v4 needed rowoff -> entries).
+//   entry = (j << 4 | fhi) << 16 | (code & 0xfff) << 4 | flo: `half & 0xfff0` IS the LDS byte offset of x[j] resp. of
+//   the codebook vector (one v_and_b32_sdwa each).  The spare nibbles carry the bookkeeping: bit 0 of a lane-step's
+//   first entry = "a row ends with this lane-step"; the first lane-step of every column carries the column's starting
+//   slot (15 bits over the remaining spare bits of entries 0 and 1).  null entry: j = in_groups (a zero vector in LDS).
+//   winfo[st][w] = {first row that STARTS in wave w, wave starts inside a row, steps with content, 0}.
+//   4 bytes per code + 6 bytes of padding per (row, slice) on average + < 1 step per wave of tail: ~2.1x the canonical
+//   code bytes for 4096-wide layers.
 //
-// Kernel: grid = 256 workgroups = 32 groups x 8 slices (slice = bid % 8 = the XCD the block is observed to land on, so
-// each XCD's L2 holds one slice; for speed only).  Workgroup (g, s): slice s of the codebook and x go to LDS; each quarter-wave (16 lanes) owns one
-// row of the group at a time; a lane takes 4 consecutive entries of that row's bucket per step (the typical 64-entry
-// bucket is one step): per entry 2 ds_read_b128 (codebook entry, x[j]) + 4 v_dot2c.  Entry loads run PD rows ahead.  fp32 partials [slice][row] -> workspace -> finalize kernel
-// (adds the 8 slices, scale + bias, one rounding).  Every lane does useful work (no scan, no 8x re-read of codes).
+// Kernel: grid = 256 workgroups = 16 groups x 16 slices (slice = block % 16 -> the two slices block % 8 and
+// block % 8 + 8 live in one XCD's L2).  Slice and x go to LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no
+// ds_write pass); the entry stream runs PD steps ahead in a register ring from fixed addresses, so it is in flight
+// before the LDS fill completes.  A lane accumulates its column in fp32; at a row end it adds the sum to the row's LDS
+// slot (ds_add_f32; a row spans 1-3 neighbouring columns of one wave; the part of a row that continues in the next
+// wave goes to that wave's carry slot and is added in wave order afterwards -> the summation order is fixed).  fp32
+// partials [slice][batch][row] -> workspace -> finalize kernel (adds the 16 slices, scale + bias, one rounding).
+// Per entry: 2 v_and_sdwa + 2 ds_read_b128 + 4 v_dot2c (x B for B input rows: one codebook read, B x reads).
 #include <algorithm>
 
 #include "aqlm_common.h"
 
 namespace aqlm {
 
-constexpr int PK_S = 8;        // slices
-constexpr int PK_NG = 32;      // row groups  (PK_S * PK_NG == 256 workgroups == CUs)
-constexpr int PK_SLICE_ENTRIES = 8192;
-constexpr int PK_PAD = 128;    // entries of slack behind the stream (prefetch may run past the end)
-constexpr int PK_MAX_RG = 4096;  // rows per row-group the load-time sort handles (out_features <= 131072)
-constexpr uint32_t PK_XBASE = 8192;  // x[j] lives at LDS slot 8192 + j (16-B slots), right behind the codebook slice
+constexpr int PK_S_LOG = 4;
+constexpr int PK_S = 1 << PK_S_LOG;          // slices
+constexpr int PK_NG = 256 / PK_S;            // row groups (PK_S * PK_NG == 256 workgroups == CUs)
+constexpr int PK_CODE_BITS = 16 - PK_S_LOG;  // bits of a code inside its slice
+constexpr int PK_SLICE_ENTRIES = 1 << PK_CODE_BITS;
+constexpr uint32_t PK_SLICE_BYTES = PK_SLICE_ENTRIES * 16;
+constexpr int PK_MAX_NW = 16;
+constexpr int PK_MAX_T = 1024;
+constexpr int PK_MAX_GROUPS = 4094;          // j needs 12 bits, in_groups itself is the null slot
+constexpr uint32_t PK_MAGIC = 0x35505141u;   // "AQP5"
+constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (x first, slice behind it)
 
 struct PackedLayout {
-  int M, in_groups, RG;
-  size_t n_rowoff;   // NG * S * (RG + 1)
-  size_t entries;    // capacity: M * in_groups real entries + up to 3 null entries per (row, slice)
-  size_t n_perm;     // NG * S * RG
-  size_t off_rowoff, off_perm, off_ent, total;
+  int M, in_groups, RG, NW, T;
+  size_t nst, off_winfo, off_rowstart, off_ent, ent_bytes, used;
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static bool packed_layout(int out_features, int in_features, int g, PackedLayout& L) {
-  if (g != 8 || out_features <= 0 || in_features <= 0 || in_features % 64 != 0 || in_features > 16320) return false;
+static bool packed_shape_ok(int out_features, int in_features, int g) {
+  return g == 8 && out_features > 0 && in_features > 0 && in_features % 8 == 0 && in_features / 8 <= PK_MAX_GROUPS &&
+         (out_features + PK_NG - 1) / PK_NG <= 32767 - PK_MAX_NW;
+}
+
+static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L) {
+  if (!packed_shape_ok(out_features, in_features, 8) || NW < 1 || NW > PK_MAX_NW || T < 1 || T > PK_MAX_T) return false;
   L.M = out_features;
   L.in_groups = in_features / 8;
-  L.RG = ((out_features + PK_NG - 1) / PK_NG + 3) / 4 * 4;
-  L.n_rowoff = (size_t)PK_NG * PK_S * (L.RG + 1);
-  L.entries = (size_t)out_features * L.in_groups + (size_t)3 * PK_S * out_features;
-  if ((L.entries + PK_PAD) * 4 >= ((size_t)1 << 32)) return false;  // 32-bit buffer offsets
-  if (L.RG > PK_MAX_RG) return false;
-  L.n_perm = (size_t)PK_NG * PK_S * L.RG;
-  L.off_rowoff = 256;  // header
-  L.off_perm = align_up(L.off_rowoff + L.n_rowoff * 4, 256);
-  L.off_ent = align_up(L.off_perm + L.n_perm * 2, 256);
-  L.total = align_up(L.off_ent + (L.entries + PK_PAD) * 4, 256);
-  return true;
+  L.RG = (out_features + PK_NG - 1) / PK_NG;
+  L.NW = NW;
+  L.T = T;
+  L.nst = (size_t)PK_NG * PK_S;
+  L.off_winfo = 256;
+  L.off_rowstart = align_up(L.off_winfo + L.nst * PK_MAX_NW * 16, 256);         // [nst][RG + 1] u32 (offset independent of NW)
+  L.off_ent = align_up(L.off_rowstart + L.nst * (size_t)(L.RG + 1) * 4, 1024);
+  L.ent_bytes = L.nst * NW * T * 1024;
+  L.used = L.off_ent + L.ent_bytes;
+  return L.ent_bytes < ((size_t)1 << 32);  // 32-bit buffer offsets
+}
+
+static bool desc_layout(const aqlm_hip_packed_desc* d, PackedLayout& L) {
+  return d && d->magic == PK_MAGIC && d->version == 5 && d->entry_bytes == 4 && d->slices_log2 == PK_S_LOG &&
+         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L) && L.used == d->used_bytes;
+}
+
+// wave-steps of work per workgroup -> waves per workgroup
+static int choose_waves(uint32_t max_lane_steps) {
+  const uint32_t q = (max_lane_steps + 63) / 64;
+  if (tuning().packed_waves == 4 || tuning().packed_waves == 8 || tuning().packed_waves == 16) return tuning().packed_waves;
+  return q >= 64 ? 16 : (q >= 24 ? 8 : 4);
 }
 
 // ------------------------------------------------------------------------------------------------ prepack
-// K1: per (row, slice) counts -> rowoff[] (as counts).  One wave per row.
-__global__ __launch_bounds__(256) void prepack_count_kernel(const uint16_t* codes, uint32_t* rowoff, int M, int in_groups,
-                                                            int RG) {
+// K1: lane-steps per (row, slice) -> a[st][r].  One wave per row.
+__global__ __launch_bounds__(256) void pk_count_kernel(const uint16_t* codes, uint32_t* a, int M, int in_groups, int RG) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -80,7 +99,7 @@ __global__ __launch_bounds__(256) void prepack_count_kernel(const uint16_t* code
 #pragma unroll
   for (int s = 0; s < PK_S; ++s) cnt[s] = 0;
   for (int j = lane; j < in_groups; j += 64) {
-    const uint32_t sl = codes[(size_t)row * in_groups + j] >> 13;
+    const uint32_t sl = codes[(size_t)row * in_groups + j] >> PK_CODE_BITS;
 #pragma unroll
     for (int s = 0; s < PK_S; ++s) cnt[s] += (sl == (uint32_t)s);
   }
@@ -90,295 +109,340 @@ __global__ __launch_bounds__(256) void prepack_count_kernel(const uint16_t* code
     uint32_t v = cnt[s];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    if (lane == 0) rowoff[((size_t)g * PK_S + s) * (RG + 1) + r] = (v + 3u) & ~3u;  // padded to 4 entries
+    if (lane == 0) a[((size_t)g * PK_S + s) * (RG + 1) + r] = v == 0 ? 1u : (v + 3u) >> 2;
   }
 }
 
-// K2: in-place exclusive prefix sum over the flat rowoff array (single block; load-time code, not a hot path).
-__global__ __launch_bounds__(1024) void prepack_scan_kernel(uint32_t* rowoff, size_t n) {
-  __shared__ uint32_t sums[1024];
+// K2: per stream, in-place exclusive prefix sum over a[st][0..RG]; a[st][RG] = total; maxL = max total.
+__global__ __launch_bounds__(256) void pk_scan_kernel(uint32_t* a, uint32_t* maxL, int RG) {
+  __shared__ uint32_t sums[256];
+  uint32_t* row = a + (size_t)blockIdx.x * (RG + 1);
   const int t = threadIdx.x;
-  const size_t chunk = (n + 1023) / 1024;
-  const size_t lo = std::min(n, (size_t)t * chunk), hi = std::min(n, lo + chunk);
+  const int n = RG + 1;
+  const int chunk = (n + 255) / 256;
+  const int lo = std::min(n, t * chunk), hi = std::min(n, lo + chunk);
   uint32_t s = 0;
-  for (size_t i = lo; i < hi; ++i) s += rowoff[i];
+  for (int i = lo; i < hi; ++i) s += row[i];
   sums[t] = s;
   __syncthreads();
   if (t == 0) {
     uint32_t run = 0;
-    for (int i = 0; i < 1024; ++i) {
+    for (int i = 0; i < 256; ++i) {
       const uint32_t v = sums[i];
       sums[i] = run;
       run += v;
     }
+    atomicMax(maxL, run);
   }
   __syncthreads();
   uint32_t run = sums[t];
-  for (size_t i = lo; i < hi; ++i) {
-    const uint32_t v = rowoff[i];
-    rowoff[i] = run;
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t v = row[i];
+    row[i] = run;
     run += v;
   }
 }
 
-// K1b: per stream (g, s): rank the rows by bucket size (descending, ties by row index) and put the counts in that
-// order.  rank[] (row -> position) is kept in the rowperm array until the scatter / arrange passes are done; K5 inverts it.
-__global__ __launch_bounds__(1024) void prepack_sort_kernel(uint32_t* rowoff, uint16_t* rank, int RG) {
-  __shared__ uint32_t c[PK_MAX_RG];
-  uint32_t* cnt = rowoff + (size_t)blockIdx.x * (RG + 1);
-  uint16_t* rk = rank + (size_t)blockIdx.x * RG;
-  for (int r = threadIdx.x; r < RG; r += 1024) c[r] = cnt[r];
-  __syncthreads();
-  uint32_t mine[PK_MAX_RG / 1024], pos[PK_MAX_RG / 1024];
-#pragma unroll
-  for (int i = 0; i < PK_MAX_RG / 1024; ++i) {
-    const int r = threadIdx.x + i * 1024;
-    mine[i] = r < RG ? c[r] : 0u;
-    uint32_t k = 0;
-    if (r < RG)
-      for (int r2 = 0; r2 < RG; ++r2) k += (c[r2] > mine[i]) || (c[r2] == mine[i] && r2 < r);
-    pos[i] = k;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < PK_MAX_RG / 1024; ++i) {
-    const int r = threadIdx.x + i * 1024;
-    if (r < RG) {
-      cnt[pos[i]] = mine[i];
-      rk[r] = (uint16_t)pos[i];
-    }
-  }
+__global__ __launch_bounds__(256) void pk_fill_kernel(uint32_t* p, size_t n, uint32_t v) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
-// K4b: order of a lane's four entries over the four levels, chosen per PAIR of neighbouring buckets so that the
-// codebook reads collide as little as possible.  The 16 lanes one ds_read_b128 pass services are l16 in {0-3,12-15} of
-// the even position of a pair plus l16 in {4-11} of the odd one ("group A"), and the complementary halves ("group B");
-// the x slots of those lanes are distinct by construction (K4), the codebook slots (code mod 16) are random: ~2.9
-// passes per read, and the gather loop is LDS-bound (traced: 0.55 us per 64-row step = the LDS cycles of 8 reads per
-// lane).  Greedy, deterministic: lanes are visited in order (even bucket, then odd bucket, lane by lane); each picks the
-// first of the 24 orders of its entries that adds the fewest collisions to the levels of its group.  Moving an entry to
-// another level of the SAME lane keeps K4's x property.  Only the two prefetched passes (entries 0-127) are treated.
-__device__ __forceinline__ bool pk_lane_in_x_half(int l16) { return l16 < 4 || l16 >= 12; }
-
-__global__ __launch_bounds__(64) void prepack_level_kernel(const uint32_t* rowoff, uint32_t* ent, int RG) {
-  const int stream = blockIdx.y;
-  const int pair = blockIdx.x * 64 + threadIdx.x;
-  if (pair >= RG / 2) return;  // RG is a multiple of 4: every position has a partner
-  const uint32_t* ro = rowoff + (size_t)stream * (RG + 1) + 2 * pair;
-  const uint32_t beg[2] = {ro[0], ro[1]};
-  const uint32_t len[2] = {ro[1] - ro[0], ro[2] - ro[1]};
-  // the 24 orders of four items, lexicographic: entry perm[k] of the lane goes to level k
-  const unsigned char P[24][4] = {{0,1,2,3},{0,1,3,2},{0,2,1,3},{0,2,3,1},{0,3,1,2},{0,3,2,1},{1,0,2,3},{1,0,3,2},
-                                  {1,2,0,3},{1,2,3,0},{1,3,0,2},{1,3,2,0},{2,0,1,3},{2,0,3,1},{2,1,0,3},{2,1,3,0},
-                                  {2,3,0,1},{2,3,1,0},{3,0,1,2},{3,0,2,1},{3,1,0,2},{3,1,2,0},{3,2,0,1},{3,2,1,0}};
-  for (uint32_t region = 0; region < 128; region += 64) {
-    uint32_t used[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // [group A / B][level]: bit r = codebook residue r taken
-    for (int l = 0; l < 16; ++l) {
-      for (int b = 0; b < 2; ++b) {
-        const uint32_t off = region + 4u * (uint32_t)l;
-        if (off + 4u > len[b]) continue;  // this lane has no chunk in this bucket
-        u32x4* slot = reinterpret_cast<u32x4*>(ent + beg[b] + off);
-        const u32x4 e = *slot;
-        const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
-        const int grp = (pk_lane_in_x_half(l) == (b == 0)) ? 0 : 1;
-        int best = 0, best_cost = 5;
-        for (int q = 0; q < 24; ++q) {
-          int cost = 0;
-          for (int k = 0; k < 4; ++k) cost += (int)((used[grp][k] >> (ev[P[q][k]] & 15u)) & 1u);
-          if (cost < best_cost) { best_cost = cost; best = q; }
-        }
-        u32x4 o;
-        o.x = ev[P[best][0]]; o.y = ev[P[best][1]]; o.z = ev[P[best][2]]; o.w = ev[P[best][3]];
-        *slot = o;
-        used[grp][0] |= 1u << (o.x & 15u);
-        used[grp][1] |= 1u << (o.y & 15u);
-        used[grp][2] |= 1u << (o.z & 15u);
-        used[grp][3] |= 1u << (o.w & 15u);
-      }
-    }
-  }
+__device__ __forceinline__ size_t pk_entry_index(uint32_t q, int k, size_t st, int NW, int T) {
+  const uint32_t w = q / (64u * T), rem = q - w * 64u * T;
+  const uint32_t l = rem / T, t = rem - l * T;
+  return ((((size_t)st * NW + w) * T + t) * 64 + l) * 4 + k;
 }
 
-// K5: rank (row -> position) -> rowperm (position -> row), in place.
-__global__ __launch_bounds__(1024) void prepack_invert_kernel(uint16_t* rank, int RG) {
-  __shared__ uint16_t t[PK_MAX_RG];
-  uint16_t* rk = rank + (size_t)blockIdx.x * RG;
-  for (int r = threadIdx.x; r < RG; r += 1024) t[r] = rk[r];
-  __syncthreads();
-  for (int r = threadIdx.x; r < RG; r += 1024) rk[t[r]] = (uint16_t)r;
-}
-
-// K3: scatter the entries.  One wave per row; ascending j within each (row, slice) bucket.
-__global__ __launch_bounds__(256) void prepack_scatter_kernel(const uint16_t* codes, const uint32_t* rowoff,
-                                                              const uint16_t* rank, uint32_t* ent, int M, int in_groups,
-                                                              int RG) {
+// K3: scatter the entries, ascending j inside every (row, slice).  One wave per row.
+__global__ __launch_bounds__(256) void pk_scatter_kernel(const uint16_t* codes, const uint32_t* a, uint32_t* ent, int M,
+                                                         int in_groups, int RG, int NW, int T) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int g = row / RG, r = row - g * RG;
-  uint32_t base[PK_S];
+  uint32_t cnt[PK_S];  // entries of this row already placed, per slice
 #pragma unroll
-  for (int s = 0; s < PK_S; ++s)
-    base[s] = rowoff[((size_t)g * PK_S + s) * (RG + 1) + rank[((size_t)g * PK_S + s) * RG + r]];
+  for (int s = 0; s < PK_S; ++s) cnt[s] = 0;
   for (int j0 = 0; j0 < in_groups; j0 += 64) {
     const int j = j0 + lane;
     const bool ok = j < in_groups;
     const uint32_t code = ok ? codes[(size_t)row * in_groups + j] : 0u;
-    const uint32_t sl = ok ? (code >> 13) : 0xffffffffu;
+    const uint32_t sl = ok ? (code >> PK_CODE_BITS) : 0xffffffffu;
 #pragma unroll
     for (int s = 0; s < PK_S; ++s) {
       const bool mine = sl == (uint32_t)s;
-      const unsigned long long mask = __ballot(mine);
-      const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
-      if (mine) ent[base[s] + before] = ((PK_XBASE + (uint32_t)j) << 16) | (code & 0x1fffu);
-      base[s] += __popcll(mask);
+      const unsigned long long m = __ballot(mine);
+      if (mine) {
+        const size_t st = (size_t)g * PK_S + s;
+        const uint32_t i = cnt[s] + __popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t q = a[st * (RG + 1) + r] + (i >> 2);
+        ent[pk_entry_index(q, i & 3, st, NW, T)] = ((uint32_t)j << 20) | ((code & (PK_SLICE_ENTRIES - 1)) << 4);
+      }
+      cnt[s] += __popcll(m);
     }
-  }
-  // pad every bucket to a multiple of 4 entries with null entries: j = in_groups (x[in_groups] is zero in LDS)
-#pragma unroll
-  for (int s = 0; s < PK_S; ++s) {
-    const uint32_t pad = (0u - base[s]) & 3u;  // bucket starts are multiples of 4
-    if ((uint32_t)lane < pad) ent[base[s] + lane] = (PK_XBASE + (uint32_t)in_groups) << 16;
   }
 }
 
-// K4: bank-aware order of the entries inside every (row, slice) bucket.  In the gemv kernel lane l16 of a quarter-wave
-// reads entries 4*l16 + k (k = 0..3: "level" k) of its row's bucket, and the 16 lanes serviced together by one
-// ds_read_b128 pass are l16 in {0-3, 12-15} of one row plus l16 in {4-11} of its neighbour row (service groups of a
-// wave64 b128 read: lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} / +32).  With ascending-j order the x[j] reads of a
-// level hit random 16-B slots (~3-way bank conflicts; traced: the gather loop is LDS-bound).  Here every entry whose
-// x slot has residue rho = j mod 16 is sent to its "home" lane -- residues 0-7 to l16 {0-3, 12-15}, residues 8-15 to
-// l16 {4-11} -- at the next free level, so that the 16 lanes of a service group read 16 DIFFERENT slot residues
-// whatever the neighbour row is.  Entries that find their home lane full (or absent in a short bucket) fill the
-// remaining holes in index order.  The sum over a bucket is order-independent up to fp32 rounding; the order is fixed
-// by this kernel (and mirrored by the numpy model in tests/), so results stay deterministic.
-constexpr int PK_MAX_GROUPS = 2040;
-constexpr uint32_t PK_EMPTY = 0xffffffffu;
+// K3b: bank-aware order of the entries.  In the gemv kernel the 64 lanes of a wave execute entry slot (t, k) together:
+// one ds_read_b128 for the codebook vectors, one for the x vectors.  The LDS services such a read in four groups of 16
+// lanes (MI355X_MICROARCH.md: {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) and needs one extra cycle for every lane whose
+// 16-B slot falls into a bank group (slot % 16) another lane of its group already uses: random slots cost ~3 cycles per
+// group instead of 1, for both reads, and the loop is LDS-bound (traced: 0.36 us per step for 8 waves).  A row's entries
+// may be summed in any order, so inside every ROW PIECE of a lane column (the consecutive lane-steps of one row within
+// the column) this kernel re-deals the entries over the piece's slots: greedy, slot by slot; within a slot the 16 lanes
+// of a service group choose one after the other (rotating priority), each taking from its own piece an entry whose x
+// bank group AND codebook bank group are still free in its service group (else a null entry -- all nulls read the same
+// two addresses, which the LDS broadcasts --, else one that is free in one of the two).  Fixed order of choices ->
+// deterministic layout.  One wave per (stream, wave range), lane = column; columns of more than 32 steps are left in
+// ascending-j order.
+constexpr int PK_ARR_MAX_T = 32;
 
-__device__ __forceinline__ int pk_home_lane(uint32_t rho) { return rho < 4 ? (int)rho : (rho < 8 ? (int)rho + 8 : (int)rho - 4); }
+__device__ __forceinline__ int pk_service_group(int l) {  // 0..3
+  const int h = l & 31;
+  const bool g0 = h < 4 || (h >= 12 && h < 16) || (h >= 20 && h < 28);
+  return (l >> 5) * 2 + (g0 ? 0 : 1);
+}
+__device__ __forceinline__ int pk_group_pos(int l) {  // 0..15: position of the lane inside its service group
+  const int h = l & 31;
+  if (h < 4) return h;                 // G0: 0-3
+  if (h < 12) return h - 4;            // G1: 4-11 -> 0-7
+  if (h < 16) return h - 12 + 4;       // G0: 12-15 -> 4-7
+  if (h < 20) return h - 16 + 8;       // G1: 16-19 -> 8-11
+  if (h < 28) return h - 20 + 8;       // G0: 20-27 -> 8-15
+  return h - 28 + 12;                  // G1: 28-31 -> 12-15
+}
 
-__global__ __launch_bounds__(128) void prepack_arrange_kernel(const uint32_t* rowoff, const uint16_t* rank, uint32_t* ent, int M,
-                                                              int in_groups, int RG) {
-  __shared__ uint32_t in_s[2][PK_MAX_GROUPS + 32];
-  __shared__ uint32_t out_s[2][PK_MAX_GROUPS + 32];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = blockIdx.x * 2 + w;
-  if (row >= M) return;  // whole wave exits together; no block barrier is used below
-  const int g = row / RG, r = row - g * RG;
-  uint32_t start[PK_S], len[PK_S], off[PK_S];
-  uint32_t run = 0;
-#pragma unroll
-  for (int s = 0; s < PK_S; ++s) {
-    const size_t k = ((size_t)g * PK_S + s) * (RG + 1) + rank[((size_t)g * PK_S + s) * RG + r];
-    start[s] = rowoff[k];
-    len[s] = rowoff[k + 1] - start[s];
-    off[s] = run;
-    run += len[s];
+__global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint32_t* ent, int M, int in_groups, int RG, int NW,
+                                                        int T) {
+  extern __shared__ uint32_t arr_sm[];
+  uint32_t* in = arr_sm;                                              // [T][64][4]
+  unsigned char* pbeg = reinterpret_cast<unsigned char*>(in + (size_t)T * 256);  // [T][64] first step of the slot's piece
+  unsigned char* pend = pbeg + (size_t)T * 64;                       // [T][64] one past its last step
+  uint32_t* gmask = reinterpret_cast<uint32_t*>(pend + (size_t)T * 64);  // [4][2] bank groups taken in the current slot
+  const size_t st = blockIdx.x;
+  const int w = blockIdx.y, l = threadIdx.x;
+  const int g = (int)(st / PK_S);
+  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  const uint32_t* starts = a + st * (RG + 1);
+  const uint32_t total = starts[nrows];
+  uint32_t* col = ent + ((((size_t)st * NW + w) * T) * 64 + l) * 4;   // + t * 256
+  const uint32_t q0 = ((uint32_t)w * 64u + (uint32_t)l) * (uint32_t)T;
+  for (int t = 0; t < T; ++t) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)t * 256);
+    *reinterpret_cast<u32x4*>(in + ((size_t)t * 64 + l) * 4) = v;
   }
-#pragma unroll
-  for (int s = 0; s < PK_S; ++s)
-    for (uint32_t i = lane; i < len[s]; i += 64) {
-      in_s[w][off[s] + i] = ent[start[s] + i];
-      out_s[w][off[s] + i] = PK_EMPTY;
-    }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  if (lane < PK_S) {  // lane s arranges bucket s (serial: load-time code, a few microseconds per layer in total)
-    uint32_t st = 0, ln = 0;
-#pragma unroll
-    for (int s = 0; s < PK_S; ++s)
-      if (lane == s) { st = off[s]; ln = len[s]; }
-    uint32_t* in = &in_s[w][st];
-    uint32_t* out = &out_s[w][st];
-    const uint32_t null_entry = (PK_XBASE + (uint32_t)in_groups) << 16;
-    uint32_t n = ln;  // real entries come first, the (< 4) null entries of the scatter pass last
-    while (n > 0 && in[n - 1] == null_entry) --n;
-    const int m = ln / 4 < 16 ? (int)(ln / 4) : 16;
-    unsigned long long cnt = 0;  // 16 x 3-bit level counters
-    for (uint32_t i = 0; i < n; ++i) {
-      const uint32_t e = in[i];
-      const int L = pk_home_lane((e >> 16) & 15u);
-      const uint32_t c = (uint32_t)(cnt >> (3 * L)) & 7u;
-      if (L < m && c < 4) {
-        out[4 * L + c] = e;
-        cnt += 1ull << (3 * L);
-        in[i] = PK_EMPTY;
+  {  // piece bounds of every step of this column
+    int r = nrows;
+    if (q0 < total) {  // last r with starts[r] <= q0
+      int lo = 0, hi = nrows;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= q0) lo = mid; else hi = mid;
       }
+      r = lo;
     }
-    uint32_t idx = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-      const uint32_t e = in[i];
-      if (e == PK_EMPTY) continue;
-      while (out[idx] != PK_EMPTY) ++idx;
-      out[idx++] = e;
+    for (int t = 0; t < T; ++t) {
+      const uint32_t q = q0 + (uint32_t)t;
+      int b = t, e = t + 1;  // trailing null steps: pieces of one step
+      if (q < total) {
+        while (starts[r + 1] <= q) ++r;
+        const uint32_t rs = starts[r], re = starts[r + 1];
+        b = rs > q0 ? (int)(rs - q0) : 0;
+        e = re < q0 + (uint32_t)T ? (int)(re - q0) : T;
+      }
+      pbeg[t * 64 + l] = (unsigned char)b;
+      pend[t * 64 + l] = (unsigned char)e;
     }
-    for (uint32_t i = 0; i < ln; ++i)
-      if (out[i] == PK_EMPTY) out[i] = null_entry;
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
+  if (l < 8) gmask[l] = 0u;
+  __syncthreads();
+  const int grp = pk_service_group(l), pos = pk_group_pos(l);
+  unsigned long long used_lo = 0ull, used_hi = 0ull;  // bit (t * 4 + k) of this column's entries already dealt
+  const uint32_t null_j = (uint32_t)in_groups;
+  for (int s = 0; s < 4 * T; ++s) {
+    const int t = s >> 2, k = s & 3;
+    const int rank = (pos + s) & 15;
+    for (int r = 0; r < 16; ++r) {
+      if (rank == r) {
+        const uint32_t ux = gmask[grp * 2], uc = gmask[grp * 2 + 1];
+        const int b = pbeg[t * 64 + l], e = pend[t * 64 + l];
+        int best = -1, best_score = -1;
+        uint32_t best_v = 0u;
+        for (int i = b * 4; i < e * 4 && best_score < 4; ++i) {
+          const bool is_used = i < 64 ? ((used_lo >> i) & 1ull) : ((used_hi >> (i - 64)) & 1ull);
+          if (is_used) continue;
+          const uint32_t v = in[((size_t)(i >> 2) * 64 + l) * 4 + (i & 3)];
+          const uint32_t j = v >> 20;
+          int score;
+          if (j == null_j) score = 3;
+          else {
+            const bool xf = !((ux >> (j & 15u)) & 1u), cf = !((uc >> ((v >> 4) & 15u)) & 1u);
+            score = xf && cf ? 4 : (xf ? 2 : (cf ? 1 : 0));
+          }
+          if (score > best_score) { best_score = score; best = i; best_v = v; }
+        }
+        // every slot of a piece has an entry left: pieces hold exactly 4 * (e - b) entries
+        if (best < 0) __builtin_trap();
+        if (best < 64) used_lo |= 1ull << best; else used_hi |= 1ull << (best - 64);
+        col[(size_t)t * 256 + k] = best_v;
+        if ((best_v >> 20) != null_j) {
+          gmask[grp * 2] = ux | (1u << ((best_v >> 20) & 15u));
+          gmask[grp * 2 + 1] = uc | (1u << ((best_v >> 4) & 15u));
+        }
+      }
+      __syncthreads();
+    }
+    if (l < 8) gmask[l] = 0u;
+    __syncthreads();
+  }
+}
+
+// K4: bookkeeping bits.  Thread (st, r): flag on the row's last lane-step.
+__global__ __launch_bounds__(256) void pk_flag_kernel(const uint32_t* a, uint32_t* ent, int M, int RG, int NW, int T) {
+  const size_t st = blockIdx.y;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int g = (int)(st / PK_S);
+  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  if (r >= nrows) return;
+  const uint32_t ql = a[st * (RG + 1) + r + 1] - 1;
+  atomicOr(&ent[pk_entry_index(ql, 0, st, NW, T)], 1u);
+}
+
+// K5: per lane column its starting row (in the spare bits of the column's first lane-step), per wave winfo.
+__global__ __launch_bounds__(64) void pk_column_kernel(const uint32_t* a, uint32_t* ent, uint32_t* winfo, int M, int RG,
+                                                       int NW, int T) {
+  const size_t st = blockIdx.x;
+  const int w = blockIdx.y, l = threadIdx.x;
+  const int g = (int)(st / PK_S);
+  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  const uint32_t* starts = a + st * (RG + 1);  // starts[r], r < nrows; starts[nrows] == total (rows past M have 0 steps)
+  const uint32_t total = starts[nrows];
+  const uint32_t w0 = (uint32_t)w * 64u * T;
+  if (l == 0) {
+    // wfr = first r in [0, nrows] with starts[r] >= w0  (informational: first row that starts in this wave range)
+    int lo = 0, hi = nrows;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (starts[mid] >= w0) hi = mid; else lo = mid + 1;
+    }
+    uint32_t* wi = winfo + (st * NW + w) * 4;
+    wi[0] = (uint32_t)lo;
+    wi[1] = (w0 < total && starts[lo] > w0) ? 1u : 0u;
+    wi[2] = w0 >= total ? 0u : (total - w0 >= (uint32_t)T ? (uint32_t)T : total - w0);
+    wi[3] = 0u;
+  }
+  const uint32_t q = w0 + (uint32_t)l * T;
+  int r0;
+  if (q >= total) {
+    r0 = nrows;
+  } else {  // last r with starts[r] <= q
+    int a0 = 0, b0 = nrows;  // invariant: starts[a0] <= q, answer in [a0, b0)
+    while (b0 - a0 > 1) {
+      const int mid = (a0 + b0) >> 1;
+      if (starts[mid] <= q) a0 = mid; else b0 = mid;
+    }
+    r0 = a0;
+  }
+  const uint32_t f = (uint32_t)r0;
+  uint32_t* e = ent + ((((size_t)st * NW + w) * T + 0) * 64 + l) * 4;
+  e[0] |= ((f & 7u) << 1) | (((f >> 3) & 15u) << 16);
+  e[1] |= ((f >> 7) & 15u) | (((f >> 11) & 15u) << 16);
+}
+
+// inverse of the repack: canonical codes [M][in_groups] from a packed buffer (lossless; used to drop / restore the
+// canonical codes of inference-only models and by the tests).  One wave per (stream, wave range).
+__global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, const uint32_t* winfo, uint16_t* codes, int M,
+                                                       int in_groups, int RG, int NW, int T) {
+  const size_t st = blockIdx.x;
+  const int w = blockIdx.y, l = threadIdx.x;
+  const int g = (int)(st / PK_S), s = (int)(st % PK_S);
+  const uint32_t* wi = winfo + (st * NW + w) * 4;
+  const int steps = (int)wi[2];
+  const uint32_t* col = ent + (((size_t)st * NW + w) * T * 64 + l) * 4;
+  int local = 0;
+  for (int t = 0; t < steps; ++t) {
+    const uint32_t* e = col + (size_t)t * 256;
+    const uint32_t e0 = e[0], e1 = e[1];
+    if (t == 0) local = (int)(((e0 >> 1) & 7u) | (((e0 >> 16) & 15u) << 3) | ((e1 & 15u) << 7) | (((e1 >> 16) & 15u) << 11));
+    const int row = g * RG + local;
 #pragma unroll
-  for (int s = 0; s < PK_S; ++s)
-    for (uint32_t i = lane; i < len[s]; i += 64) ent[start[s] + i] = out_s[w][off[s] + i];
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t v = e[k];
+      const int j = (int)(v >> 20);
+      if (j < in_groups && row < M) codes[(size_t)row * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | ((v >> 4) & 0xfffu));
+    }
+    local += (int)(e0 & 1u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ gemv
 struct PackedGemvParams {
-  const uint32_t* rowoff;
-  const uint16_t* rowperm;
   const uint32_t* ent;
+  const uint32_t* winfo;
+  const uint32_t* rowstart;  // [nst][RG + 1]
   const uint8_t* codebook;
   const uint16_t* x;
-  float* partial;  // [S][M]
-  int M, in_groups, RG;
+  float* partial;  // [S][B][M]
+  long x_row_stride;
+  int M, in_groups, RG, NW, T;
   uint32_t ent_bytes;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
 #endif
 };
 
-// LDS access by absolute byte address.  The kernel has no static LDS, so its dynamic LDS starts at address 0 (checked
-// at kernel entry): the codebook slice occupies [0, 128 KiB) and x slot j sits at (8192 + j) * 16.
 typedef __attribute__((address_space(3))) const u32x4* lds_u32x4_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
+typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;  // constant address space: uniform loads go through s_load
 
 template <int WORD>
-__device__ __forceinline__ uint32_t half_shl4(uint32_t w, uint32_t four) {
-  uint32_t d;  // d = ((w >> 16*WORD) & 0xffff) << 4 in one instruction (sub-dword operand select)
+__device__ __forceinline__ uint32_t half_and(uint32_t w, uint32_t mask) {
+  uint32_t d;  // d = ((w >> 16*WORD) & 0xffff) & mask in one instruction (sub-dword operand select)
   if constexpr (WORD == 0)
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(four), "v"(w));
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(mask), "v"(w));
   else
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(four), "v"(w));
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(mask), "v"(w));
   return d;
 }
 
-// one 32-bit entry -> fp32 contribution
-template <class T>
-__device__ __forceinline__ float packed_entry(uint32_t w, uint32_t four, float acc) {
-  const u32x4 e = *(lds_u32x4_ptr)(size_t)half_shl4<0>(w, four);   // codebook vector of (code & 0x1fff)
-  const u32x4 xv = *(lds_u32x4_ptr)(size_t)half_shl4<1>(w, four);  // x[j]
-  return dot8<T>(e, xv, acc);
+__device__ __forceinline__ void lds_store_f32(uint32_t byte_addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" : : "v"(byte_addr), "v"(v) : "memory");
 }
 
-// `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
-// LPR = lanes per row: 16 (a quarter-wave per row: layers whose (row, slice) buckets hold ~64 entries and more), 8 or 4
-// (16 rows per wave step: narrow layers,  [32 / 64 lanes per row for wide layers were measured slower: 14336->4096
-// 16.3 vs 15.6 us, 8192->28672 39 vs 35 us -- more steps outweigh the avoided third-pass loop] e.g. the 1024-wide shards of a row-parallel 70B layer, whose buckets hold ~16
-// entries -- with 16 lanes per row three quarters of the lanes would idle and the loop would need 4x the steps).
-template <class T, int NWAVES, int PD, int LPR = 16>
-__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
-  constexpr int NT = NWAVES * 64;
-  constexpr int RPW = 64 / LPR;          // rows per wave and step
-  constexpr int STRIDE = NWAVES * RPW;   // rows between two consecutive rows of one lane group
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32x4* const cbl = reinterpret_cast<u32x4*>(smem_raw);   // [8192] codebook slice
-  u32x4* const xl = cbl + PK_SLICE_ENTRIES;                  // [in_groups + 1] x, 16 B per input group, then zeros
+// LDS map (byte offsets from the start of the workgroup's LDS, which is address 0: the kernel has no static LDS).
+//   B == 1: x at 0 (XWIN bytes reserved), slice at XWIN, bookkeeping behind the slice   (x-first: both reads cost one op)
+//   B  > 1: slice at 0, then B planes x[b][j] of XP = (in_groups + 1) * 16 bytes (a plane keeps the bank pattern of
+//           the single-row case: slot j -> bank group j % 16; interleaving the rows would leave 16 / B groups), bookkeeping
+//   bookkeeping: rowstart[RG + 1] u32 (LDS-DMA copy of the stream's row starts), rowval[B][RG + 1] f32 (sum of the
+//   lane-steps of a row from the start of the column that holds its LAST lane-step), colend[B][16 * 64] f32 (what a
+//   column accumulated after its last row end: the head of a row that continues in the next column)
+template <int B, uint32_t XWIN>
+struct PackedLds {
+  static constexpr bool XFIRST = (B == 1);
+  static constexpr uint32_t SLICE = XFIRST ? XWIN : 0u;
+  static constexpr uint32_t X = XFIRST ? 0u : PK_SLICE_BYTES;
+  __host__ __device__ static uint32_t plane(int in_groups) { return (uint32_t)(in_groups + 1) * 16u; }
+  __host__ __device__ static uint32_t rowstart(int in_groups) {
+    return XFIRST ? XWIN + PK_SLICE_BYTES : PK_SLICE_BYTES + plane(in_groups) * B;
+  }
+  __host__ __device__ static uint32_t rs_bytes(int RG) { return ((uint32_t)(RG + 1) * 4u + 1023u) & ~1023u; }  // whole DMA pieces
+  __host__ __device__ static uint32_t rowval(int in_groups, int RG) { return rowstart(in_groups) + rs_bytes(RG); }
+  __host__ __device__ static uint32_t colend(int in_groups, int RG) { return rowval(in_groups, RG) + (uint32_t)B * (RG + 1) * 4u; }
+  __host__ __device__ static size_t total(int in_groups, int RG) {
+    return (size_t)colend(in_groups, RG) + (size_t)B * PK_MAX_NW * 64 * 4;
+  }
+};
 
+// `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
+template <class T_, int B, int PD, uint32_t XWIN>
+__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
+  using LDS = PackedLds<B, XWIN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
+  const int NT = (int)blockDim.x;
+  const int NWB = NT >> 6;                                              // waves in the workgroup (>= p.NW)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l16 = lane & (LPR - 1), quarter = lane / LPR;  // lane within its row's group, group within the wave
-  // slice = blockIdx % 8: blocks are observed to land on XCD blockIdx % 8, so each XCD's L2 serves ONE 128 KiB slice
-  // (fetched once) instead of the whole codebook (speed only; any placement is correct).  Workgroups of one row-group
-  // share nothing -- each walks its own bucket stream -- so they need not be co-located.
 #ifdef AQLM_PACKED_TRACE
   unsigned long long tr[7];
   tr[0] = wall_clock64();
@@ -386,215 +450,239 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #else
 #define AQLM_TRACE(i)
 #endif
-  const int slice = block & 7;
-  const int group = block >> 3;
+  // slice = block % 16: blocks are observed to land on XCD block % 8, so each XCD's L2 serves two 64 KiB slices
+  // (speed only; any placement is correct).
+  const int slice = block & (PK_S - 1);
+  const int group = block >> PK_S_LOG;
   const int row_begin = group * p.RG;
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
-  const uint32_t* const ro = p.rowoff + ((size_t)group * PK_S + slice) * (p.RG + 1);
-  const uint16_t* const pm = p.rowperm + ((size_t)group * PK_S + slice) * p.RG;  // position -> row of the group
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();  // LDS map above
 
-  __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
-  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();  // see lds_u32x4_ptr
+  const int RG1 = p.RG + 1;
+  const uint32_t rowstart_off = LDS::rowstart(p.in_groups);
+  const uint32_t rowval_off = LDS::rowval(p.in_groups, p.RG);
+  const uint32_t colend_off = LDS::colend(p.in_groups, p.RG);
 
-  // Software pipeline over this quarter-wave's rows r0, r0+STRIDE, ...: bucket bounds run 2*PD rows ahead (ring of
-  // 2*PD slots), the first two 4-entry chunks of each lane PD rows ahead (ring of PD slots).  Rings are indexed with
-  // compile-time slots only (main loop unrolled 2*PD times) and never copied, so no in-flight register is touched
-  // before its row is consumed.  Everything below is issued before the LDS fill (HBM latency overlaps it).
-  constexpr int NB2 = 2 * PD;
-  const int r0 = wave * RPW + quarter;
-  uint32_t bst[NB2], ben[NB2];
-  uint16_t brow[NB2];
-  u32x4 e_q[PD], e_q2[PD];              // chunk l16 and chunk l16 + 16 (buckets of 65..128 entries) of each row
-  // Every load below is UNCONDITIONAL (rows past the end are clamped to the closing rowoff slot = an empty bucket;
-  // chunks past a bucket's end read neighbouring entries or, past the planes, zeros from the bounds-checked buffer
-  // descriptor, and are never consumed).  Loads inside divergent branches make hipcc's s_waitcnt bookkeeping fall
-  // back to vmcnt(0) at every use, which serialises the whole prefetch pipeline (measured: 0.85 us per step).
-  auto bounds = [&](int r, uint32_t& st, uint32_t& en, uint16_t& row) {  // r is a POSITION in the sorted stream
-    const int a = r < p.RG ? r : p.RG, b = r + 1 < p.RG ? r + 1 : p.RG;
-    st = ro[a];
-    en = ro[b];
-    row = pm[r < p.RG ? r : p.RG - 1];
-  };
-  auto fetch = [&](uint32_t st, int chunk, u32x4& e) {
-    e = __builtin_amdgcn_raw_buffer_load_b128(rs_ent, (st + 4u * (uint32_t)chunk) * 4u, 0, 0);
-  };
-  // Prologue, in dependency order.  Loads return in issue order (one vmcnt counter), so the bucket bounds go FIRST:
-  // the entry fetches that depend on them can then be issued while the 128 KiB codebook slice and x are still in
-  // flight, instead of the slice being requested only after the rowoff round trip (traced: 1.9 us from kernel entry to
-  // "all loads issued" before this ordering).
-#pragma unroll
-  for (int k = 0; k < NB2; ++k) bounds(r0 + k * STRIDE, bst[k], ben[k], brow[k]);
-  constexpr int PER = PK_SLICE_ENTRIES / NT;
-  static_assert(PK_SLICE_ENTRIES % NT == 0, "slice must split evenly over the workgroup");
-  static_assert(2 * NT >= 2040, "x is staged in one pass of two pieces per thread (in_features <= 16320)");
-  u32x4 stage[PER], xv[2];
+  // ---- prologue: everything that needs no other data is issued first, in one burst -------------------------------
+  const uint32_t XP = LDS::plane(p.in_groups);
+  // (1) LDS-DMA: the 64 KiB slice (shared by the 16 workgroups of the XCD that hold it -> L2 hits) and x
   {
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebook) + (size_t)slice * PK_SLICE_ENTRIES;
-    // the 32 workgroups of an XCD copy the same slice at the same time: each starts at a different 16 KiB piece so that
-    // they do not all hit the same L2 lines (one channel) in lock step
-#pragma unroll
-    for (int k = 0; k < PER; ++k) stage[k] = src[tid + ((k + group) % PER) * NT];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int q = tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups - 1;
-      xv[k] = *reinterpret_cast<const u32x4*>(p.x + (size_t)q * 8);
+    const uint8_t* src = p.codebook + (size_t)slice * PK_SLICE_BYTES;
+    for (int i = wave; i < (int)(PK_SLICE_BYTES / 1024); i += NWB)
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + i * 1024 + lane * 16),
+                                       (lds_void_ptr)(size_t)(LDS::SLICE + (uint32_t)i * 1024u), 16, 0, 0);
+    const int nchunk = (p.in_groups + 63) >> 6;  // KiB pieces per row of x
+    for (int c = wave; c < nchunk * B; c += NWB) {
+      const int b = B == 1 ? 0 : c / nchunk, i = c - b * nchunk;
+      const int idx = i * 64 + lane;
+      if (idx < p.in_groups)
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.x + (size_t)b * p.x_row_stride + (size_t)idx * 8),
+                                         (lds_void_ptr)(size_t)(LDS::X + (uint32_t)b * XP + (uint32_t)i * 1024u), 16, 0, 0);
+    }
+    // the stream's row starts (needed by the epilogue only; as an LDS-DMA they are older than the ring loads, see (5)).
+    // Rows of the table are only 4-B aligned -> dword DMA, 256 B per wave-instruction.
+    const uint32_t* rs_src = p.rowstart + (size_t)block * RG1;
+    for (int i = wave; i * 64 < RG1; i += NWB) {
+      const int idx = i * 64 + lane;
+      if (idx < RG1)
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rs_src + idx), (lds_void_ptr)(size_t)(rowstart_off + (uint32_t)i * 256u), 4, 0, 0);
     }
   }
+  // (2) the entry stream of this wave: fixed addresses, PD steps ahead in a register ring with compile-time slots
+  __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
+  const int wv = wave < p.NW ? wave : p.NW - 1;  // waves beyond the stream's wave count (shared-input launches) idle
+  const uint32_t wbase = (uint32_t)(((size_t)block * p.NW + wv) * p.T) * 1024u;
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const int Tm1 = p.T - 1;
+  auto fetch = [&](int t) -> u32x4 {  // unconditional; steps past the end re-read the last step (never consumed)
+    const int tc = t < Tm1 ? t : Tm1;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs_ent, voff, wbase + (uint32_t)tc * 1024u, AUX_NT);
+  };
+  u32x4 ring[PD];
 #pragma unroll
-  for (int k = 0; k < PD; ++k) {  // needs the bounds only: vmcnt leaves the slice / x loads in flight
-    fetch(bst[k], l16, e_q[k]);
-    fetch(bst[k], l16 + LPR, e_q2[k]);
-  }
+  for (int k = 0; k < PD; ++k) ring[k] = fetch(k);
+  // (3) steps of this wave through the scalar cache (not a VMEM op: it must not sit in the vmcnt queue, see (5))
+  const const_u32_ptr wi = (const_u32_ptr)(uintptr_t)(p.winfo + ((size_t)block * p.NW + wv) * 4);
+  const int steps = wave < p.NW ? (int)wi[2] : 0;
+  // (4) LDS that needs no data: the zero vectors the null entries point at
+  if (tid < B) *reinterpret_cast<u32x4*>(smem_raw + LDS::X + (uint32_t)tid * XP + (uint32_t)p.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};
   AQLM_TRACE(1);  // every load of the prologue has been issued
-  // unconditional LDS writes (threads past the end write a dump slot): with the store under a branch hipcc sinks the
-  // x load into the branch and guards it with vmcnt(0), i.e. the whole LDS fill then waits for the entry prefetch
-  // (traced: workgroup barrier 2 us after the first wave had its data)
-#pragma unroll
-  for (int k = 0; k < 2; ++k) xl[tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups + 1] = xv[k];
-  if (tid == 0) xl[p.in_groups] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int k = 0; k < PER; ++k) cbl[tid + ((k + group) % PER) * NT] = stage[k];
-#ifdef AQLM_PACKED_TRACE
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes (hence its slice data) are done
-  AQLM_TRACE(6);
-#endif
-  __syncthreads();
-  AQLM_TRACE(2);  // LDS filled
+  // (5) the slice and x are older in the VMEM queue than the PD ring loads: wait for everything BUT the ring, so the
+  // stream keeps flowing while the loop starts (a __syncthreads() here would emit vmcnt(0) and drain it)
+  // (the builtin, not an asm string: hipcc's wait-count pass must learn that the LDS-DMA ops have retired, or it guards
+  // the first use of the ring with vmcnt(0))
+  __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD) lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  AQLM_TRACE(2);
 
-  uint32_t four = 4u;
-  asm volatile("" : "+v"(four));  // the SDWA shift count must sit in a VGPR
-  auto consume = [&](const u32x4& e, float acc) -> float {
-    acc = packed_entry<T>(e.x, four, acc);
-    acc = packed_entry<T>(e.y, four, acc);
-    acc = packed_entry<T>(e.z, four, acc);
-    acc = packed_entry<T>(e.w, four, acc);
-    return acc;
+  uint32_t mask = 0xfff0u;
+  asm volatile("" : "+v"(mask));  // the SDWA operand must sit in a VGPR
+  float acc[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) acc[b] = 0.f;
+  uint32_t row_addr = 0;  // LDS byte address of rowval[0][current row of this column]
+
+  auto entry = [&](uint32_t w) {
+    const uint32_t a_cb = half_and<0>(w, mask);
+    uint32_t a_x = half_and<1>(w, mask);
+    const u32x4 e = *(lds_u32x4_ptr)(size_t)(a_cb + LDS::SLICE);
+    if constexpr (B == 1) {
+      const u32x4 xv = *(lds_u32x4_ptr)(size_t)(a_x + LDS::X);
+      acc[0] = dot8<T_>(e, xv, acc[0]);
+    } else {
+      a_x += LDS::X;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const u32x4 xv = *(lds_u32x4_ptr)(size_t)(a_x + (uint32_t)b * XP);
+        acc[b] = dot8<T_>(e, xv, acc[b]);
+      }
+    }
+  };
+  auto step = [&](const u32x4& e) {
+    const uint32_t row_ends = e.x & 1u;
+    entry(e.x);
+    entry(e.y);
+    entry(e.z);
+    entry(e.w);
+    if (row_ends) {  // a row ends here: exactly one lane-step per row does, so the store has a unique writer
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        lds_store_f32(row_addr + (uint32_t)(b * RG1) * 4u, acc[b]);
+        acc[b] = 0.f;
+      }
+      row_addr += 4u;
+    }
   };
 
-  int r = r0;
-  while (__any(r < nrows)) {
-#pragma unroll
-    for (int s6 = 0; s6 < NB2; ++s6) {  // no early exit: a single back-edge keeps every in-flight load in place
-      const int es = s6 % PD;
-      const uint32_t st = bst[s6], en = ben[s6];
-      const uint32_t out_row = brow[s6];
-      const u32x4 e1 = e_q[es], e2 = e_q2[es];
-      // refill: entries of row r + PD*STRIDE (its bounds sit PD slots further in the ring), bounds of row r + 2*PD*STRIDE
-      fetch(bst[(s6 + PD) % NB2], l16, e_q[es]);
-      fetch(bst[(s6 + PD) % NB2], l16 + LPR, e_q2[es]);
-      bounds(r + NB2 * STRIDE, bst[s6], ben[s6], brow[s6]);
-
-      const int nchunks = (int)((en - st) >> 2);
-      float acc = 0.f;
-      if (l16 < nchunks) acc = consume(e1, acc);
-      if (l16 + LPR < nchunks) acc = consume(e2, acc);
-      for (int c = l16 + 2 * LPR; __any(c < nchunks); c += LPR) {  // buckets longer than 128 entries (rare): blocking loads
-        u32x4 e3;
-        fetch(st, c, e3);
-        if (c < nchunks) acc = consume(e3, acc);
-      }
-      // reduction over the row's lanes on the VALU (DPP / readlane): no LDS traffic
-      if constexpr (LPR == 16) acc = row16_sum(acc);
-      else if constexpr (LPR == 8) acc = oct_sum(acc);
-      else acc = quad_sum(acc);
-      if (l16 == 0 && r < nrows) p.partial[(size_t)slice * p.M + row_begin + out_row] = acc;  // positions < nrows are the valid rows
-#ifdef AQLM_PACKED_TRACE
-      if (r == r0) AQLM_TRACE(3);  // first row done: the rowoff -> entries chain has arrived
-      if (p.trace && tid == 0 && r >= r0 && s6 < 6 && r < r0 + 6 * STRIDE) p.trace[256 * 8 + (size_t)block * 8 + s6] = wall_clock64();
-#endif
-      r += STRIDE;
+  if (steps > 0) {
+    {  // the column's starting row rides in the spare bits of its first lane-step
+      const uint32_t e0 = ring[0].x, e1 = ring[0].y;
+      const uint32_t f = ((e0 >> 1) & 7u) | (((e0 >> 16) & 15u) << 3) | ((e1 & 15u) << 7) | (((e1 >> 16) & 15u) << 11);
+      row_addr = rowval_off + f * 4u;
     }
+    int t = 0;
+    for (; t + PD <= steps; t += PD) {
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {  // single back-edge, static ring slots: no in-flight register is ever copied
+        step(ring[k]);                 // the slot's words are dead once their addresses are formed ...
+        ring[k] = fetch(t + PD + k);   // ... so the refill lands in the same registers (no copy at the back-edge)
+      }
+    }
+    const int rem = steps - t;
+#pragma unroll
+    for (int k = 0; k < PD - 1; ++k)
+      if (k < rem) step(ring[k]);
+  }
+  // what the column gathered after its last row end belongs to a row that continues in the next column (0 otherwise)
+  if (wave < p.NW) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) lds_store_f32(colend_off + (uint32_t)((b * PK_MAX_NW + wave) * 64 + lane) * 4u, acc[b]);
   }
   AQLM_TRACE(4);
-#ifdef AQLM_PACKED_TRACE
+  asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");  // the asm LDS stores above are invisible to the compiler's counters
   __syncthreads();
-  unsigned long long* wdone = reinterpret_cast<unsigned long long*>(smem_raw);  // the codebook slice is dead by now
-  if (lane == 0) { wdone[wave] = tr[4]; wdone[NWAVES + wave] = tr[0]; wdone[2 * NWAVES + wave] = tr[6]; }
-  __syncthreads();
-  tr[5] = wall_clock64();
-  if (tid == 0 && p.trace) {
-    for (int i = 0; i < 6; ++i) p.trace[(size_t)block * 8 + i] = tr[i];
-    unsigned long long mx = 0, me = 0, ms = 0;
-    for (int w = 0; w < NWAVES; ++w) {
-      mx = wdone[w] > mx ? wdone[w] : mx;
-      me = wdone[NWAVES + w] > me ? wdone[NWAVES + w] : me;
-      ms = wdone[2 * NWAVES + w] > ms ? wdone[2 * NWAVES + w] : ms;
+  AQLM_TRACE(5);
+  // ---- epilogue: row r = rowval[r] + the column remainders of the columns it crosses, in column order -------------
+  {
+    const uint32_t* rs = reinterpret_cast<const uint32_t*>(smem_raw + rowstart_off);
+    const float* rowval = reinterpret_cast<const float*>(smem_raw + rowval_off);
+    const float* colend = reinterpret_cast<const float*>(smem_raw + colend_off);
+    const uint32_t T = (uint32_t)p.T;
+    for (int r = tid; r < nrows; r += NT) {
+      const uint32_t q0 = rs[r], q1 = rs[r + 1];
+      const uint32_t c0 = q0 / T, c1 = (q1 - 1u) / T;  // first / last column the row touches (column = wave * 64 + lane)
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float v = rowval[b * RG1 + r];
+        for (uint32_t c = c0; c < c1; ++c) v += colend[(size_t)b * PK_MAX_NW * 64 + c];
+        p.partial[((size_t)slice * B + b) * p.M + row_begin + r] = v;
+      }
     }
-    p.trace[(size_t)block * 8 + 5] = me;  // last wave of the workgroup to START
-    p.trace[(size_t)block * 8 + 6] = ms;  // last wave to have its share of the slice in LDS
-    p.trace[(size_t)block * 8 + 7] = mx;  // last wave to leave the loop
+  }
+#ifdef AQLM_PACKED_TRACE
+  AQLM_TRACE(6);
+  if (p.trace && lane == 0) {
+    unsigned long long* o = p.trace + ((size_t)block * PK_MAX_NW + wave) * 8;
+    for (int i = 0; i < 7; ++i) o[i] = tr[i];
   }
 #endif
-  // (An in-kernel finalize -- last-arriving slice workgroup of a row-group adds the eight partials -- was measured:
-  // with __threadfence() it costs +80 us (the agent-scope buffer_inv throws away the L2 lines every other workgroup of
-  // the XCD is streaming through); with write-through sc1 stores / sc1 loads and no fence it is correct but exactly as
-  // slow as the separate finalize launch, +-0.3 us on every shape.  Hence the plain two-kernel form.)
 }
 
-template <class T, int NWAVES, int PD, int LPR = 16>
-__global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
-  gemv_1x16_packed_body<T, NWAVES, PD, LPR>(p, blockIdx.x);
+template <class T_, int B, int PD, uint32_t XWIN>
+__global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
+  gemv_1x16_packed_body<T_, B, PD, XWIN>(p, blockIdx.x);
 }
 
-// Several prepacked layers that multiply the same x (gate/up) in one launch of 256 workgroups per layer; the second
-// layer's workgroups start as CUs free up, so the first layer's tail and the second's LDS fill overlap.
+// Several prepacked layers that multiply the same x (q/k/v, gate/up) in one launch of 256 workgroups per layer; the
+// next layer's workgroups start as CUs free up, so one layer's tail and the next one's LDS fill overlap.
 struct PackedSegment {
-  const uint32_t* rowoff;
-  const uint16_t* rowperm;
   const uint32_t* ent;
+  const uint32_t* winfo;
+  const uint32_t* rowstart;
   const uint8_t* codebook;
   float* partial;
-  int M, RG;
+  int M, RG, NW, T;
   uint32_t ent_bytes;
 };
 
 struct PackedMultiParams {
   const uint16_t* x;
+  long x_row_stride;
   int in_groups, nseg;
   PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
-template <class T, int NWAVES, int PD, int LPR = 16>
-__global__ __launch_bounds__(NWAVES * 64) void gemv_1x16_packed_multi_kernel(const PackedMultiParams mp) {
+template <class T_, int B, int PD, uint32_t XWIN>
+__global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const PackedMultiParams mp) {
   const int sidx = (int)blockIdx.x >> 8;
   PackedGemvParams p{};
   p.x = mp.x;
+  p.x_row_stride = mp.x_row_stride;
   p.in_groups = mp.in_groups;
 #pragma unroll
   for (int k = 0; k < AQLM_HIP_MAX_SEGMENTS; ++k) {
     if (k == 0 || sidx == k) {  // scalar select chain (no dynamic indexing of the kernel-argument struct)
-      p.rowoff = mp.seg[k].rowoff;
-      p.rowperm = mp.seg[k].rowperm;
       p.ent = mp.seg[k].ent;
+      p.winfo = mp.seg[k].winfo;
+      p.rowstart = mp.seg[k].rowstart;
       p.codebook = mp.seg[k].codebook;
       p.partial = mp.seg[k].partial;
       p.M = mp.seg[k].M;
       p.RG = mp.seg[k].RG;
+      p.NW = mp.seg[k].NW;
+      p.T = mp.seg[k].T;
       p.ent_bytes = mp.seg[k].ent_bytes;
     }
   }
-  gemv_1x16_packed_body<T, NWAVES, PD, LPR>(p, (int)blockIdx.x & 255);
+  gemv_1x16_packed_body<T_, B, PD, XWIN>(p, (int)blockIdx.x & 255);
 }
 
 struct PackedFinalizeParams {
-  const float* partial;
+  const float* partial;  // [S][B][M]
   const uint16_t* scales;
   const uint16_t* bias;
   uint16_t* y;
-  int M;
+  long y_row_stride;
+  int M, B;
 };
 
-template <class T>
-__global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const PackedFinalizeParams p) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
+template <class T_>
+__device__ __forceinline__ void packed_finalize_row(const PackedFinalizeParams& p, int row) {
   if (row >= p.M) return;
-  float s = 0.f;
+  const float scale = T_::to_float(p.scales[row]);
+  const float bias = p.bias ? T_::to_float(p.bias[row]) : 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < PK_S; ++k) s += p.partial[(size_t)k * p.M + row];
-  const float scale = T::to_float(p.scales[row]);
-  const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
+    for (int k = 0; k < PK_S; ++k) s += p.partial[((size_t)k * p.B + b) * p.M + row];
+    p.y[(size_t)b * p.y_row_stride + row] = T_::from_float(__builtin_fmaf(s, scale, bias));
+  }
+}
+
+template <class T_>
+__global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const PackedFinalizeParams p) {
+  packed_finalize_row<T_>(p, blockIdx.x * 256 + threadIdx.x);
 }
 
 struct PackedFinalizeSegment {
@@ -607,7 +695,7 @@ struct PackedFinalizeMultiParams {
   PackedFinalizeSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
-template <class T>
+template <class T_>
 __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const PackedFinalizeMultiParams mp) {
   PackedFinalizeParams p = mp.seg[0].f;
   int begin = 0;
@@ -618,14 +706,68 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const Pac
       begin = mp.seg[k].block_begin;
     }
   }
-  const int row = ((int)blockIdx.x - begin) * 256 + threadIdx.x;
-  if (row >= p.M) return;
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < PK_S; ++k) s += p.partial[(size_t)k * p.M + row];
-  const float scale = T::to_float(p.scales[row]);
-  const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-  p.y[row] = T::from_float(__builtin_fmaf(s, scale, bias));
+  packed_finalize_row<T_>(p, ((int)blockIdx.x - begin) * 256 + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------- host launch helpers
+static int pick_pd(const PackedLayout& L) {
+  const int t = tuning().packed_prefetch;
+  if (t == 4 || t == 8) return t;
+  return (L.NW >= 16 || L.T < 8) ? 4 : 8;
+}
+
+template <class KP, class Launch>
+static int dispatch_packed(int dtype, int batch, int pd, Launch&& launch) {
+  // launch(kernel, lds_bytes_fn): instantiations are (dtype, B, PD); XWIN is the full window for now
+#define AQLM_PK_CASE(BB)                                                                                               \
+  case BB:                                                                                                             \
+    if (dtype == AQLM_HIP_F16)                                                                                         \
+      return pd == 8 ? launch(KP::template get<F16, BB, 8>(), PackedLds<BB, PK_XWIN_FULL>{})                           \
+                     : launch(KP::template get<F16, BB, 4>(), PackedLds<BB, PK_XWIN_FULL>{});                          \
+    return pd == 8 ? launch(KP::template get<BF16, BB, 8>(), PackedLds<BB, PK_XWIN_FULL>{})                            \
+                   : launch(KP::template get<BF16, BB, 4>(), PackedLds<BB, PK_XWIN_FULL>{});
+  switch (batch) {
+    AQLM_PK_CASE(1)
+    AQLM_PK_CASE(2)
+    AQLM_PK_CASE(3)
+    AQLM_PK_CASE(4)
+    AQLM_PK_CASE(5)
+    AQLM_PK_CASE(6)
+    AQLM_PK_CASE(7)
+    AQLM_PK_CASE(8)
+  }
+#undef AQLM_PK_CASE
+  return AQLM_HIP_E_INVALID;
+}
+
+struct SingleKernels {
+  template <class T_, int B, int PD>
+  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL>; }
+};
+struct MultiKernels {
+  template <class T_, int B, int PD>
+  static auto get() { return gemv_1x16_packed_multi_kernel<T_, B, PD, PK_XWIN_FULL>; }
+};
+
+// largest batch whose LDS image fits the CU
+template <int BB>
+static size_t packed_lds_total(int in_groups, int RG) { return PackedLds<BB, PK_XWIN_FULL>::total(in_groups, RG); }
+static size_t packed_lds_need(int b, int in_groups, int RG) {
+  switch (b) {
+    case 1: return packed_lds_total<1>(in_groups, RG);
+    case 2: return packed_lds_total<2>(in_groups, RG);
+    case 3: return packed_lds_total<3>(in_groups, RG);
+    case 4: return packed_lds_total<4>(in_groups, RG);
+    case 5: return packed_lds_total<5>(in_groups, RG);
+    case 6: return packed_lds_total<6>(in_groups, RG);
+    case 7: return packed_lds_total<7>(in_groups, RG);
+    default: return packed_lds_total<8>(in_groups, RG);
+  }
+}
+static int packed_max_batch(int in_groups, int RG) {
+  int b = AQLM_HIP_MAX_GEMV_BATCH;
+  while (b > 1 && packed_lds_need(b, in_groups, RG) > 160 * 1024) --b;
+  return packed_lds_need(b, in_groups, RG) <= 160 * 1024 ? b : 0;
 }
 
 }  // namespace aqlm
@@ -633,58 +775,122 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const Pac
 using namespace aqlm;
 
 extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size) {
-  PackedLayout L;
-  return packed_layout(out_features, in_features, in_group_size, L) ? L.total : 0;
+  if (!packed_shape_ok(out_features, in_features, in_group_size)) return 0;
+  // capacity for codes that use the slices up to 25 % unevenly, plus the scratch of the repack (row starts);
+  // the bytes actually used come back in the descriptor and the buffer may be trimmed to them
+  const size_t nst = (size_t)PK_NG * PK_S;
+  const size_t RG = (size_t)(out_features + PK_NG - 1) / PK_NG;
+  const size_t in_groups = (size_t)in_features / 8;
+  const size_t lane_steps = RG * in_groups / (4 * PK_S) * 5 / 4 + RG + 64;   // per stream
+  const size_t ent = nst * (lane_steps * 16 + 16 * 1024);
+  const size_t meta = 2048 + nst * PK_MAX_NW * 16 + nst * (RG + 1) * 4;
+  return align_up(meta + ent, 1024);
 }
 
 extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
-                                     void* packed, size_t packed_bytes, void* stream_) {
+                                     void* packed, size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PackedLayout L;
-  if (!codes || !packed) {
+  if (!codes || !packed || !desc) {
     set_last_error("aqlm_hip_prepack_1x16: null pointer argument");
     return AQLM_HIP_E_INVALID;
   }
-  if (!packed_layout(out_features, in_features, in_group_size, L)) {
-    set_last_error("aqlm_hip_prepack_1x16: unsupported shape (needs g=8, in %% 64 == 0, in <= 16320; got g=%d in=%d)",
-                   in_group_size, in_features);
+  if (!packed_shape_ok(out_features, in_features, in_group_size)) {
+    set_last_error("aqlm_hip_prepack_1x16: unsupported shape (needs g=8, in/8 <= %d; got g=%d in=%d out=%d)", PK_MAX_GROUPS,
+                   in_group_size, in_features, out_features);
     return AQLM_HIP_E_UNSUPPORTED;
   }
-  if (packed_bytes < L.total || !aligned16(packed)) {
-    set_last_error("aqlm_hip_prepack_1x16: packed buffer needs %zu bytes (16-B aligned), got %zu", L.total, packed_bytes);
+  const size_t cap = aqlm_hip_prepack_1x16_bytes(out_features, in_features, in_group_size);
+  if (packed_bytes < cap || !aligned16(packed)) {
+    set_last_error("aqlm_hip_prepack_1x16: packed buffer needs %zu bytes (16-B aligned), got %zu", cap, packed_bytes);
     return AQLM_HIP_E_INVALID;
   }
+  const int M = out_features, in_groups = in_features / 8;
+  const int RG = (M + PK_NG - 1) / PK_NG;
+  const size_t nst = (size_t)PK_NG * PK_S;
   uint8_t* base = (uint8_t*)packed;
-  // header (informational; the kernels take the layout from the shapes)
-  const uint32_t hdr[16] = {0x31505141u, 4u, (uint32_t)L.M, (uint32_t)L.in_groups, 8u, (uint32_t)PK_S, (uint32_t)PK_NG,
-                            (uint32_t)L.RG, (uint32_t)L.entries, (uint32_t)L.off_rowoff, (uint32_t)L.off_ent,
-                            (uint32_t)L.off_perm, (uint32_t)(L.total & 0xffffffffu), (uint32_t)(L.total >> 32), 0u, 0u};
-  if (int e = check_hip(hipMemsetAsync(base, 0, L.off_ent, stream), "prepack memset")) return e;
-  if (int e = check_hip(hipMemcpyAsync(base, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream), "prepack header")) return e;
-  if (int e = check_hip(hipStreamSynchronize(stream), "prepack header sync")) return e;  // hdr is on the stack
-  uint32_t* rowoff = (uint32_t*)(base + L.off_rowoff);
-  uint16_t* perm = (uint16_t*)(base + L.off_perm);
+  // the row starts are built in place (their offset does not depend on the wave count chosen later); the max stream
+  // length is read back from the header area
+  PackedLayout L0;
+  packed_layout(M, in_features, 1, 1, L0);
+  uint32_t* a = (uint32_t*)(base + L0.off_rowstart);
+  uint32_t* maxL_d = (uint32_t*)(base + 128);
+  if (int e = check_hip(hipMemsetAsync(base, 0, L0.off_ent, stream), "prepack memset")) return e;
+  const int row_blocks = (M + 3) / 4;
+  hipLaunchKernelGGL(pk_count_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, M, in_groups, RG);
+  hipLaunchKernelGGL(pk_scan_kernel, dim3((unsigned)nst), dim3(256), 0, stream, a, maxL_d, RG);
+  uint32_t maxL = 0;
+  if (int e = check_hip(hipMemcpyAsync(&maxL, maxL_d, 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
+  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
+  const int NW = choose_waves(maxL);
+  const int T = (int)((maxL + 64u * NW - 1) / (64u * NW));
+  PackedLayout L;
+  if (!packed_layout(M, in_features, NW, T, L) || L.used > packed_bytes) {
+    set_last_error("aqlm_hip_prepack_1x16: codes too unevenly spread over the codebook slices for the packed format "
+                   "(longest stream %u lane-steps, %d steps per wave)", maxL, T);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  uint32_t* winfo = (uint32_t*)(base + L.off_winfo);
   uint32_t* ent = (uint32_t*)(base + L.off_ent);
-  if (int e = check_hip(hipMemsetAsync(ent, 0, L.total - L.off_ent, stream), "prepack memset entries")) return e;
-  const int blocks = (L.M + 3) / 4;
-  hipLaunchKernelGGL(prepack_count_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, L.M,
-                     L.in_groups, L.RG);
-  hipLaunchKernelGGL(prepack_sort_kernel, dim3(PK_NG * PK_S), dim3(1024), 0, stream, rowoff, perm, L.RG);
-  hipLaunchKernelGGL(prepack_scan_kernel, dim3(1), dim3(1024), 0, stream, rowoff, L.n_rowoff);
-  hipLaunchKernelGGL(prepack_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint16_t*)codes, rowoff, perm, ent,
-                     L.M, L.in_groups, L.RG);
-  hipLaunchKernelGGL(prepack_arrange_kernel, dim3((L.M + 1) / 2), dim3(128), 0, stream, rowoff, perm, ent, L.M, L.in_groups,
-                     L.RG);
-  hipLaunchKernelGGL(prepack_level_kernel, dim3((L.RG / 2 + 63) / 64, PK_NG * PK_S), dim3(64), 0, stream, rowoff, ent, L.RG);
-  hipLaunchKernelGGL(prepack_invert_kernel, dim3(PK_NG * PK_S), dim3(1024), 0, stream, perm, L.RG);
-  return check_hip(hipGetLastError(), "prepack launch");
+  aqlm_hip_packed_desc d{};
+  d.magic = PK_MAGIC;
+  d.version = 5;
+  d.out_features = M;
+  d.in_features = in_features;
+  d.slices_log2 = PK_S_LOG;
+  d.waves = NW;
+  d.steps = T;
+  d.entry_bytes = 4;
+  d.used_bytes = L.used;
+  if (int e = check_hip(hipMemcpyAsync(base, &d, sizeof(d), hipMemcpyHostToDevice, stream), "prepack header")) return e;
+  const uint32_t null_entry = (uint32_t)in_groups << 20;
+  hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L.ent_bytes / 4, null_entry);
+  hipLaunchKernelGGL(pk_scatter_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, ent, M, in_groups, RG, NW, T);
+  if (tuning().packed_arrange && T <= PK_ARR_MAX_T)
+    hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 128 + 64, stream, a,
+                       ent, M, in_groups, RG, NW, T);
+  hipLaunchKernelGGL(pk_flag_kernel, dim3((RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, M, RG, NW, T);
+  hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, M, RG, NW, T);
+  if (int e = check_hip(hipGetLastError(), "prepack launch")) return e;
+  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;  // `d` is on the stack
+  *desc = d;
+  return 0;
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codebook, const void* scales, const void* bias,
-                                         const void* x, void* y, int out_features, int in_features, int in_group_size,
-                                         int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int aqlm_hip_packed_desc_read(const void* header_host, size_t header_bytes, aqlm_hip_packed_desc* desc) {
+  if (!header_host || !desc || header_bytes < sizeof(aqlm_hip_packed_desc)) {
+    set_last_error("aqlm_hip_packed_desc_read: need the first %zu bytes of the packed buffer", sizeof(aqlm_hip_packed_desc));
+    return AQLM_HIP_E_INVALID;
+  }
+  aqlm_hip_packed_desc d;
+  memcpy(&d, header_host, sizeof(d));
+  PackedLayout L;
+  if (!desc_layout(&d, L)) {
+    set_last_error("aqlm_hip_packed_desc_read: not a packed 1x16 buffer of format v5");
+    return AQLM_HIP_E_INVALID;
+  }
+  *desc = d;
+  return 0;
+}
+
+extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, void* codes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!packed || !codebook || !scales || !x || !y) {
+  PackedLayout L;
+  if (!packed || !codes || !desc_layout(desc, L)) {
+    set_last_error("aqlm_hip_unpack_1x16: null pointer or invalid descriptor");
+    return AQLM_HIP_E_INVALID;
+  }
+  const uint8_t* base = (const uint8_t*)packed;
+  hipLaunchKernelGGL(pk_unpack_kernel, dim3((unsigned)L.nst, L.NW), dim3(64), 0, stream, (const uint32_t*)(base + L.off_ent),
+                     (const uint32_t*)(base + L.off_winfo), (uint16_t*)codes, L.M, L.in_groups, L.RG, L.NW, L.T);
+  return check_hip(hipGetLastError(), "unpack launch");
+}
+
+extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+                                         const void* scales, const void* bias, const void* x, void* y, int batch,
+                                         long x_row_stride, long y_row_stride, int dtype, void* workspace,
+                                         size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!packed || !codebook || !scales || !x || !y || !desc) {
     set_last_error("aqlm_hip_gemv_1x16_packed: null pointer argument");
     return AQLM_HIP_E_INVALID;
   }
@@ -693,70 +899,78 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codeboo
     return AQLM_HIP_E_UNSUPPORTED;
   }
   PackedLayout L;
-  if (!packed_layout(out_features, in_features, in_group_size, L) || !aligned16(packed) || !aligned16(codebook) ||
-      !aligned16(x)) {
-    set_last_error("aqlm_hip_gemv_1x16_packed: unsupported shape or misaligned buffer (g=%d in=%d)", in_group_size,
-                   in_features);
-    return AQLM_HIP_E_UNSUPPORTED;
-  }
-  const size_t need = (size_t)PK_S * out_features * sizeof(float);
-  if (!workspace || workspace_bytes < need) {
-    set_last_error("aqlm_hip_gemv_1x16_packed: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+  if (!desc_layout(desc, L)) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: invalid packed descriptor");
     return AQLM_HIP_E_INVALID;
   }
+  if (batch < 1 || batch > AQLM_HIP_MAX_GEMV_BATCH || !aligned16(packed) || !aligned16(codebook) || !aligned16(x) ||
+      (batch > 1 && x_row_stride % 8 != 0)) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: batch must be 1..%d and packed / codebook / x rows 16-B aligned (batch %d)",
+                   AQLM_HIP_MAX_GEMV_BATCH, batch);
+    return AQLM_HIP_E_INVALID;
+  }
+  const int max_b = packed_max_batch(L.in_groups, L.RG);
+  if (max_b == 0) {
+    set_last_error("aqlm_hip_gemv_1x16_packed: layer does not fit the LDS image (in_features %d)", desc->in_features);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
   const uint8_t* base = (const uint8_t*)packed;
-  PackedGemvParams p{};
-  p.rowoff = (const uint32_t*)(base + L.off_rowoff);
-  p.rowperm = (const uint16_t*)(base + L.off_perm);
-  p.ent = (const uint32_t*)(base + L.off_ent);
-  p.codebook = (const uint8_t*)codebook;
-  p.x = (const uint16_t*)x;
-  p.partial = (float*)workspace;
-  p.M = L.M;
-  p.in_groups = L.in_groups;
-  p.RG = L.RG;
-  p.ent_bytes = (uint32_t)((L.entries + PK_PAD) * 4);
+  const int pd = pick_pd(L);
+  for (int b0 = 0; b0 < batch; b0 += max_b) {  // rows that do not fit one LDS image go in several launches
+    const int nb = std::min(max_b, batch - b0);
+    const size_t need = (size_t)PK_S * nb * L.M * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+      set_last_error("aqlm_hip_gemv_1x16_packed: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+      return AQLM_HIP_E_INVALID;
+    }
+    PackedGemvParams p{};
+    p.ent = (const uint32_t*)(base + L.off_ent);
+    p.winfo = (const uint32_t*)(base + L.off_winfo);
+    p.rowstart = (const uint32_t*)(base + L.off_rowstart);
+    p.codebook = (const uint8_t*)codebook;
+    p.x = (const uint16_t*)x + (size_t)b0 * x_row_stride;
+    p.partial = (float*)workspace;
+    p.x_row_stride = x_row_stride;
+    p.M = L.M;
+    p.in_groups = L.in_groups;
+    p.RG = L.RG;
+    p.NW = L.NW;
+    p.T = L.T;
+    p.ent_bytes = (uint32_t)L.ent_bytes;
 #ifdef AQLM_PACKED_TRACE
-  p.trace = workspace_bytes >= need + 2 * 256 * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+    p.trace = workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
 #endif
-  const size_t lds = (size_t)(PK_SLICE_ENTRIES + L.in_groups + 2) * 16;  // slice, x, zero slot, dump slot
-  constexpr int NW = 16;
-  auto launch = [&](auto kern) -> int {
-    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, stream, p);
-    return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
-  };
-  // rows per quarter-wave <= 2 (<= 4096-row layers): a shorter ring, so that the unrolled pipeline has fewer idle steps
-  const bool short_rows = L.RG <= 2 * NW * 4;
-  int e;
-  if (L.in_groups <= 128)  // ~16 entries per bucket: 4 lanes per row
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3, 4>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3, 4>);
-  else if (L.in_groups <= 256)  // ~32 entries per bucket: 8 lanes per row
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3, 8>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3, 8>);
-  else if (short_rows)
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 2>) : launch(gemv_1x16_packed_kernel<BF16, NW, 2>);
-  else
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_kernel<F16, NW, 3>) : launch(gemv_1x16_packed_kernel<BF16, NW, 3>);
-  if (e) return e;
-  PackedFinalizeParams f{};
-  f.partial = (const float*)workspace;
-  f.scales = (const uint16_t*)scales;
-  f.bias = (const uint16_t*)bias;
-  f.y = (uint16_t*)y;
-  f.M = out_features;
-  if (dtype == AQLM_HIP_F16)
-    hipLaunchKernelGGL(gemv_1x16_packed_finalize<F16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
-  else
-    hipLaunchKernelGGL(gemv_1x16_packed_finalize<BF16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
-  return check_hip(hipGetLastError(), "gemv_1x16_packed_finalize launch");
+    auto launch = [&](auto kern, auto lds_map) -> int {
+      const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG);
+      if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+      hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p);
+      return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
+    };
+    if (int e = dispatch_packed<SingleKernels>(dtype, nb, pd, launch)) return e;
+    PackedFinalizeParams f{};
+    f.partial = (const float*)workspace;
+    f.scales = (const uint16_t*)scales;
+    f.bias = (const uint16_t*)bias;
+    f.y = (uint16_t*)y + (size_t)b0 * y_row_stride;
+    f.y_row_stride = y_row_stride;
+    f.M = L.M;
+    f.B = nb;
+    if (dtype == AQLM_HIP_F16)
+      hipLaunchKernelGGL(gemv_1x16_packed_finalize<F16>, dim3((L.M + 255) / 256), dim3(256), 0, stream, f);
+    else
+      hipLaunchKernelGGL(gemv_1x16_packed_finalize<BF16>, dim3((L.M + 255) / 256), dim3(256), 0, stream, f);
+    if (int e = check_hip(hipGetLastError(), "gemv_1x16_packed_finalize launch")) return e;
+  }
+  return 0;
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
-                                               int in_features, int in_group_size, int dtype, void* workspace,
-                                               size_t workspace_bytes, void* stream_) {
+extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+                                               int num_segments, const void* x, int in_features, int batch,
+                                               long x_row_stride, int dtype, void* workspace, size_t workspace_bytes,
+                                               void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!segments || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS || !x) {
-    set_last_error("aqlm_hip_gemv_1x16_packed_multi: 1..%d segments and a non-null x required (got %d)",
+  if (!segments || !descs || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS || !x) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi: 1..%d segments, their descriptors and a non-null x required (got %d)",
                    AQLM_HIP_MAX_SEGMENTS, num_segments);
     return AQLM_HIP_E_INVALID;
   }
@@ -765,12 +979,18 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
                    dtype);
     return AQLM_HIP_E_UNSUPPORTED;
   }
+  if (batch < 1 || batch > AQLM_HIP_MAX_GEMV_BATCH || !aligned16(x) || (batch > 1 && x_row_stride % 8 != 0)) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi: batch must be 1..%d with 16-B aligned rows (batch %d)",
+                   AQLM_HIP_MAX_GEMV_BATCH, batch);
+    return AQLM_HIP_E_INVALID;
+  }
   PackedMultiParams mp{};
   PackedFinalizeMultiParams fm{};
   mp.x = (const uint16_t*)x;
+  mp.x_row_stride = x_row_stride;
   mp.nseg = fm.nseg = num_segments;
   size_t need = 0;
-  int fblocks = 0;
+  int fblocks = 0, max_rg = 0, nw = 0, pd = 4;
   for (int k = 0; k < num_segments; ++k) {
     const aqlm_hip_segment& sg = segments[k];
     if (!sg.codes || !sg.codebook || !sg.scales || !sg.y) {
@@ -778,55 +998,55 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
       return AQLM_HIP_E_INVALID;
     }
     PackedLayout L;
-    if (!packed_layout(sg.out_features, in_features, in_group_size, L) || !aligned16(sg.codes) ||
-        !aligned16(sg.codebook) || !aligned16(x)) {
-      set_last_error("aqlm_hip_gemv_1x16_packed_multi: unsupported shape or misaligned buffer (segment %d, g=%d in=%d)",
-                     k, in_group_size, in_features);
-      return AQLM_HIP_E_UNSUPPORTED;
+    if (!desc_layout(descs[k], L) || descs[k]->in_features != in_features || descs[k]->out_features != sg.out_features ||
+        !aligned16(sg.codes) || !aligned16(sg.codebook)) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi: segment %d: invalid descriptor, or it does not match in_features "
+                     "%d / out_features %d", k, in_features, sg.out_features);
+      return AQLM_HIP_E_INVALID;
     }
     const uint8_t* base = (const uint8_t*)sg.codes;
     PackedSegment& ps = mp.seg[k];
-    ps.rowoff = (const uint32_t*)(base + L.off_rowoff);
-    ps.rowperm = (const uint16_t*)(base + L.off_perm);
     ps.ent = (const uint32_t*)(base + L.off_ent);
+    ps.winfo = (const uint32_t*)(base + L.off_winfo);
+    ps.rowstart = (const uint32_t*)(base + L.off_rowstart);
     ps.codebook = (const uint8_t*)sg.codebook;
     ps.partial = (float*)((uint8_t*)workspace + need);
     ps.M = L.M;
     ps.RG = L.RG;
-    ps.ent_bytes = (uint32_t)((L.entries + PK_PAD) * 4);
+    ps.NW = L.NW;
+    ps.T = L.T;
+    ps.ent_bytes = (uint32_t)L.ent_bytes;
     mp.in_groups = L.in_groups;
+    max_rg = std::max(max_rg, L.RG);
+    nw = std::max(nw, L.NW);
+    pd = std::max(pd, pick_pd(L));
     PackedFinalizeSegment& fs = fm.seg[k];
     fs.f.partial = ps.partial;
     fs.f.scales = (const uint16_t*)sg.scales;
     fs.f.bias = (const uint16_t*)sg.bias;
     fs.f.y = (uint16_t*)sg.y;
+    fs.f.y_row_stride = sg.y_row_stride;
     fs.f.M = sg.out_features;
+    fs.f.B = batch;
     fs.block_begin = fblocks;
     fblocks += (sg.out_features + 255) / 256;
-    need += (size_t)PK_S * sg.out_features * sizeof(float);
+    need += (size_t)PK_S * batch * sg.out_features * sizeof(float);
   }
   if (!workspace || workspace_bytes < need) {
     set_last_error("aqlm_hip_gemv_1x16_packed_multi: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
   }
-  const size_t lds = (size_t)(PK_SLICE_ENTRIES + mp.in_groups + 2) * 16;  // slice, x, zero slot, dump slot
-  constexpr int NW = 16;
-  auto launch = [&](auto kern) -> int {
+  if (packed_max_batch(mp.in_groups, max_rg) < batch) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi: %d rows of %d features do not fit the LDS image", batch, in_features);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  auto launch = [&](auto kern, auto lds_map) -> int {
+    const size_t lds = decltype(lds_map)::total(mp.in_groups, max_rg);
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(256 * num_segments), dim3(NW * 64), lds, stream, mp);
+    hipLaunchKernelGGL(kern, dim3(256 * num_segments), dim3(nw * 64), lds, stream, mp);
     return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
   };
-  int e;
-  if (mp.in_groups <= 128)  // same lanes-per-row choice as the single-layer launch: results stay bit-identical
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3, 4>)
-                              : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3, 4>);
-  else if (mp.in_groups <= 256)
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3, 8>)
-                              : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3, 8>);
-  else
-    e = dtype == AQLM_HIP_F16 ? launch(gemv_1x16_packed_multi_kernel<F16, NW, 3>)
-                              : launch(gemv_1x16_packed_multi_kernel<BF16, NW, 3>);
-  if (e) return e;
+  if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, launch)) return e;
   if (dtype == AQLM_HIP_F16)
     hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);
   else

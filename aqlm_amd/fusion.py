@@ -8,7 +8,9 @@ The q/k/v projections (and gate/up) of a decoder layer multiply the same hidden 
 ``fuse_shared_input_linears(model)`` groups sibling ``QuantizedLinear`` modules by name; the modules stay in place
 (same parameters, same state_dict), Hugging Face's modeling code keeps calling ``q_proj(x)``, ``k_proj(x)``,
 ``v_proj(x)`` one after the other: the first call launches the whole group and parks the siblings' outputs, the
-following calls on the *same tensor object* pick theirs up.  Outputs are bit-identical to the unfused modules.
+following calls on the *same tensor object* pick theirs up.  Every member runs on the kernel it would use alone
+(prepacked members share one packed launch, the rest one direct launch), so 1x16 / 8x8 outputs are bit-identical to the
+unfused modules.
 """
 from __future__ import annotations
 
@@ -53,8 +55,6 @@ class SharedInputGroup:
             if m.codebooks.dtype != first.codebooks.dtype or m.codebooks.device != first.codebooks.device:
                 raise ValueError("members of a shared-input group must share dtype and device")
         self.members: List[QuantizedLinear] = members
-        # parameter lists, resolved once (re-resolved by _launch if a parameter object was replaced, e.g. by .to())
-        self._codes = self._codebooks = self._scales = self._biases = None
         self._input: Optional[torch.Tensor] = None
         self._version = -1
         self._pending: Dict[int, torch.Tensor] = {}
@@ -89,19 +89,28 @@ class SharedInputGroup:
         for m in ms:
             if m.gemv_op is None or m._derived_state_is_stale():
                 m.prepare_matmul_op(input)
-        if self._codes is None or any(a is not m.codes for a, m in zip(self._codes, ms)):
-            self._codes = [m.codes for m in ms]
-            self._codebooks = [m.codebooks for m in ms]
-            self._scales = [m.scales for m in ms]
-            self._biases = [m.bias for m in ms]
-        if input.numel() == ms[0].in_features and all(getattr(m, "_packed_codes", None) is not None for m in ms):
-            return hip_kernel.code1x16_matmat_packed_multi(
-                input, [m._packed_codes for m in ms], [m.codebooks for m in ms], [m.scales for m in ms],
-                [m.bias for m in ms], [m.out_features for m in ms])
-        # direct call of the op implementations: the group never runs under torch.compile tracing (applicable()), and the
-        # dispatcher costs ~15 us per call for Tensor[] arguments -- as much as the launch itself in eager decode loops
-        op = hip_kernel.code1x16_matmat_multi if ms[0].nbits_per_codebook == 16 else hip_kernel.codekx8_matmat_multi
-        return op(input, self._codes, self._codebooks, self._scales, self._biases)
+        # every member runs on the kernel it would use alone (so outputs stay bit-identical to the unfused modules):
+        # prepacked members share one packed launch, the others one direct launch
+        packed_idx = [i for i, m in enumerate(ms) if m._packed_codes is not None and input.dtype == m.codebooks.dtype]
+        direct_idx = [i for i in range(len(ms)) if i not in packed_idx]
+        outs: List[Optional[torch.Tensor]] = [None] * len(ms)
+        if packed_idx:
+            sub = [ms[i] for i in packed_idx]
+            res = hip_kernel.code1x16_matmat_packed_multi(
+                input, [m._packed_codes for m in sub], [m.codebooks for m in sub], [m.scales for m in sub],
+                [m.bias for m in sub])
+            for i, o in zip(packed_idx, res):
+                outs[i] = o
+        if direct_idx:
+            # direct call of the op implementations: the group never runs under torch.compile tracing (applicable()), and
+            # the dispatcher costs ~15 us per call for Tensor[] arguments -- as much as the launch itself in eager decode
+            op = hip_kernel.code1x16_matmat_multi if ms[0].nbits_per_codebook == 16 else hip_kernel.codekx8_matmat_multi
+            sub = [ms[i] for i in direct_idx]
+            res = op(input, [m._canonical_codes() for m in sub], [m.codebooks for m in sub], [m.scales for m in sub],
+                     [m.bias for m in sub])
+            for i, o in zip(direct_idx, res):
+                outs[i] = o
+        return outs
 
 
 def fuse_shared_input_linears(model: nn.Module,
@@ -130,4 +139,7 @@ def fuse_shared_input_linears(model: nn.Module,
 def unfuse_shared_input_linears(model: nn.Module) -> None:
     for m in model.modules():
         if isinstance(m, QuantizedLinear):
+            g = m._shared_input_group
+            if g is not None:  # drop the parked outputs and the input they keep alive
+                g._pending, g._input = {}, None
             m._shared_input_group = None

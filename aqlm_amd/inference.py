@@ -19,13 +19,12 @@ from .utils import get_int_dtype
 # rows (batch * seq) at or below which the gemv op is used; the reference's value (inference.py:95-96)
 GEMV_MAX_ROWS = 6
 
-# Single-row 1x16 g8 matvecs of layers with at least this many codes (out_features * in_features / 8) run on
-# slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): 1.7-3x faster than the direct L2-gather kernel on
-# MI355X for large layers, at the price of a one-off repack at first use and 2.1x the code bytes kept next to the
-# original codes.  0 disables.  Measured: the packed path has ~7 us more fixed cost per call than the direct kernel and
-# costs ~3.2 ps less per code: 4096x4096 (2.1 M codes) is 4 % faster (11.6 vs 12.1 us in a decode stack; q/k/v in one
-# prepacked launch 28.7 vs 31.4 us), 4096->11008 and 14336->4096 are 1.9x faster; below 2 M codes the direct kernel wins.
-PREPACK_MIN_CODES = 2_000_000
+# 1x16 g8 matvecs (<= GEMV_MAX_ROWS rows) of layers with at least this many codes (out_features * in_features / 8) run on
+# slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): several times faster than the direct L2-gather kernel
+# on MI355X, at the price of a one-off repack at first use and ~2.1x the code bytes (kept next to the original codes
+# unless `drop_canonical_codes()` is called).  0 disables.  Below the threshold the direct kernel's single launch wins
+# (the packed path is two dependent launches).
+PREPACK_MIN_CODES = 1_000_000
 
 
 class QuantizedLinear(nn.Module):
@@ -68,7 +67,9 @@ class QuantizedLinear(nn.Module):
         self.gemm_op = None
         self.use_gemv_rule = None
         self._packed_codes = None  # derived, never saved: rebuilt from `codes` at first use
-        self._packed_version = 0
+        self._packed_fingerprint = None
+        self._codes_dropped = False
+        self._codes_shape = None
         self._prepack_deferred = False
         self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
 
@@ -80,33 +81,82 @@ class QuantizedLinear(nn.Module):
         group = self._shared_input_group
         if group is not None and group.applicable(input):
             return group.forward(self, input)  # one launch for all projections of this input (fusion.py)
-        if self.gemv_op is None or self._derived_state_is_stale():
+        if self.gemv_op is None or (not torch.compiler.is_compiling() and self._derived_state_is_stale()):
             self.prepare_matmul_op(input)
-        if self._packed_codes is not None and input.numel() == self.in_features and not (
-            torch.is_grad_enabled() and input.requires_grad
-        ):
+        packed = self._packed_codes
+        if (packed is not None and input.dtype == self.codebooks.dtype and input.is_cuda
+                and math.prod(input.shape[:-1]) <= GEMV_MAX_ROWS and not (torch.is_grad_enabled() and input.requires_grad)):
             from .inference_kernels import hip_kernel
 
-            return hip_kernel.code1x16_matmat_packed(input, self._packed_codes, self.codebooks, self.scales, self.bias,
-                                                     self.out_features)
+            if torch.compiler.is_compiling():  # traced: go through the dispatcher op (it has a fake implementation)
+                return torch.ops.aqlm.code1x16_matmat_packed(input, packed.buf, self.codebooks, self.scales, self.bias,
+                                                             packed._ints)
+            return hip_kernel.code1x16_matmat_packed(input, packed, self.codebooks, self.scales, self.bias)
         op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
-        return op.apply(input, self.codes, self.codebooks, self.scales, self.bias)
+        return op.apply(input, self._canonical_codes(), self.codebooks, self.scales, self.bias)
+
+    def _codes_fingerprint(self):
+        c = self.codes
+        try:
+            v = c._version
+        except RuntimeError:  # inference tensors carry no version counter
+            v = 0
+        return (id(c), c.data_ptr() if c.numel() else 0, tuple(c.shape), v)
 
     def _derived_state_is_stale(self) -> bool:
         """The prepacked buffer is derived from ``codes``: rebuild it when ``codes`` was written in place
-        (``load_state_dict`` / ``copy_`` after the first forward) or when a repack was postponed during graph capture."""
+        (``load_state_dict`` / ``copy_`` after the first forward), rebound (``module.codes = ...``, accelerate's
+        ``set_module_tensor_to_device``) or when a repack was postponed during graph capture."""
         if self._prepack_deferred:
             return not torch.cuda.is_current_stream_capturing()
-        if self._packed_codes is None:
+        if self._packed_codes is None or self._codes_dropped:
             return False
-        try:
-            return self.codes._version != self._packed_version
-        except RuntimeError:  # inference tensors carry no version counter
+        return self._codes_fingerprint() != self._packed_fingerprint
+
+    def _canonical_codes(self) -> torch.Tensor:
+        """``codes`` in the checkpoint layout; rebuilt from the prepacked buffer (lossless) when they were dropped."""
+        if not self._codes_dropped:
+            return self.codes
+        from .inference_kernels import hip_kernel
+
+        return hip_kernel.unpack_1x16(self._packed_codes)
+
+    def drop_canonical_codes(self) -> bool:
+        """Inference-only memory saver: free ``codes`` of a prepacked layer (the packed buffer holds the same
+        information; ``state_dict()`` and the large-batch / backward ops rebuild them on demand).  Returns whether
+        anything was freed."""
+        if self._packed_codes is None or self._codes_dropped:
             return False
+        self._codes_shape = tuple(self.codes.shape)
+        self.codes = nn.Parameter(torch.empty((0,), dtype=self.codes.dtype, device=self.codes.device), requires_grad=False)
+        self._codes_dropped = True
+        return True
+
+    def restore_canonical_codes(self) -> None:
+        if self._codes_dropped:
+            codes = self._canonical_codes()
+            self._codes_dropped = False
+            self.codes = nn.Parameter(codes, requires_grad=False)
+            self._packed_fingerprint = self._codes_fingerprint()
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._codes_dropped:  # checkpoints always carry the reference layout
+            destination[prefix + "codes"] = self._canonical_codes()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if self._codes_dropped and prefix + "codes" in state_dict:  # new codes arrive: give them a parameter to land in
+            self._codes_dropped = False
+            self._packed_codes = None
+            self.codes = nn.Parameter(torch.empty(self._codes_shape, dtype=self.codes.dtype, device=self.codes.device),
+                                      requires_grad=False)
+            self.gemv_op = None
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
         """``.to()`` / ``.half()`` / ``.cuda()`` replace the parameters: drop everything derived from them (kernel
         choice, prepacked codes); it is rebuilt at the next forward."""
+        self.restore_canonical_codes()  # the derived buffer does not survive a conversion; the codes must
         out = super()._apply(fn, *args, **kwargs)
         self.gemv_op = self.gemm_op = self.use_gemv_rule = None
         self._packed_codes = None
@@ -125,6 +175,8 @@ class QuantizedLinear(nn.Module):
         self.use_gemv_rule = lambda x: math.prod(x.shape[:-1]) <= GEMV_MAX_ROWS
         # load-time re-layout of the codes for the decode kernel (the reference does the analogous thing for its CPU
         # kernel here, inference.py:78-83 -- but in place; we keep `codes` untouched and add a derived buffer)
+        if self._codes_dropped:
+            return  # the packed buffer IS the weights now
         self._packed_codes = None
         self._prepack_deferred = False
         if (PREPACK_MIN_CODES and self.out_features * (self.in_features // 8) >= PREPACK_MIN_CODES and self.num_codebooks == 1
@@ -138,10 +190,7 @@ class QuantizedLinear(nn.Module):
             from .inference_kernels import hip_kernel
 
             self._packed_codes = hip_kernel.prepack_1x16(self.codes, 8)
-            try:
-                self._packed_version = self.codes._version
-            except RuntimeError:
-                self._packed_version = 0
+            self._packed_fingerprint = self._codes_fingerprint()
 
 
 def _get_autograd_matmul_op(forward_pass_kernel, backward_pass_kernel):

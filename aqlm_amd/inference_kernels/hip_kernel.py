@@ -14,6 +14,7 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from types import SimpleNamespace
 from typing import Optional
@@ -106,68 +107,124 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
     return y.reshape(input.shape[:-1] + (out_features,))
 
 
-# out_features at and above which the slice-scan (LDS-resident codebook) kernel replaces the direct L2-gather
-# kernel for a single-row 1x16 g8 matvec; 0 disables it.  Set from measurements.
-LDS_GEMV_MIN_OUT = 0
+# ------------------------------------------------------------------------------------------------------
+# prepacked 1x16 g8 path (format v5): 1..8 input rows per launch on slice-bucketed codes
+# ------------------------------------------------------------------------------------------------------
+class PackedCodes:
+    """A prepacked 1x16 g8 code buffer (``aqlm_hip_prepack_1x16``): device bytes + the host-side descriptor the
+    kernels are launched with.  Derived from ``codes`` (lossless: ``unpack_1x16`` gives them back); never saved."""
+
+    __slots__ = ("buf", "desc", "out_features", "in_features", "_ints")
+
+    def __init__(self, buf: torch.Tensor, desc: "_native.PackedDesc"):
+        self.buf, self.desc = buf, desc
+        self.out_features, self.in_features = int(desc.out_features), int(desc.in_features)
+        self._ints = desc.as_ints()
+
+    def numel(self) -> int:  # bytes held
+        return self.buf.numel()
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    @classmethod
+    def from_buffer(cls, buf: torch.Tensor) -> "PackedCodes":
+        """Re-attach a descriptor to a packed buffer (e.g. one that was saved / moved): it is stored in its first bytes."""
+        head = bytes(buf[:64].cpu().numpy().tobytes())
+        desc = _native.PackedDesc()
+        raw = (ctypes.c_char * len(head)).from_buffer_copy(head)
+        _native.check(_lib.aqlm_hip_packed_desc_read(ctypes.addressof(raw), len(head), ctypes.byref(desc)), "packed_desc_read")
+        return cls(buf, desc)
 
 
-def _gemv_1x16_lds(input, codes, codebooks, scales, bias):
-    """Single-row 1x16 g8 matvec through aqlm_hip_gemv_1x16_lds (codebook slices in LDS + fp32 partial workspace)."""
-    dt = _dtype_id(input)
-    out_features, in_features = codes.shape[0], codes.shape[1] * 8
-    if input.shape[-1] != in_features:
-        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
-    x = _flat_rows(input)
-    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
-    if bias is not None:
-        bias = _c(bias)
-    y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
-    ws = torch.empty((8 * out_features,), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
-        rc = _lib.aqlm_hip_gemv_1x16_lds(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
-                                         x.data_ptr(), y.data_ptr(), out_features, in_features, 8, dt,
-                                         ws.data_ptr(), ws.numel() * 4, _stream_ptr())
-    if rc:
-        _native.check(rc, "aqlm gemv_1x16_lds")
-    return y.reshape(input.shape[:-1] + (out_features,))
-
-
-def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8) -> Optional[torch.Tensor]:
+def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8) -> Optional[PackedCodes]:
     """Repack 1x16 g8 codes [out, in/8, 1] (int16) into the slice-bucketed buffer of aqlm_hip_gemv_1x16_packed.
-    Returns None when the packed path does not cover the shape.  One-off, at load / first use (the counterpart of the
+    Returns None when the packed path does not cover the layer.  One-off, at load / first use (the counterpart of the
     reference's load-time code permutation for its CPU kernel, inference.py:78-83)."""
     out_features, in_features = codes.shape[0], codes.shape[1] * in_group_size
-    nbytes = _lib.aqlm_hip_prepack_1x16_bytes(out_features, in_features, in_group_size)
-    if nbytes == 0:
+    cap = _lib.aqlm_hip_prepack_1x16_bytes(out_features, in_features, in_group_size)
+    if cap == 0:
         return None
     codes = _c(codes)
-    packed = torch.empty((nbytes,), dtype=torch.uint8, device=codes.device)
+    scratch = torch.empty((cap,), dtype=torch.uint8, device=codes.device)
+    desc = _native.PackedDesc()
     with torch.cuda.device(codes.device):
-        rc = _lib.aqlm_hip_prepack_1x16(codes.data_ptr(), out_features, in_features, in_group_size, packed.data_ptr(),
-                                        nbytes, _stream_ptr())
+        rc = _lib.aqlm_hip_prepack_1x16(codes.data_ptr(), out_features, in_features, in_group_size, scratch.data_ptr(),
+                                        cap, ctypes.byref(desc), _stream_ptr(codes.device))
+    if rc == _native.E_UNSUPPORTED:
+        return None  # codes too unevenly spread over the codebook slices: the direct kernel serves this layer
     if rc:
         _native.check(rc, "aqlm prepack_1x16")
-    return packed
+    return PackedCodes(scratch[: int(desc.used_bytes)].clone(), desc)  # keep only the bytes in use
 
 
-def code1x16_matmat_packed(input, packed, codebooks, scales, bias, out_features: int):
-    """Single-row 1x16 g8 matvec on prepacked codes (aqlm_hip_gemv_1x16_packed)."""
+def unpack_1x16(packed: PackedCodes) -> torch.Tensor:
+    """The canonical codes [out, in/8, 1] (int16) of a prepacked buffer (aqlm_hip_unpack_1x16; lossless)."""
+    codes = torch.empty((packed.out_features, packed.in_features // 8, 1), dtype=torch.int16, device=packed.device)
+    with torch.cuda.device(packed.device):
+        rc = _lib.aqlm_hip_unpack_1x16(ctypes.byref(packed.desc), packed.data_ptr(), codes.data_ptr(),
+                                       _stream_ptr(packed.device))
+    if rc:
+        _native.check(rc, "aqlm unpack_1x16")
+    return codes
+
+
+# fp32 partial workspaces, one per (device, stream): a decode loop calls the packed op hundreds of times per token and
+# the allocator round trip is a measurable part of an eager call.  Not used while a hipGraph is being captured (the
+# capture's private pool must own what the graph touches).
+_WORKSPACES = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 20) // 4,), dtype=torch.float32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _check_packed_args(input, packed, codebooks, scales):
     dt = _dtype_id(input)
-    in_features = input.shape[-1]
-    if input.numel() != in_features:
-        raise ValueError("the packed kernel handles exactly one input row")
+    if codebooks.dtype != input.dtype or scales.dtype != input.dtype:
+        raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {codebooks.dtype}")
+    if input.shape[-1] != packed.in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {packed.in_features}")
+    if input.device != packed.device or codebooks.device != input.device:
+        raise ValueError(f"input on {input.device}, layer on {packed.device}")
+    return dt
+
+
+def code1x16_matmat_packed(input, packed: PackedCodes, codebooks, scales, bias=None):
+    """1x16 g8 matvec on prepacked codes (aqlm_hip_gemv_1x16_packed): up to 8 input rows per launch share the codes and
+    the gathered codebook vectors (the reference relaunches its matvec per row, cuda_kernel.cpp:165-175)."""
+    dt = _check_packed_args(input, packed, codebooks, scales)
+    out_features = packed.out_features
     x = _flat_rows(input)
     codebooks, scales = _c(codebooks), _c(scales)
     if bias is not None:
         bias = _c(bias)
-    y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
-    ws = torch.empty((8 * out_features,), dtype=torch.float32, device=input.device)
+    B = x.shape[0]
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    nb_max = min(B, _native.MAX_GEMV_BATCH)
+    ws_bytes = 16 * nb_max * out_features * 4
+    ws = _workspace(input.device, ws_bytes)
+    stream = _stream_ptr(input.device)
     with torch.cuda.device(input.device):
-        rc = _lib.aqlm_hip_gemv_1x16_packed(packed.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
-                                            x.data_ptr(), y.data_ptr(), out_features, in_features, 8, dt,
-                                            ws.data_ptr(), ws.numel() * 4, _stream_ptr())
-    if rc:
-        _native.check(rc, "aqlm gemv_1x16_packed")
+        for b0 in range(0, B, _native.MAX_GEMV_BATCH):
+            nb = min(_native.MAX_GEMV_BATCH, B - b0)
+            rc = _lib.aqlm_hip_gemv_1x16_packed(ctypes.byref(packed.desc), packed.data_ptr(), codebooks.data_ptr(),
+                                                scales.data_ptr(), _ptr(bias), x.data_ptr() + b0 * x.stride(0) * 2,
+                                                y.data_ptr() + b0 * out_features * 2, nb, x.stride(0), out_features, dt,
+                                                ws.data_ptr(), ws.numel() * 4, stream)
+            if rc:
+                _native.check(rc, "aqlm gemv_1x16_packed")
     return y.reshape(input.shape[:-1] + (out_features,))
 
 
@@ -259,7 +316,7 @@ def _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias):
     ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
     with torch.cuda.device(input.device):
         rc = _lib.aqlm_hip_gemv_8x8_lut_multi(segs, n, x.data_ptr(), in_features, g, dt, ws.data_ptr(), ws_bytes,
-                                              _stream_ptr())
+                                              _stream_ptr(input.device))
     if rc:
         _native.check(rc, "aqlm gemv_8x8_lut_multi")
     return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
@@ -279,50 +336,46 @@ def codekx8_matmat_multi(input, codes, codebooks, scales, bias):
     return _gemv_multi(input, codes, codebooks, scales, bias, "kx8")
 
 
-def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias, out_features):
-    """Several prepacked 1x16 g8 layers applied to the same single input row in one launch
+def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
+    """Several prepacked 1x16 g8 layers applied to the same input (up to 8 rows) in one launch
     (aqlm_hip_gemv_1x16_packed_multi); outputs bit-identical to code1x16_matmat_packed per layer."""
     n = len(packed)
-    if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == len(out_features) == n):
+    if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == n):
         raise ValueError(f"code1x16_matmat_packed_multi takes 1..{_native.MAX_SEGMENTS} layers with one entry per list")
-    dt = _dtype_id(input)
-    in_features = input.shape[-1]
-    if input.numel() != in_features:
-        raise ValueError("the packed kernel handles exactly one input row")
     x = _flat_rows(input)
+    B = x.shape[0]
+    if B > _native.MAX_GEMV_BATCH:
+        return [code1x16_matmat_packed(input, packed[k], codebooks[k], scales[k], bias[k]) for k in range(n)]
     segs = (_native.Segment * n)()
+    descs = (_native._descp * n)()
     keep, outs = [], []
-    total = sum(int(o) for o in out_features)
-    ws = torch.empty((8 * total,), dtype=torch.float32, device=input.device)
+    total = sum(pk.out_features for pk in packed)
+    ws_bytes = 16 * B * total * 4
+    ws = _workspace(input.device, ws_bytes)
+    dt = None
     for k in range(n):
+        dt = _check_packed_args(input, packed[k], codebooks[k], scales[k])
         cb, sc = _c(codebooks[k]), _c(scales[k])
         bi = None if bias[k] is None else _c(bias[k])
-        if cb.dtype != input.dtype or sc.dtype != input.dtype:
-            raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {cb.dtype}")
-        y = torch.empty((1, int(out_features[k])), dtype=input.dtype, device=input.device)
+        of = packed[k].out_features
+        y = torch.empty((B, of), dtype=input.dtype, device=input.device)
         keep += [cb, sc, bi]
         outs.append(y)
         segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = packed[k].data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
-        segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), int(out_features[k]), int(out_features[k])
+        segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), of, of
+        descs[k] = ctypes.pointer(packed[k].desc)
     with torch.cuda.device(input.device):
-        rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, n, x.data_ptr(), in_features, 8, dt, ws.data_ptr(),
-                                                  ws.numel() * 4, _stream_ptr())
+        rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, descs, n, x.data_ptr(), packed[0].in_features, B, x.stride(0), dt,
+                                                  ws.data_ptr(), ws.numel() * 4, _stream_ptr(input.device))
     if rc:
         _native.check(rc, "aqlm gemv_1x16_packed_multi")
     return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
-
-
-def _lds_gemv_applicable(input, codes, codebooks):
-    return (codebooks.shape[3] == 8 and input.numel() == input.shape[-1] and input.shape[-1] % 64 == 0
-            and input.shape[-1] <= 14336 and input.dtype == codebooks.dtype)
 
 
 def code1x16_matmat(input, codes, codebooks, scales, bias=None):
     """aqlm::code1x16_matmat (cuda_kernel.py:13-22, cuda_kernel.cpp:148-182)."""
     if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536:
         raise NotImplementedError(f"code1x16_matmat needs codebooks [1, 65536, 1, g], got {tuple(codebooks.shape)}")
-    if LDS_GEMV_MIN_OUT and codes.shape[0] >= LDS_GEMV_MIN_OUT and _lds_gemv_applicable(input, codes, codebooks):
-        return _gemv_1x16_lds(input, codes, codebooks, scales, bias)
     return _gemv(input, codes, codebooks, scales, bias, "1x16")
 
 
@@ -360,7 +413,7 @@ def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
     with torch.cuda.device(input.device):
         rc = _lib.aqlm_hip_gemv_8x8_lut(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
                                         x.data_ptr(), y.data_ptr(), out_features, in_features, g, dt, ws.data_ptr(),
-                                        ws_bytes, _stream_ptr())
+                                        ws_bytes, _stream_ptr(input.device))
     if rc:
         _native.check(rc, "aqlm gemv_8x8_lut")
     return y.reshape(input.shape[:-1] + (out_features,))
@@ -399,15 +452,15 @@ def _dequant(codes, codebooks, scales, kind):
     with torch.cuda.device(codebooks.device):
         if kind == "1x16":
             rc = _lib.aqlm_hip_dequant_1x16(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
-                                            out_features, in_features, in_group_size, dt, _stream_ptr())
+                                            out_features, in_features, in_group_size, dt, _stream_ptr(codebooks.device))
         elif kind == "generic":
             nbits = int(codebook_size).bit_length() - 1
             rc = _lib.aqlm_hip_dequant_generic(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
                                                out_features, in_features, num_codebooks, nbits, in_group_size, dt,
-                                               _stream_ptr())
+                                               _stream_ptr(codebooks.device))
         else:
             rc = _lib.aqlm_hip_dequant_kx8(codes.data_ptr(), codebooks.data_ptr(), _ptr(scales), W.data_ptr(),
-                                           out_features, in_features, num_codebooks, in_group_size, dt, _stream_ptr())
+                                           out_features, in_features, num_codebooks, in_group_size, dt, _stream_ptr(codebooks.device))
     if rc:
         _native.check(rc, "aqlm dequant")
     return W
@@ -475,7 +528,7 @@ def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
     with torch.cuda.device(input.device):
         rc = _lib.aqlm_hip_gemm_1x16_mfma(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
                                           x.data_ptr(), y.data_ptr(), B, out_features, in_features, in_group_size,
-                                          x.stride(0), out_features, dt, ws.data_ptr(), ws.numel() * 4, _stream_ptr())
+                                          x.stride(0), out_features, dt, ws.data_ptr(), ws.numel() * 4, _stream_ptr(input.device))
     if rc:
         _native.check(rc, "aqlm gemm_1x16_mfma")
     return y.reshape(input.shape[:-1] + (out_features,))
@@ -587,6 +640,22 @@ for _name, _impl in (("code1x16_matmat_multi", code1x16_matmat_multi), ("codekx8
     _LIB.define(f"{_name}(Tensor input, Tensor[] codes, Tensor[] codebooks, Tensor[] scales, Tensor?[] bias) -> Tensor[]")
     _LIB.impl(_name, _impl, "CUDA")
     torch.library.register_fake(f"aqlm::{_name}")(_fake_multi)
+
+
+# the prepacked op as a dispatcher op, so that a QuantizedLinear on the packed path traces under torch.compile
+# (the descriptor travels as a list of ints; eager calls skip the dispatcher and use code1x16_matmat_packed directly)
+def _packed_op(input, packed, codebooks, scales, bias, desc):
+    return code1x16_matmat_packed(input, PackedCodes(packed, _native.PackedDesc.from_ints(desc)), codebooks, scales, bias)
+
+
+def _fake_packed(input, packed, codebooks, scales, bias, desc):
+    return torch.empty(input.shape[:-1] + (int(desc[2]),), device=input.device, dtype=input.dtype)
+
+
+_LIB.define("code1x16_matmat_packed(Tensor input, Tensor packed, Tensor codebooks, Tensor scales, Tensor? bias, "
+            "int[] desc) -> Tensor")
+_LIB.impl("code1x16_matmat_packed", _packed_op, "CUDA")
+torch.library.register_fake("aqlm::code1x16_matmat_packed")(_fake_packed)
 
 
 # what benchmark/matmul_benchmark.py:6,103 reaches for: CUDA_KERNEL.code1x16_matmat etc. (pybind module in the

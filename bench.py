@@ -36,7 +36,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # 1x16 g8 layers with at least this many codes run the prepacked (slice-bucketed) decode kernel, like
 # aqlm_amd.inference.PREPACK_MIN_CODES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
-PACK_MIN_OUT = 2_000_000
+PACK_MIN_OUT = 1_000_000
 
 
 def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
@@ -71,26 +71,24 @@ class Layer:
         return algorithmic_bytes(self.fin, self.fout, self.K, self.nbits, self.g, batch)
 
     def prepack(self, lib):
-        """One-off load-time repack for the slice-bucketed decode kernel (layers with >= PACK_MIN_OUT rows)."""
-        from aqlm_amd import _native
+        """One-off load-time repack for the slice-bucketed decode kernel (layers with >= PACK_MIN_OUT codes)."""
+        from aqlm_amd.inference_kernels import hip_kernel as hk
 
-        nbytes = lib.aqlm_hip_prepack_1x16_bytes(self.fout, self.fin, self.g)
-        if not nbytes:
-            return
-        self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=self.codes.device)
-        self.ws = torch.empty((8 * self.fout,), dtype=torch.float32, device=self.codes.device)
-        rc = lib.aqlm_hip_prepack_1x16(self.codes.data_ptr(), self.fout, self.fin, self.g, self.packed.data_ptr(), nbytes,
-                                       torch.cuda.current_stream().cuda_stream)
-        if rc:
-            _native.check(rc)
+        self.packed = hk.prepack_1x16(self.codes, self.g)
+        if self.packed is not None:
+            nb = self.x.shape[0]
+            self.ws = torch.empty((16 * nb * self.fout,), dtype=torch.float32, device=self.codes.device)
 
     def launch(self, lib, stream, batch=1):
+        import ctypes
+
         from aqlm_amd import _native
 
-        if batch == 1 and getattr(self, "packed", None) is not None:
-            rc = lib.aqlm_hip_gemv_1x16_packed(self.packed.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(),
-                                               None, self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g,
-                                               _native.F16, self.ws.data_ptr(), self.ws.numel() * 4, stream)
+        if batch <= self.x.shape[0] and getattr(self, "packed", None) is not None:
+            rc = lib.aqlm_hip_gemv_1x16_packed(ctypes.byref(self.packed.desc), self.packed.data_ptr(),
+                                               self.codebooks.data_ptr(), self.scales.data_ptr(), None, self.x.data_ptr(),
+                                               self.y.data_ptr(), batch, self.fin, self.fout, _native.F16,
+                                               self.ws.data_ptr(), self.ws.numel() * 4, stream)
         elif batch == 1 and self.K == 8 and self.nbits == 8:
             if getattr(self, "lut_ws", None) is None:
                 n = lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, self.g, self.fout, self.fin)
@@ -115,6 +113,8 @@ class FusedLayers:
     every member is prepacked): the q/k/v or gate/up projections of a decoder block."""
 
     def __init__(self, members, mode="auto"):
+        import ctypes
+
         from aqlm_amd import _native
 
         self.members = members
@@ -132,7 +132,8 @@ class FusedLayers:
             sg.codebook, sg.scales, sg.bias = m.codebooks.data_ptr(), m.scales.data_ptr(), None
             sg.y, sg.y_row_stride, sg.out_features = m.y.data_ptr(), m.fout, m.fout
         if self.packed:
-            self.ws = torch.empty((8 * sum(m.fout for m in members),), dtype=torch.float32, device=self.x.device)
+            self.ws = torch.empty((16 * sum(m.fout for m in members),), dtype=torch.float32, device=self.x.device)
+            self.descs = (_native._descp * len(members))(*[ctypes.pointer(m.packed.desc) for m in members])
 
     def alg_bytes(self, batch=1):
         return sum(m.alg_bytes(batch) for m in self.members)
@@ -152,8 +153,9 @@ class FusedLayers:
             rc = lib.aqlm_hip_gemv_kx8_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, m0.K, self.g, batch,
                                              self.fin, _native.F16, stream)
         elif self.packed and batch == 1:
-            rc = lib.aqlm_hip_gemv_1x16_packed_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g,
-                                                     _native.F16, self.ws.data_ptr(), self.ws.numel() * 4, stream)
+            rc = lib.aqlm_hip_gemv_1x16_packed_multi(self.segs, self.descs, len(self.members), self.x.data_ptr(), self.fin,
+                                                     1, self.fin, _native.F16, self.ws.data_ptr(), self.ws.numel() * 4,
+                                                     stream)
         else:
             rc = lib.aqlm_hip_gemv_1x16_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g, batch,
                                               self.fin, _native.F16, stream)

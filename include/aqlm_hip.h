@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 1
+#define AQLM_HIP_ABI_VERSION 2
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -163,47 +163,58 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
                             size_t workspace_bytes, void* stream);
 
 /*
- * Slice-scan variant of the 1x16 g8 matvec (batch 1): the codebook lives in LDS as 8 per-CU slices, every CU scans the
- * code rows of its row-group and gathers only the codes of its slice from LDS; fp32 partials go through `workspace`
- * (aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_LDS, 1, out, in) bytes) and a finalize kernel applies scale + bias.
- * Same result contract as aqlm_hip_gemv_1x16 (which it replaces for large layers; same reference lines).  Returns
- * AQLM_HIP_E_UNSUPPORTED for shapes it does not cover (in_group_size != 8, in_features % 64 != 0 or > 14336) --
- * callers then use aqlm_hip_gemv_1x16.
- */
-int aqlm_hip_gemv_1x16_lds(const void* codes_i16, const void* codebook, const void* scales, const void* bias,
-                           const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
-                           void* workspace, size_t workspace_bytes, void* stream);
-
-/*
- * Load-time repack of 1x16 g8 codes into the slice-bucketed format consumed by aqlm_hip_gemv_1x16_packed
- * (layout documented in aqlm_amd/csrc/gemv_packed.hip and DESIGN.md; ~4.1 bytes per code + 4 bytes per (row, slice)).
+ * Load-time repack of 1x16 g8 codes into the slice-bucketed format v5 consumed by aqlm_hip_gemv_1x16_packed (layout:
+ * aqlm_amd/csrc/gemv_packed.hip, specification tests/packed_model.py; 4 bytes per code + ~6 bytes per (row, slice)).
  * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
- * (inference.py:78-83).  aqlm_hip_prepack_1x16_bytes returns 0 for shapes the packed path does not cover
- * (in_group_size != 8, in_features % 64 != 0, in_features > 16320).  aqlm_hip_prepack_1x16 synchronises `stream`
- * once (it is not meant to be graph-captured).
+ * (inference.py:78-83).
+ *   aqlm_hip_prepack_1x16_bytes  capacity the caller must provide (0: shape not covered -- in_group_size != 8 or
+ *                                in_features / 8 > 4094); more than the result needs: the repack uses the tail as scratch.
+ *   aqlm_hip_prepack_1x16        fills `packed` and `*desc`; desc->used_bytes <= capacity is what has to be kept (the
+ *                                buffer may be trimmed / copied; the descriptor travels with it and is also stored in the
+ *                                buffer's first bytes).  Synchronises `stream` (load-time call, not graph-capturable).
+ *                                AQLM_HIP_E_UNSUPPORTED when the codes use the 16 codebook slices too unevenly.
+ *   aqlm_hip_packed_desc_read    descriptor from the first sizeof(desc) bytes of a packed buffer copied to the host.
+ *   aqlm_hip_unpack_1x16         the inverse: canonical int16 codes [out][in/8] from a packed buffer (lossless).
  */
+typedef struct aqlm_hip_packed_desc {
+  uint32_t magic;   /* "AQP5" */
+  uint32_t version; /* 5 */
+  int32_t out_features, in_features;
+  int32_t slices_log2; /* 4: 16 codebook slices of 4096 entries */
+  int32_t waves;       /* wave ranges per stream = waves per workgroup of the gemv kernel */
+  int32_t steps;       /* KiB steps per wave range */
+  int32_t entry_bytes; /* 4 */
+  uint64_t used_bytes;
+  uint64_t reserved;
+} aqlm_hip_packed_desc;
+
 size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size);
 int aqlm_hip_prepack_1x16(const void* codes_i16, int out_features, int in_features, int in_group_size, void* packed,
-                          size_t packed_bytes, void* stream);
+                          size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream);
+int aqlm_hip_packed_desc_read(const void* header_host, size_t header_bytes, aqlm_hip_packed_desc* desc);
+int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, void* codes_i16, void* stream);
 
 /*
- * Batch-1 1x16 g8 matvec on prepacked codes: every CU keeps one 128 KiB slice of the codebook in LDS and walks only
- * the codes of that slice.  Same result contract as aqlm_hip_gemv_1x16.  workspace:
- * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, 1, out, in) bytes of fp32 partials.
+ * 1x16 g8 matvec for 1..AQLM_HIP_MAX_GEMV_BATCH input rows on prepacked codes: every CU keeps one 64 KiB slice of the
+ * codebook in LDS and walks only the codes of that slice; the rows of x share the codes and the gathered codebook
+ * vectors.  Same result contract as aqlm_hip_gemv_1x16 (which it replaces for large layers; same reference lines:
+ * cuda_kernel.cu:7-95, cuda_kernel.cpp:148-182 incl. the per-row relaunch loop :165-175).  x / y row strides in elements.
+ * workspace: aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, batch, out, in) bytes of fp32 partials.
  */
-int aqlm_hip_gemv_1x16_packed(const void* packed, const void* codebook, const void* scales, const void* bias,
-                              const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
-                              void* workspace, size_t workspace_bytes, void* stream);
+int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+                              const void* scales, const void* bias, const void* x, void* y, int batch,
+                              long x_row_stride, long y_row_stride, int dtype, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /*
- * aqlm_hip_gemv_1x16_packed for up to AQLM_HIP_MAX_SEGMENTS prepacked layers that share x (batch 1), in one launch
- * (+ one finalize); segment.codes is the prepacked buffer, y_row_stride is unused.  workspace: the sum over segments
- * of aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, 1, out_features_s, in_features), 16-B aligned.  Results
+ * aqlm_hip_gemv_1x16_packed for up to AQLM_HIP_MAX_SEGMENTS prepacked layers that share x, in one launch (+ one
+ * finalize); segment.codes is the prepacked buffer, descs[s] its descriptor.  workspace: the sum over segments of
+ * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, batch, out_features_s, in_features), 16-B aligned.  Results
  * are bit-identical to separate aqlm_hip_gemv_1x16_packed calls.
  */
-int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
-                                    int in_features, int in_group_size, int dtype, void* workspace,
-                                    size_t workspace_bytes, void* stream);
+int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+                                    int num_segments, const void* x, int in_features, int batch, long x_row_stride,
+                                    int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Batch-1 matvec for 8 x 8-bit schemes (e.g. the 2-bit 8x8 g32 models; in_group_size 8, 16 or 32) through per-token
@@ -227,7 +238,6 @@ int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segmen
                                 int in_group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
-#define AQLM_HIP_OP_GEMV_1X16_LDS 2
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3
 #define AQLM_HIP_OP_GEMV_8X8_LUT 4
 size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);

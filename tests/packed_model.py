@@ -1,126 +1,221 @@
-"""numpy model of the packed 1x16 format v4 (aqlm_amd/csrc/gemv_packed.hip): the bit-exact oracle for
-aqlm_hip_prepack_1x16.  Test infrastructure only."""
+"""numpy model of the packed 1x16 g8 format v5 (aqlm_amd/csrc/gemv_packed.hip): the specification that
+aqlm_hip_prepack_1x16 is held to, plus a straight-line simulation of the kernel's traversal (column walk, flag masks,
+LDS slots, carries).  Test infrastructure only.
+
+Format v5 in one paragraph: the 65536-entry codebook is cut into S = 16 slices (code >> 12); the rows into NG = 16
+row-groups of RG rows; workgroup (g, s) of the kernel owns *stream* (g, s) = every code of the group's rows whose slice is
+s.  A row's codes of the slice are rounded up to whole *lane-steps* of 4 entries (at least one; null entries pad), and the
+lane-steps of rows 0, 1, 2, ... are laid end to end.  That sequence is cut into NW wave ranges of 64*T lane-steps, each
+wave range into 64 lane *columns* of T lane-steps: lane l of wave w reads lane-steps [(w*64 + l)*T, +T).  In memory
+entry (w, t, l, k) sits at (((st*NW + w)*T + t)*64 + l)*4 + k, so step t of a wave is one contiguous KiB.  An entry is
+(XB + j) << 16 | (code & 0xfff) with XB = 4096: both halves, shifted left by 4, are LDS byte addresses (slice at 0, x at
+64 KiB).  Per lane column a bit mask marks the steps that END a row (mask word t/32, bit t%32), `frow` is the row (within
+the group) the column's first lane-step belongs to, `rowstart[st][r]` is the first lane-step of row r in stream st, and per
+wave `winfo` holds (first row that STARTS in the wave, wave starts inside a row, steps = steps that carry content).
+(In the device buffer the mask and frow bits ride in the spare nibbles of the entries.)"""
 import numpy as np
 
-S, NG, PAD = 8, 32, 128
-XBASE = 8192   # x[j] sits at LDS slot XBASE + j: the high half of an entry is that slot index
+S_LOG = 4
+S = 1 << S_LOG
+NG = 256 // S
+CODE_BITS = 16 - S_LOG
+SLICE_ENTRIES = 1 << CODE_BITS
+XB = SLICE_ENTRIES
+MAX_T = 128
+MAGIC = 0x35505141  # "AQP5"
 
 
 def align_up(v, a):
     return (v + a - 1) // a * a
 
 
-def layout(out_features, in_features):
-    in_groups = in_features // 8
-    RG = ((out_features + NG - 1) // NG + 3) // 4 * 4
-    n_rowoff = NG * S * (RG + 1)
-    entries = out_features * in_groups + 3 * S * out_features  # capacity incl. null padding
-    off_rowoff = 256
-    n_perm = NG * S * RG
-    off_perm = align_up(off_rowoff + n_rowoff * 4, 256)
-    off_ent = align_up(off_perm + n_perm * 2, 256)
-    total = align_up(off_ent + (entries + PAD) * 4, 256)
-    return dict(in_groups=in_groups, RG=RG, n_rowoff=n_rowoff, n_perm=n_perm, entries=entries, off_rowoff=off_rowoff,
-                off_perm=off_perm, off_ent=off_ent, total=total)
+def choose_waves(max_lane_steps):
+    q = (max_lane_steps + 63) // 64  # wave-steps of work per workgroup
+    if q >= 64:
+        return 16
+    if q >= 24:
+        return 8
+    return 4
 
 
-def pack(codes_unsigned):
-    """codes_unsigned: [M, in_groups] ints in [0, 65536).  Returns (rowoff u32, rowperm u16, entries u32, layout).
-    Inside a stream (g, s) the buckets are ordered by padded size, largest first, ties by row index."""
+def layout(M, in_groups, NW, T):
+    RG = (M + NG - 1) // NG
+    nst = NG * S
+    off_winfo = 256
+    off_rowstart = align_up(off_winfo + nst * 16 * 16, 256)
+    off_ent = align_up(off_rowstart + nst * (RG + 1) * 4, 1024)
+    ent_bytes = nst * NW * T * 1024
+    return dict(RG=RG, off_winfo=off_winfo, off_rowstart=off_rowstart, off_ent=off_ent, ent_bytes=ent_bytes,
+                used=off_ent + ent_bytes)
+
+
+def lane_steps(codes_unsigned):
+    """[NG*S, RG] lane-steps per (stream, row) and their exclusive prefix sums [NG*S, RG+1]."""
     M, in_groups = codes_unsigned.shape
-    L = layout(M, in_groups * 8)
-    RG = L["RG"]
-    counts = np.zeros((NG, S, RG + 1), dtype=np.int64)
-    sl = codes_unsigned >> 13
+    RG = (M + NG - 1) // NG
+    sl = codes_unsigned >> CODE_BITS
+    ls = np.zeros((NG, S, RG), dtype=np.int64)
     for s in range(S):
-        c = ((sl == s).sum(axis=1) + 3) // 4 * 4  # buckets padded to multiples of 4 entries
-        for r in range(M):
-            counts[r // RG, s, r % RG] = c[r]
-    perm = np.zeros((NG, S, RG), dtype=np.uint16)   # position -> row
-    rank = np.zeros((NG, S, RG), dtype=np.int64)    # row -> position
+        c = np.maximum(1, ((sl == s).sum(axis=1) + 3) // 4)
+        for g in range(NG):
+            rows = c[g * RG:(g + 1) * RG]
+            ls[g, s, :len(rows)] = rows
+    ls = ls.reshape(NG * S, RG)
+    a = np.zeros((NG * S, RG + 1), dtype=np.int64)
+    a[:, 1:] = np.cumsum(ls, axis=1)
+    return ls, a
+
+
+def pack(codes_unsigned, NW=None):
+    """codes_unsigned [M, in_groups] ints in [0, 65536) -> dict with the arrays of the packed buffer."""
+    M, in_groups = codes_unsigned.shape
+    RG = (M + NG - 1) // NG
+    ls, a = lane_steps(codes_unsigned)
+    maxL = int(a[:, RG].max())
+    if NW is None:
+        NW = choose_waves(maxL)
+    T = (maxL + 64 * NW - 1) // (64 * NW)
+    assert 1 <= T <= MAX_T
+    MW = (T + 31) // 32
+    nst = NG * S
+    null = np.uint32((XB + in_groups) << 16)
+    ent = np.full((nst, NW, T, 64, 4), null, dtype=np.uint32)
+    mask = np.zeros((nst, NW, MW, 64), dtype=np.uint32)
+    frow = np.zeros((nst, NW, 64), dtype=np.uint16)
+    winfo = np.zeros((nst, NW, 4), dtype=np.uint32)
     for g in range(NG):
+        nrows = max(0, min(RG, M - g * RG))
         for s in range(S):
-            order = sorted(range(RG), key=lambda r: (-counts[g, s, r], r))
-            perm[g, s] = order
-            rank[g, s, order] = np.arange(RG)
-            counts[g, s, :RG] = counts[g, s, order]
-    flat = counts.reshape(-1)
-    rowoff = np.concatenate([[0], np.cumsum(flat)[:-1]]).astype(np.uint32)
-    ent = np.zeros(L["entries"], dtype=np.uint32)
-    ro = rowoff.reshape(NG, S, RG + 1)
-    for r in range(M):
-        g, rl = divmod(r, RG)
-        row = codes_unsigned[r]
-        for s in range(S):
-            js = np.nonzero((row >> 13) == s)[0]
-            e = ((js.astype(np.uint32) + XBASE) << 16) | (row[js].astype(np.uint32) & 0x1FFF)
-            b = int(ro[g, s, rank[g, s, rl]])
-            pad = (-len(js)) % 4
-            null = np.uint32((in_groups + XBASE) << 16)  # j = in_groups, code 0
-            ent[b:b + len(e) + pad] = arrange(e, len(e) + pad, null)
-    # K4b: per pair of neighbouring positions, order each lane's four entries over the levels (codebook bank conflicts)
-    for g in range(NG):
-        for s in range(S):
-            for i in range(RG // 2):
-                order_levels(ent, [int(ro[g, s, 2 * i]), int(ro[g, s, 2 * i + 1])],
-                             [int(ro[g, s, 2 * i + 1] - ro[g, s, 2 * i]), int(ro[g, s, 2 * i + 2] - ro[g, s, 2 * i + 1])])
-    return rowoff, perm.reshape(-1), ent, L
+            st = g * S + s
+            total = int(a[st, nrows])
+            for r in range(nrows):
+                row = codes_unsigned[g * RG + r]
+                js = np.nonzero((row >> CODE_BITS) == s)[0]
+                e = ((js.astype(np.uint32) + XB) << 16) | (row[js].astype(np.uint32) & (SLICE_ENTRIES - 1))
+                q0 = int(a[st, r])
+                for i, v in enumerate(e):
+                    q, k = q0 + i // 4, i % 4
+                    w, rem = divmod(q, 64 * T)
+                    l, t = divmod(rem, T)
+                    ent[st, w, t, l, k] = v
+                ql = q0 + int(ls[st, r]) - 1  # the row's last lane-step carries the flag
+                w, rem = divmod(ql, 64 * T)
+                l, t = divmod(rem, T)
+                mask[st, w, t // 32, l] |= np.uint32(1 << (t % 32))
+            starts = a[st, :nrows + 1]  # starts[r] for r < nrows, starts[nrows] = total
+            for w in range(NW):
+                w0 = w * 64 * T
+                wfr = int(np.searchsorted(starts[:nrows], w0, side="left"))  # first row starting at or after w0
+                cont = 1 if (w0 < total and wfr <= nrows and int(starts[wfr]) > w0) else 0
+                if w0 >= total:
+                    steps = 0
+                elif total - w0 >= T:
+                    steps = T
+                else:
+                    steps = total - w0
+                winfo[st, w] = (wfr, cont, steps, 0)
+                for l in range(64):
+                    q = w0 + l * T
+                    r0 = nrows if q >= total else int(np.searchsorted(starts[:nrows], q, side="right")) - 1
+                    frow[st, w, l] = r0
+    return dict(M=M, in_groups=in_groups, NW=NW, T=T, MW=MW, RG=RG, ent=ent, mask=mask, frow=frow, winfo=winfo,
+                rowstart=a.astype(np.uint32))
 
 
-import itertools  # noqa: E402
-
-PERMS = list(itertools.permutations(range(4)))  # lexicographic, like the table in prepack_level_kernel
-
-
-def order_levels(ent, beg, length):
-    """prepack_level_kernel for one pair of buckets: greedy choice, lane by lane (even bucket, then odd), of the first of
-    the 24 orders of a lane's entries that adds the fewest codebook-residue collisions to its service group."""
-    for region in (0, 64):
-        used = [[0] * 4, [0] * 4]
-        for lane in range(16):
-            for b in range(2):
-                off = region + 4 * lane
-                if off + 4 > length[b]:
-                    continue
-                ev = [int(v) for v in ent[beg[b] + off: beg[b] + off + 4]]
-                in_x = lane < 4 or lane >= 12
-                grp = 0 if (in_x == (b == 0)) else 1
-                best, best_cost = 0, 5
-                for q, pm in enumerate(PERMS):
-                    cost = sum((used[grp][k] >> (ev[pm[k]] & 15)) & 1 for k in range(4))
-                    if cost < best_cost:
-                        best, best_cost = q, cost
-                o = [ev[PERMS[best][k]] for k in range(4)]
-                ent[beg[b] + off: beg[b] + off + 4] = o
-                for k in range(4):
-                    used[grp][k] |= 1 << (o[k] & 15)
+def walk(P):
+    """Yield (st, w, l, t, row_in_group_or_None, entries[4]) following the kernel's column walk.  `row` is the row the
+    lane-step belongs to (None for trailing null steps)."""
+    NW, T, RG, M = P["NW"], P["T"], P["RG"], P["M"]
+    for st in range(NG * S):
+        g = st // S
+        nrows = max(0, min(RG, M - g * RG))
+        for w in range(NW):
+            wfr, cont, steps, _ = (int(v) for v in P["winfo"][st, w])
+            for l in range(64):
+                row = int(P["frow"][st, w, l])
+                for t in range(steps):
+                    yield st, w, l, t, (row if row < nrows else None), P["ent"][st, w, t, l]
+                    if (int(P["mask"][st, w, t // 32, l]) >> (t % 32)) & 1:
+                        row += 1
 
 
-def home_lane(rho):
-    return rho if rho < 4 else (rho + 8 if rho < 8 else rho - 4)
-
-
-def arrange(entries, slots, null):
-    """Bank-aware order inside a bucket (prepack_arrange_kernel): an entry whose x slot has residue rho = j mod 16 goes
-    to its home lane (index 4*lane + level) while that lane exists and has a free level; the others fill the holes in
-    index order; what is left is null padding."""
-    EMPTY = 0xFFFFFFFF
-    out = np.full(slots, EMPTY, dtype=np.uint32)
-    m = min(16, slots // 4)
-    cnt = [0] * 16
-    rest = []
-    for e in entries:
-        L = home_lane((int(e) >> 16) & 15)
-        if L < m and cnt[L] < 4:
-            out[4 * L + cnt[L]] = e
-            cnt[L] += 1
-        else:
-            rest.append(e)
-    idx = 0
-    for e in rest:
-        while out[idx] != EMPTY:
-            idx += 1
-        out[idx] = e
-        idx += 1
-    out[out == EMPTY] = null
+def unpack(P):
+    """Reconstruct the canonical codes [M, in_groups] from the packed arrays (lossless)."""
+    M, in_groups, RG = P["M"], P["in_groups"], P["RG"]
+    out = np.full((M, in_groups), -1, dtype=np.int64)
+    for st, w, l, t, row, e in walk(P):
+        g, s = divmod(st, S)
+        for v in e:
+            j = (int(v) >> 16) - XB
+            if j == in_groups:
+                continue
+            assert row is not None and 0 <= j < in_groups
+            assert out[g * RG + row, j] == -1
+            out[g * RG + row, j] = (s << CODE_BITS) | (int(v) & 0xFFFF)
+    assert (out >= 0).all()
     return out
+
+
+def simulate(P, codebook, x):
+    """The kernel's arithmetic in float64 with its exact bookkeeping: a lane adds up its column; at a row end it
+    stores the sum to rowval[row] (one writer per row) and starts over; what is left at the end of the column goes to
+    colend[column]; row r = rowval[r] + colend of the columns it crosses.  codebook [65536, 8], x [B, in_features] ->
+    y [B, M] (unscaled)."""
+    M, in_groups, NW, T, RG = P["M"], P["in_groups"], P["NW"], P["T"], P["RG"]
+    B = x.shape[0]
+    xg = np.concatenate([x.reshape(B, in_groups, 8), np.zeros((B, 1, 8))], axis=1)
+    y = np.zeros((B, M))
+    for st in range(NG * S):
+        g, s = divmod(st, S)
+        nrows = max(0, min(RG, M - g * RG))
+        rowval = np.full((B, RG + 1), np.nan)
+        colend = np.zeros((B, NW * 64))
+        for w in range(NW):
+            steps = int(P["winfo"][st, w, 2])
+            for l in range(64):
+                row = int(P["frow"][st, w, l])
+                acc = np.zeros(B)
+                for t in range(steps):
+                    for v in P["ent"][st, w, t, l]:
+                        c, j = int(v) & 0xFFFF, (int(v) >> 16) - XB
+                        acc += xg[:, j] @ codebook[(s << CODE_BITS) | c]
+                    if (int(P["mask"][st, w, t // 32, l]) >> (t % 32)) & 1:
+                        assert np.isnan(rowval[0, row])  # exactly one writer per row
+                        rowval[:, row] = acc
+                        acc = np.zeros(B)
+                        row += 1
+                colend[:, w * 64 + l] = acc
+        rs = P["rowstart"][st].astype(np.int64)
+        for r in range(nrows):
+            c0, c1 = rs[r] // T, (rs[r + 1] - 1) // T
+            v = rowval[:, r].copy()
+            for c in range(c0, c1):
+                v += colend[:, c]
+            y[:, g * RG + r] += v
+    assert not np.isnan(y).any()
+    return y
+
+
+SERVICE_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+                  [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+SERVICE_GROUPS += [[l + 32 for l in g] for g in SERVICE_GROUPS]
+
+
+def conflict_cycles(P, max_streams=6):
+    """Mean LDS cycles per 16-lane service group and ds_read_b128 (1.0 = conflict-free) over the steps that carry
+    content: max number of DISTINCT 16-B slots that fall into one bank group (slot % 16), for the x reads and the
+    codebook reads (identical slots -- the null entries -- are broadcast)."""
+    ent, in_groups = P["ent"], P["in_groups"]
+    tot, n = 0.0, 0
+    for st in range(0, ent.shape[0], max(1, ent.shape[0] // max_streams)):
+        for w in range(P["NW"]):
+            steps = int(P["winfo"][st, w, 2])
+            for t in range(steps):
+                for k in range(4):
+                    v = ent[st, w, t, :, k].astype(np.int64)
+                    for field in ((v >> 16) - XB, v & 0xFFFF):
+                        for grp in SERVICE_GROUPS:
+                            slots = np.unique(field[grp])
+                            tot += np.bincount(slots % 16, minlength=16).max()
+                            n += 1
+    return tot / max(n, 1)

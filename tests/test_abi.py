@@ -32,7 +32,7 @@ def test_header_and_binding_agree(native):
 
 
 def test_abi_version_and_error_string(native):
-    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 1
+    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 2
     assert isinstance(native.last_error(), str)
 
 
@@ -88,10 +88,29 @@ def test_segment_struct_and_multi_validation(native):
     assert rc == native.E_UNSUPPORTED and "8 or 16" in native.last_error()
     rc = L.aqlm_hip_gemv_1x16_multi(segs, 2, p, 512, 8, 1, 512, 5, None)
     assert rc == native.E_UNSUPPORTED and "float16 and bfloat16" in native.last_error()
-    rc = L.aqlm_hip_gemv_1x16_packed_multi(segs, 2, p, 512, 16, native.F16, p, 1 << 20, None)  # g16 not packable
+    # prepacked entry points: descriptors are validated before anything is launched
+    assert ctypes.sizeof(native.PackedDesc) == 48
+    assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 8) > 2 * 4096 * 512 * 2
+    assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 16) == 0          # g16 is not packable
+    assert L.aqlm_hip_prepack_1x16_bytes(64, 8 * 4095, 8) == 0         # in/8 > 4094: j does not fit 12 bits
+    bad = native.PackedDesc()
+    descs = (native._descp * 2)(ctypes.pointer(bad), ctypes.pointer(bad))
+    rc = L.aqlm_hip_gemv_1x16_packed_multi(segs, descs, 2, p, 512, 1, 512, native.F16, p, 1 << 20, None)
+    assert rc == native.E_INVALID and "descriptor" in native.last_error()
+    rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(bad), p, p, p, None, p, p, 1, 512, 64, native.F16, p, 1 << 20, None)
+    assert rc == native.E_INVALID and "descriptor" in native.last_error()
+    # 64 rows -> 4 per row group; winfo (sized for 16 waves) + row starts (256 x 5 u32) end at 70 KiB, then 256 x 4 x 1 KiB
+    good = native.PackedDesc(0x35505141, 5, 64, 512, 4, 4, 1, 4, 1024 * (70 + 1024), 0)
+    back = native.PackedDesc.from_ints(good.as_ints())
+    assert bytes(back) == bytes(good)
+    rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(good), p, p, p, None, p, p, 9, 512, 64, native.F16, p, 1 << 20, None)
+    assert rc == native.E_INVALID and "batch" in native.last_error()
+    rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(good), p, p, p, None, p, p, 1, 512, 64, 7, p, 1 << 20, None)
     assert rc == native.E_UNSUPPORTED
-    rc = L.aqlm_hip_gemv_1x16_packed_multi(segs, 2, p, 512, 8, native.F16, None, 0, None)
-    assert rc == native.E_INVALID and "workspace" in native.last_error()
+    hdr = ctypes.create_string_buffer(bytes(good), 64)
+    out = native.PackedDesc()
+    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(hdr), 64, ctypes.byref(out)) == 0 and bytes(out) == bytes(good)
+    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(buf), 64, ctypes.byref(out)) == native.E_INVALID
 
 
 def test_workspace_bytes(native):
@@ -100,6 +119,8 @@ def test_workspace_bytes(native):
     assert n > 0 and n % (4096 * 128 * 4) == 0
     assert L.aqlm_hip_workspace_bytes(99, 128, 4096, 4096) == 0
     assert L.aqlm_hip_workspace_bytes(native.OP_GEMM_1X16_MFMA, 7, 4096, 4096) < n
+    assert L.aqlm_hip_workspace_bytes(native.OP_GEMV_1X16_PACKED, 1, 4096, 4096) == 16 * 4096 * 4
+    assert L.aqlm_hip_workspace_bytes(native.OP_GEMV_1X16_PACKED, 4, 11008, 4096) == 16 * 4 * 11008 * 4
 
 
 def test_tuning_knobs(native):

@@ -20,7 +20,7 @@ def test_make_pmc_traffic_applies_the_gfx950_correction(tmp_path):
     cols = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id",
             "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
             "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
-    main = "void aqlm::gemv_1x16_packed_kernel<aqlm::F16, 16, 3>(aqlm::PackedGemvParams)"
+    main = "void aqlm::gemv_1x16_packed_kernel<aqlm::F16, 1, 4, 65520u>(aqlm::PackedGemvParams)"
     fin = "void aqlm::gemv_1x16_packed_finalize<aqlm::F16>(aqlm::PackedFinalizeParams)"
     rows = {"pmc_fetch": [(main, "FETCH_SIZE", 1000.0), (main, "FETCH_SIZE", 3000.0), (fin, "FETCH_SIZE", 10.0),
                           (fin, "FETCH_SIZE", 10.0), ("aqlm::prepack_count_kernel(...)", "FETCH_SIZE", 9e9)],

@@ -100,6 +100,75 @@ __global__ __launch_bounds__(1024) void ldsgather(uint32_t entry_mask, int iters
   out[gid] = acc;
 }
 
+// ---------------------------------------------------------------- VALU / LDS issue rates of the packed kernel's inner loop
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+template <int MODE>  // 0: v_dot2c_f32_f16, 1: v_fma_f32, 2: v_and_b32_sdwa
+__global__ __launch_bounds__(1024) void valu_rate(int iters, float* out) {
+  float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f;
+  uint32_t w0 = threadIdx.x * 2654435761u, w1 = w0 ^ 0x3c003c00u;
+  uint32_t m = 0xfff0u;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (MODE == 0) {
+        a0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w0), __builtin_bit_cast(h2, w1), a0, false);
+        a1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w1), __builtin_bit_cast(h2, w0), a1, false);
+        a2 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w0), __builtin_bit_cast(h2, w0), a2, false);
+        a3 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w1), __builtin_bit_cast(h2, w1), a3, false);
+      } else if (MODE == 1) {
+        a0 = __builtin_fmaf(a0, 1.0001f, 0.5f); a1 = __builtin_fmaf(a1, 1.0001f, 0.5f);
+        a2 = __builtin_fmaf(a2, 1.0001f, 0.5f); a3 = __builtin_fmaf(a3, 1.0001f, 0.5f);
+      } else {
+        uint32_t d0, d1, d2, d3;
+        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d0) : "v"(m), "v"(w0));
+        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d1) : "v"(m), "v"(w0));
+        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d2) : "v"(m), "v"(w1));
+        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d3) : "v"(m), "v"(w1));
+        w0 ^= d0 ^ d2; w1 ^= d1 ^ d3;
+      }
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(w0 ^ w1);
+}
+
+// ds_read_b128 with the addresses held in registers (no address arithmetic in the loop): MODE 0 random slots,
+// 1 conflict-free (slot % 16 == position of the lane in its 16-lane service group), 2 two reads per "entry" like the kernel
+__device__ __forceinline__ int mb_group_pos(int l) {
+  const int h = l & 31;
+  if (h < 4) return h;
+  if (h < 12) return h - 4;
+  if (h < 16) return h - 12 + 4;
+  if (h < 20) return h - 16 + 8;
+  if (h < 28) return h - 20 + 8;
+  return h - 28 + 12;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void lds_rate(int iters, u32x4* out) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 tab[];  // 64 KiB = 4096 slots
+  for (uint32_t q = threadIdx.x; q < 4096; q += blockDim.x) tab[q] = u32x4{q, q * 3, q * 5, q * 7};
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  uint32_t idx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t r = mix((blockIdx.x * 1024 + threadIdx.x) * 8 + k) & 4095u;
+    if (MODE == 1) r = (r & ~15u) | (uint32_t)mb_group_pos(lane);
+    idx[k] = r * 16u;
+  }
+  u32x4 acc = {0, 0, 0, 0};
+  typedef __attribute__((address_space(3))) const u32x4* lp;
+  const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) u32x4*)tab;
+  for (int it = 0; it < iters; ++it) {
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *(lp)(size_t)(base + idx[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : : "v"(v[k]));
+    acc.x += v[0].x;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // ---------------------------------------------------------------- streaming read
 __global__ __launch_bounds__(256) void stream_read(const u32x4* p, size_t n, u32x4* out) {
   u32x4 acc = {0, 0, 0, 0};
@@ -201,6 +270,45 @@ static void bench_lds() {
   CK(hipFree(out));
 }
 
+static void bench_rates() {
+  float* out; u32x4* out4;
+  CK(hipMalloc(&out, (size_t)256 * 1024 * 4)); CK(hipMalloc(&out4, (size_t)256 * 1024 * 16));
+  const int iters = 4096;
+  auto run = [&](const char* name, auto kern, int threads, double per_iter) {
+    Timer t;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, iters, out);
+    CK(hipDeviceSynchronize());
+    t.start();
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, iters, out);
+    const float ms = t.stop_ms() / 5;
+    const double waves_per_simd = threads / 256.0;
+    const double cyc = ms * 1e-3 * clock_ghz() * 1e9 / (iters * per_iter * waves_per_simd);
+    printf("valu %-16s %4d thr/CU  %7.2f cycles per wave-instruction per SIMD\n", name, threads, cyc);
+  };
+  for (int thr : {256, 512, 1024}) {
+    run("v_dot2c_f32_f16", valu_rate<0>, thr, 32);
+    run("v_fma_f32", valu_rate<1>, thr, 32);
+    run("v_and_b32_sdwa", valu_rate<2>, thr, 32);
+  }
+  auto runl = [&](const char* name, auto kern, int threads) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    Timer t;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 65536, 0, iters, out4);
+    CK(hipDeviceSynchronize());
+    t.start();
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 65536, 0, iters, out4);
+    const float ms = t.stop_ms() / 5;
+    const double reads = (double)iters * 8 * (threads / 64);  // wave-instructions per CU
+    printf("lds  %-16s %4d thr/CU  %7.2f cycles per ds_read_b128 wave-instruction per CU  (%.1f B/clk/CU)\n", name, threads,
+           ms * 1e-3 * clock_ghz() * 1e9 / reads, reads * 1024 / (ms * 1e-3 * clock_ghz() * 1e9));
+  };
+  for (int thr : {256, 512, 1024}) {
+    runl("random", lds_rate<0>, thr);
+    runl("conflict-free", lds_rate<1>, thr);
+  }
+  CK(hipFree(out)); CK(hipFree(out4));
+}
+
 static void bench_stream() {
   const size_t bytes = (size_t)2 << 30;
   u32x4 *buf, *out;
@@ -223,12 +331,13 @@ static void bench_stream() {
 struct Layer {
   void *codes, *cb, *scales, *x, *y;
   void* packed = nullptr;
+  aqlm_hip_packed_desc desc;
 };
 
 struct Scheme {
   const char* name;
   int K, nbits, g;
-  bool lds = false;  // route 1x16 through aqlm_hip_gemv_1x16_lds
+  bool lds = false;  // (unused: the slice-scan experiment was removed)
   bool packed = false;  // route 1x16 through aqlm_hip_gemv_1x16_packed
   bool lut = false;     // route 8x8 through aqlm_hip_gemv_8x8_lut
 };
@@ -246,9 +355,7 @@ static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int ba
   if (s.lut)
     return aqlm_hip_gemv_8x8_lut(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16 && s.packed)
-    return aqlm_hip_gemv_1x16_packed(L.packed, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
-  if (s.nbits == 16 && s.lds)
-    return aqlm_hip_gemv_1x16_lds(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
+    return aqlm_hip_gemv_1x16_packed(&L.desc, L.packed, L.cb, L.scales, nullptr, L.x, L.y, batch, in, out, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16)
     return aqlm_hip_gemv_1x16(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, batch, in, out, AQLM_HIP_F16, st);
   return aqlm_hip_gemv_kx8(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.K, s.g, batch, in, out, AQLM_HIP_F16, st);
@@ -309,9 +416,11 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     const size_t pb = aqlm_hip_prepack_1x16_bytes(out, in, s.g);
     for (auto& L : v) {
       CK(hipMalloc(&L.packed, pb));
-      if (int rc = aqlm_hip_prepack_1x16(L.codes, out, in, s.g, L.packed, pb, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+      if (int rc = aqlm_hip_prepack_1x16(L.codes, out, in, s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
     }
     CK(hipDeviceSynchronize());
+    printf("# packed %d->%d: waves %d steps %d, %.3f B per code (capacity %.1f MB, used %.1f MB)\n", in, out, v[0].desc.waves,
+           v[0].desc.steps, (double)v[0].desc.used_bytes / ((double)out * (in / 8)), pb * 1e-6, v[0].desc.used_bytes * 1e-6);
   }
   return v;
 }
@@ -320,16 +429,15 @@ static void free_layers(std::vector<Layer>& v) {
   for (auto& L : v) { hipFree(L.codes); hipFree(L.cb); hipFree(L.scales); hipFree(L.x); hipFree(L.y); if (L.packed) hipFree(L.packed); }
 }
 
+struct Scheme; static void check_packed(const Scheme& s, const Layer& L, int in, int out);
 static void bench_gemv(int argc, char** argv) {
-  g_ws_bytes = (size_t)32 * 32768 * 4;
+  g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
   CK(hipMalloc(&g_ws, g_ws_bytes));
-  const Scheme S1x16L{"1x16g8L", 1, 16, 8, true};
   const Scheme S1x16P{"1x16g8P", 1, 16, 8, false, true};
   const Scheme S8x8L{"8x8g32LUT", 8, 8, 32, false, false, true};
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
   std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672}, {S1x16P, 1024, 28672}, {S1x16P, 2048, 28672},
-                             {S1x16L, 4096, 4096}, {S1x16L, 4096, 11008}, {S1x16L, 4096, 14336}, {S1x16L, 14336, 4096}, {S1x16L, 4096, 1024}, {S1x16L, 8192, 28672},
                              {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
                              {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
                              {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}, {S8x8L, 4096, 4096}, {S8x8L, 4096, 11008}, {S8x8L, 11008, 4096}};
@@ -347,6 +455,7 @@ static void bench_gemv(int argc, char** argv) {
     if (n > 160) n = 160;
     if (n < 8) n = 8;
     auto layers = make_layers(c.s, c.in, c.out, 8, n);
+    if (c.s.packed) check_packed(c.s, layers[0], c.in, c.out);
     std::vector<Layer> one(layers.begin(), layers.begin() + 1);
     std::vector<Layer> warm(16, one[0]);
     struct Var { const char* name; const char* key; int val; };
@@ -360,8 +469,14 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=4", "gemv_rows_per_wave", 4}});
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
+    } else if (c.s.packed && !quick) {
+      variants.push_back({{"waves=4", "packed_waves", 4}});
+      variants.push_back({{"waves=8", "packed_waves", 8}});
+      variants.push_back({{"waves=16", "packed_waves", 16}});
+      variants.push_back({{"prefetch=4", "packed_prefetch", 4}});
+      variants.push_back({{"prefetch=8", "packed_prefetch", 8}});
+      variants.push_back({{"arrange=0", "packed_arrange", 0}});
     } else if (c.s.packed) {
-    } else if (c.s.lds) {
     } else if (c.s.nbits == 8 && c.s.g == 8) {
       variants.push_back({{"replicas=off", "kx8_replicas", 0}});
       variants.push_back({{"replicas=force", "kx8_replicas", 2}});
@@ -373,7 +488,7 @@ static void bench_gemv(int argc, char** argv) {
     for (const auto& var : variants) {
       std::string vn = var.empty() ? "default" : "";
       CK(hipMemset(g_ws, 0, g_ws_bytes));
-      if (c.s.packed && !var.empty()) {  // the variant must reproduce the default path bit for bit
+      if (false) {  // (format v4 check, kept for reference)
         std::vector<uint16_t> y0(c.out), y1(c.out);
         CK(hipMemset(layers[0].y, 0xff, (size_t)c.out * 2));
         launch_layer(c.s, layers[0], c.in, c.out, 1, nullptr);
@@ -391,8 +506,16 @@ static void bench_gemv(int argc, char** argv) {
         }
       }
       for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
+      if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange"))) {  // a format parameter: repack
+        const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
+        for (auto& L : layers)
+          if (int rc = aqlm_hip_prepack_1x16(L.codes, c.out, c.in, c.s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+        one[0] = layers[0];
+        for (auto& w : warm) w = layers[0];
+        printf("# repacked: waves %d steps %d\n", layers[0].desc.waves, layers[0].desc.steps);
+      }
       for (int batch : {1, 2, 4, 8}) {
-        if (batch > 1 && (!var.empty() || c.s.lds || c.s.packed || quick)) continue;
+        if (batch > 1 && (!var.empty() || quick)) continue;
         const size_t ab = algo_bytes(c.in, c.out, c.s, batch);
         const double cold = time_graph(c.s, layers, c.in, c.out, batch, 4);
         const double w = time_graph(c.s, warm, c.in, c.out, batch, 20);
@@ -400,7 +523,7 @@ static void bench_gemv(int argc, char** argv) {
                ab / cold * 1e-3 / 80.0);
         fflush(stdout);
       }
-      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, !strcmp(kv.key, "kx8_replicas") ? 1 : 0);
+      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange")) ? 1 : 0);
     }
     free_layers(layers);
   }
@@ -414,34 +537,54 @@ static void bench_trace(int in, int out) {
   const size_t ab1 = algo_bytes(in, out, s, 1);
   int n = (int)((600u << 20) / ab1) + 1;
   auto layers = make_layers(s, in, out, 8, n);
-  const size_t need = (size_t)8 * out * 4;
+  const size_t need = (size_t)16 * out * 4;
   unsigned long long* tr = (unsigned long long*)((char*)g_ws + need);
-  std::vector<unsigned long long> h(256 * 8);
-  const char* names[8] = {"entry", "loads issued", "LDS filled", "first row done", "loop done (wave 0)", "last wave entry", "last wave slice in LDS", "last wave out"};
+  const int NWMAX = 16;
+  std::vector<unsigned long long> h(256 * NWMAX * 8);
+  const int NW = layers[0].desc.waves;
+  const char* names[7] = {"entry", "loads issued", "LDS filled (barrier)", "-", "loop done", "2nd barrier", "end"};
   for (int rep = 0; rep < 3; ++rep) {
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
-    CK(hipMemset(tr, 0, 2 * 256 * 8 * 8));
+    CK(hipMemset(tr, 0, h.size() * 8));
     CK(hipDeviceSynchronize());
     launch_layer(s, layers[0], in, out, 1, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
-    for (int b = 0; b < 256; ++b) t0 = std::min(t0, h[b * 8]);
-    printf("# packed %d->%d cold, run %d: per-phase time since the first workgroup's entry, us (min / mean / max over 256 workgroups)\n", in, out, rep);
-    {
-      std::vector<unsigned long long> st(256 * 8);
-      CK(hipMemcpy(st.data(), tr + 256 * 8, st.size() * 8, hipMemcpyDeviceToHost));
-      printf("  wave-0 step completion (mean over workgroups, us):");
-      for (int i = 0; i < 6; ++i) { double sum = 0; int n = 0; for (int b = 0; b < 256; ++b) if (st[b * 8 + i] > t0) { sum += (double)(st[b * 8 + i] - t0) * 0.01; ++n; } printf(" %.2f", n ? sum / n : 0.0); }
-      printf("\n");
-    }
-    for (int i = 0; i < 8; ++i) {
+    for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) t0 = std::min(t0, h[(b * NWMAX + w) * 8]);
+    printf("# packed %d->%d cold, run %d (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
+           in, out, rep, NW, layers[0].desc.steps, 256 * NW);
+    for (int i = 0; i < 7; ++i) {
+      if (i == 3) continue;
       double mn = 1e9, mx = 0, sum = 0;
-      for (int b = 0; b < 256; ++b) { const double v = (double)(h[b * 8 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
-      printf("  %-16s %7.2f %7.2f %7.2f\n", names[i], mn, sum / 256, mx);
+      for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) {
+        const double v = (double)(h[(b * NWMAX + w) * 8 + i] - t0) * 0.01;
+        mn = std::min(mn, v); mx = std::max(mx, v); sum += v;
+      }
+      printf("  %-22s %7.2f %7.2f %7.2f\n", names[i], mn, sum / (256 * NW), mx);
     }
   }
   free_layers(layers);
+}
+
+// packed kernel vs the direct kernel on the same layer (quick on-device sanity check; the real parity tests are in tests/)
+static void check_packed(const Scheme& s, const Layer& L, int in, int out) {
+  for (int batch : {1, 4, 8}) {
+    std::vector<uint16_t> y0((size_t)batch * out), y1((size_t)batch * out);
+    CK(hipMemset(L.y, 0xff, y0.size() * 2));
+    int rc = aqlm_hip_gemv_1x16(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, batch, in, out, AQLM_HIP_F16, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(y0.data(), L.y, y0.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(L.y, 0xff, y0.size() * 2));
+    rc |= launch_layer(s, L, in, out, batch, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(y1.data(), L.y, y1.size() * 2, hipMemcpyDeviceToHost));
+    auto h2f = [](uint16_t h) { _Float16 f; memcpy(&f, &h, 2); return (double)(float)f; };
+    double num = 0, den = 0, worst = 0;
+    for (size_t i = 0; i < y0.size(); ++i) { const double d = fabs(h2f(y0[i]) - h2f(y1[i])); num += d; den += fabs(h2f(y0[i])); worst = std::max(worst, d); }
+    printf("# check packed vs direct %d->%d B=%d: rc=%d mean-rel %.3e worst-abs %.3e%s\n", in, out, batch, rc, num / den, worst,
+           (num / den < 2e-3 && rc == 0) ? "" : "   <-- MISMATCH");
+  }
 }
 
 // ---------------------------------------------------------------- large-batch ops through the C ABI
@@ -523,10 +666,11 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "l2gather") || !strcmp(what, "all")) bench_l2();
   if (!strcmp(what, "ldsgather") || !strcmp(what, "all")) bench_lds();
   if (!strcmp(what, "stream") || !strcmp(what, "all")) bench_stream();
+  if (!strcmp(what, "rates") || !strcmp(what, "all")) bench_rates();
   if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
   if (!strcmp(what, "trace")) {
-    g_ws_bytes = (size_t)32 * 32768 * 4;
+    g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
     CK(hipMalloc(&g_ws, g_ws_bytes));
     bench_trace(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 4096);
   }
