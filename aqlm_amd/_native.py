@@ -41,15 +41,16 @@ class PackedDesc(ctypes.Structure):
     _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint32), ("out_features", ctypes.c_int32),
                 ("in_features", ctypes.c_int32), ("slices_log2", ctypes.c_int32), ("waves", ctypes.c_int32),
                 ("steps", ctypes.c_int32), ("entry_bytes", ctypes.c_int32), ("used_bytes", ctypes.c_uint64),
-                ("reserved", ctypes.c_uint64)]
+                ("x_copies", ctypes.c_uint64)]
 
     def as_ints(self):
         return [int(self.magic), int(self.version), int(self.out_features), int(self.in_features),
-                int(self.slices_log2), int(self.waves), int(self.steps), int(self.entry_bytes), int(self.used_bytes)]
+                int(self.slices_log2), int(self.waves), int(self.steps), int(self.entry_bytes), int(self.used_bytes),
+                int(self.x_copies)]
 
     @classmethod
     def from_ints(cls, v):
-        return cls(*[int(x) for x in v[:9]], 0)
+        return cls(*[int(x) for x in v[:10]])
 
 
 _descp = ctypes.POINTER(PackedDesc)

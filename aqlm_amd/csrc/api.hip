@@ -58,6 +58,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "packed_waves")) return &t.packed_waves;
   if (!strcmp(key, "packed_prefetch")) return &t.packed_prefetch;
   if (!strcmp(key, "packed_arrange")) return &t.packed_arrange;
+  if (!strcmp(key, "packed_xcopies")) return &t.packed_xcopies;
   return nullptr;
 }
 

@@ -137,6 +137,7 @@ struct Tuning {
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
   int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel), 0 = ascending j
+  int packed_xcopies = 0;        // prepack: cap on the rotated copies of x the batch-1 kernel keeps (1..4); 0 = as many as fit
   int packed_prefetch = 0;       // packed 1x16 kernel: steps of the entry stream in flight per wave (4 / 8); 0 = heuristic
 };
 Tuning& tuning();

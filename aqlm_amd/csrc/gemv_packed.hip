@@ -49,8 +49,17 @@ constexpr int PK_MAX_GROUPS = 4094;          // j needs 12 bits, in_groups itsel
 constexpr uint32_t PK_MAGIC = 0x35505141u;   // "AQP5"
 constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (x first, slice behind it)
 
+// x copies (batch-1 kernel): copy c of x starts at 16-B slot c * stride with stride = 4 (mod 16), i.e. its bank-group
+// pattern is rotated by 4 c: an entry can read the copy whose bank group is still free in its service group.
+__host__ __device__ static inline int pk_x_stride(int in_groups) { return ((in_groups + 1 + 11) & ~15) + 4; }  // >= in_groups + 1
+static inline int pk_max_x_copies(int in_groups) { return std::max(1, std::min(4, 4095 / pk_x_stride(in_groups))); }
+// start row of a column: 15 bits over the low nibbles of its first lane-step (entry 0: bits 1-3, entries 1-3: bits 0-3)
+__host__ __device__ static inline uint32_t pk_get_start_row(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3) {
+  return ((e0 >> 1) & 7u) | ((e1 & 15u) << 3) | ((e2 & 15u) << 7) | ((e3 & 15u) << 11);
+}
+
 struct PackedLayout {
-  int M, in_groups, RG, NW, T;
+  int M, in_groups, RG, NW, T, XC;
   size_t nst, off_winfo, off_rowstart, off_ent, ent_bytes, used;
 };
 
@@ -61,8 +70,10 @@ static bool packed_shape_ok(int out_features, int in_features, int g) {
          (out_features + PK_NG - 1) / PK_NG <= 32767 - PK_MAX_NW;
 }
 
-static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L) {
+static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1) {
   if (!packed_shape_ok(out_features, in_features, 8) || NW < 1 || NW > PK_MAX_NW || T < 1 || T > PK_MAX_T) return false;
+  if (XC < 1 || XC > pk_max_x_copies(in_features / 8)) return false;
+  L.XC = XC;
   L.M = out_features;
   L.in_groups = in_features / 8;
   L.RG = (out_features + PK_NG - 1) / PK_NG;
@@ -79,14 +90,24 @@ static bool packed_layout(int out_features, int in_features, int NW, int T, Pack
 
 static bool desc_layout(const aqlm_hip_packed_desc* d, PackedLayout& L) {
   return d && d->magic == PK_MAGIC && d->version == 5 && d->entry_bytes == 4 && d->slices_log2 == PK_S_LOG &&
-         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L) && L.used == d->used_bytes;
+         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L, (int)d->x_copies) && L.used == d->used_bytes;
 }
 
-// wave-steps of work per workgroup -> waves per workgroup
+// Wave-steps of work in the longest stream -> waves per workgroup.  Large layers: 16 waves (measured: 13-15 waves with
+// fewer wasted tail steps are 10-18 % slower on the 14336-wide shapes -- parallelism beats bytes).  Small layers
+// (< 48 wave-steps per workgroup): the wave ranges have T = ceil(q / NW) steps each, so the capacity NW * T overshoots
+// the content by up to NW - 1 steps, a large share of such a layer: pick 4..8 waves with the least overshoot.
 static int choose_waves(uint32_t max_lane_steps) {
-  const uint32_t q = (max_lane_steps + 63) / 64;
-  if (tuning().packed_waves == 4 || tuning().packed_waves == 8 || tuning().packed_waves == 16) return tuning().packed_waves;
-  return q >= 64 ? 16 : (q >= 24 ? 8 : 4);
+  const int q = (int)((max_lane_steps + 63) / 64);
+  if (tuning().packed_waves >= 1 && tuning().packed_waves <= PK_MAX_NW) return tuning().packed_waves;
+  if (q >= 48) return 16;
+  int best = 8, best_cost = 1 << 30;
+  for (int nw = 8; nw >= 4; --nw) {
+    const int t = (q + nw - 1) / nw;
+    const int cost = (nw * t - q) * 8 + (8 - nw);
+    if (cost < best_cost) { best_cost = cost; best = nw; }
+  }
+  return best;
 }
 
 // ------------------------------------------------------------------------------------------------ prepack
@@ -187,51 +208,46 @@ __global__ __launch_bounds__(256) void pk_scatter_kernel(const uint16_t* codes, 
 // one ds_read_b128 for the codebook vectors, one for the x vectors.  The LDS services such a read in four groups of 16
 // lanes (MI355X_MICROARCH.md: {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) and needs one extra cycle for every lane whose
 // 16-B slot falls into a bank group (slot % 16) another lane of its group already uses: random slots cost ~3 cycles per
-// group instead of 1, for both reads, and the loop is LDS-bound (traced: 0.36 us per step for 8 waves).  A row's entries
-// may be summed in any order, so inside every ROW PIECE of a lane column (the consecutive lane-steps of one row within
-// the column) this kernel re-deals the entries over the piece's slots: greedy, slot by slot; within a slot the 16 lanes
-// of a service group choose one after the other (rotating priority), each taking from its own piece an entry whose x
-// bank group AND codebook bank group are still free in its service group (else a null entry -- all nulls read the same
-// two addresses, which the LDS broadcasts --, else one that is free in one of the two).  Fixed order of choices ->
-// deterministic layout.  One wave per (stream, wave range), lane = column; columns of more than 32 steps are left in
-// ascending-j order.
+// group instead of 1 for both reads, and the loop is LDS-bound.  Two freedoms are used against that:
+//   * a row's entries may be summed in any order: inside a wave range the entries of a row form a POOL that is re-dealt
+//     over the row's slots (greedy, slot by slot; within a slot the lanes of a service group choose one after the other
+//     with rotating priority; a lane takes from its row's pool the first entry whose codebook bank group AND x bank group
+//     are still free in its service group, else a null entry -- all nulls read the same two addresses, which the LDS
+//     broadcasts --, else one that is free in one of the two);
+//   * x is small: the batch-1 kernel keeps XC copies of it in LDS, copy c rotated by 4 c bank groups, and an entry names
+//     the copy it reads -- so the x side almost always finds a free bank group and the pool choice serves the codebook.
+// The order of choices is fixed -> the layout is deterministic.  One wave per (stream, wave range): the 64 lanes scan
+// the pool in parallel, the picks themselves are sequential.  Wave ranges of more than 32 steps keep ascending-j order.
 constexpr int PK_ARR_MAX_T = 32;
 
-__device__ __forceinline__ int pk_service_group(int l) {  // 0..3
-  const int h = l & 31;
-  const bool g0 = h < 4 || (h >= 12 && h < 16) || (h >= 20 && h < 28);
-  return (l >> 5) * 2 + (g0 ? 0 : 1);
-}
-__device__ __forceinline__ int pk_group_pos(int l) {  // 0..15: position of the lane inside its service group
-  const int h = l & 31;
-  if (h < 4) return h;                 // G0: 0-3
-  if (h < 12) return h - 4;            // G1: 4-11 -> 0-7
-  if (h < 16) return h - 12 + 4;       // G0: 12-15 -> 4-7
-  if (h < 20) return h - 16 + 8;       // G1: 16-19 -> 8-11
-  if (h < 28) return h - 20 + 8;       // G0: 20-27 -> 8-15
-  return h - 28 + 12;                  // G1: 28-31 -> 12-15
+__device__ __forceinline__ int pk_group_lane(int grp, int pos) {  // inverse of (service group, position) -> lane
+  const int half = grp >> 1, g1 = grp & 1;
+  int h;
+  if (!g1) h = pos < 4 ? pos : (pos < 8 ? pos + 8 : pos + 12);          // G0: 0-3, 12-15, 20-27
+  else h = pos < 8 ? pos + 4 : (pos < 12 ? pos + 8 : pos + 16);          // G1: 4-11, 16-19, 28-31
+  return half * 32 + h;
 }
 
 __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint32_t* ent, int M, int in_groups, int RG, int NW,
-                                                        int T) {
+                                                        int T, int XC) {
   extern __shared__ uint32_t arr_sm[];
-  uint32_t* in = arr_sm;                                              // [T][64][4]
-  unsigned char* pbeg = reinterpret_cast<unsigned char*>(in + (size_t)T * 256);  // [T][64] first step of the slot's piece
-  unsigned char* pend = pbeg + (size_t)T * 64;                       // [T][64] one past its last step
-  uint32_t* gmask = reinterpret_cast<uint32_t*>(pend + (size_t)T * 64);  // [4][2] bank groups taken in the current slot
+  uint32_t* pool = arr_sm;                                                   // [64 * T * 4] entries in (lane, t, k) order
+  uint16_t* rowa = reinterpret_cast<uint16_t*>(pool + (size_t)T * 256);    // [64 * T] first lane-step (in the wave range) of the slot's row
+  uint16_t* rem = rowa + (size_t)T * 64;                                    // [64 * T] entries left in the pool of the row starting at that lane-step
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
   const int g = (int)(st / PK_S);
   const int nrows = std::min(RG, std::max(0, M - g * RG));
   const uint32_t* starts = a + st * (RG + 1);
   const uint32_t total = starts[nrows];
-  uint32_t* col = ent + ((((size_t)st * NW + w) * T) * 64 + l) * 4;   // + t * 256
-  const uint32_t q0 = ((uint32_t)w * 64u + (uint32_t)l) * (uint32_t)T;
+  uint32_t* wave_ent = ent + (((size_t)st * NW + w) * T) * 256;             // + (t * 64 + lane) * 4 + k
+  const uint32_t w0 = (uint32_t)w * 64u * (uint32_t)T;
+  const uint32_t q0 = w0 + (uint32_t)l * (uint32_t)T;
   for (int t = 0; t < T; ++t) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)t * 256);
-    *reinterpret_cast<u32x4*>(in + ((size_t)t * 64 + l) * 4) = v;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wave_ent + ((size_t)t * 64 + l) * 4);
+    *reinterpret_cast<u32x4*>(pool + ((size_t)l * T + t) * 4) = v;
   }
-  {  // piece bounds of every step of this column
+  {  // row range of every lane-step of this column, clipped to the wave range
     int r = nrows;
     if (q0 < total) {  // last r with starts[r] <= q0
       int lo = 0, hi = nrows;
@@ -243,57 +259,74 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
     }
     for (int t = 0; t < T; ++t) {
       const uint32_t q = q0 + (uint32_t)t;
-      int b = t, e = t + 1;  // trailing null steps: pieces of one step
+      uint32_t ra = q - w0, rb = ra + 1;  // trailing null lane-steps: pools of one step
       if (q < total) {
         while (starts[r + 1] <= q) ++r;
         const uint32_t rs = starts[r], re = starts[r + 1];
-        b = rs > q0 ? (int)(rs - q0) : 0;
-        e = re < q0 + (uint32_t)T ? (int)(re - q0) : T;
+        ra = rs > w0 ? rs - w0 : 0u;
+        rb = re < w0 + 64u * (uint32_t)T ? re - w0 : 64u * (uint32_t)T;
       }
-      pbeg[t * 64 + l] = (unsigned char)b;
-      pend[t * 64 + l] = (unsigned char)e;
+      rowa[l * T + t] = (uint16_t)ra;
+      if (q - w0 == ra) rem[ra] = (uint16_t)((rb - ra) * 4u);
     }
   }
-  if (l < 8) gmask[l] = 0u;
   __syncthreads();
-  const int grp = pk_service_group(l), pos = pk_group_pos(l);
-  unsigned long long used_lo = 0ull, used_hi = 0ull;  // bit (t * 4 + k) of this column's entries already dealt
   const uint32_t null_j = (uint32_t)in_groups;
+  const uint32_t xstride = (uint32_t)pk_x_stride(in_groups);
   for (int s = 0; s < 4 * T; ++s) {
     const int t = s >> 2, k = s & 3;
-    const int rank = (pos + s) & 15;
-    for (int r = 0; r < 16; ++r) {
-      if (rank == r) {
-        const uint32_t ux = gmask[grp * 2], uc = gmask[grp * 2 + 1];
-        const int b = pbeg[t * 64 + l], e = pend[t * 64 + l];
-        int best = -1, best_score = -1;
-        uint32_t best_v = 0u;
-        for (int i = b * 4; i < e * 4 && best_score < 4; ++i) {
-          const bool is_used = i < 64 ? ((used_lo >> i) & 1ull) : ((used_hi >> (i - 64)) & 1ull);
-          if (is_used) continue;
-          const uint32_t v = in[((size_t)(i >> 2) * 64 + l) * 4 + (i & 3)];
+    for (int grp = 0; grp < 4; ++grp) {
+      uint32_t ux = 0u, uc = 0u;  // bank groups taken in this (slot, service group); wave-uniform
+      bool null_placed = false;   // the null entry's two addresses are already being read (further nulls are free)
+      const uint32_t null_x = 1u << (null_j & 15u), null_c = 1u;
+      for (int r = 0; r < 16; ++r) {
+        const int tl = pk_group_lane(grp, (r - s) & 15);  // the lane whose turn it is
+        const uint32_t ra = rowa[tl * T + t];
+        const uint32_t n = rem[ra];
+        const uint32_t base = ra * 4u;
+        uint32_t key = 0u;  // (score + 1) << 20 | copy << 16 | (0xffff - index): the maximum is the best, lowest-index candidate
+        for (uint32_t i = (uint32_t)l; i < n; i += 64u) {
+          const uint32_t v = pool[base + i];
           const uint32_t j = v >> 20;
-          int score;
-          if (j == null_j) score = 3;
+          uint32_t score, copy = 0u;
+          if (j == null_j) score = (null_placed || (!(ux & null_x) && !(uc & null_c))) ? 3u : 0u;
           else {
-            const bool xf = !((ux >> (j & 15u)) & 1u), cf = !((uc >> ((v >> 4) & 15u)) & 1u);
-            score = xf && cf ? 4 : (xf ? 2 : (cf ? 1 : 0));
+            const bool cf = !((uc >> ((v >> 4) & 15u)) & 1u);
+            bool xf = false;
+            for (uint32_t c = 0; c < (uint32_t)XC; ++c)
+              if (!((ux >> ((j + 4u * c) & 15u)) & 1u)) { xf = true; copy = c; break; }
+            score = xf && cf ? 4u : (xf ? 2u : (cf ? 1u : 0u));
           }
-          if (score > best_score) { best_score = score; best = i; best_v = v; }
+          const uint32_t kk = ((score + 1u) << 20) | (copy << 16) | (0xffffu - i);
+          key = kk > key ? kk : key;
         }
-        // every slot of a piece has an entry left: pieces hold exactly 4 * (e - b) entries
-        if (best < 0) __builtin_trap();
-        if (best < 64) used_lo |= 1ull << best; else used_hi |= 1ull << (best - 64);
-        col[(size_t)t * 256 + k] = best_v;
-        if ((best_v >> 20) != null_j) {
-          gmask[grp * 2] = ux | (1u << ((best_v >> 20) & 15u));
-          gmask[grp * 2 + 1] = uc | (1u << ((best_v >> 4) & 15u));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)key, o, WAVE);
+          key = other > key ? other : key;
         }
+        if (key == 0u) __builtin_trap();  // every slot of a row has an entry left in the row's pool
+        const uint32_t idx = 0xffffu - (key & 0xffffu), copy = (key >> 16) & 3u;
+        const uint32_t v = pool[base + idx];           // same address in every lane: broadcast
+        const uint32_t j = v >> 20;
+        if (j != null_j) {
+          ux |= 1u << ((j + 4u * copy) & 15u);
+          uc |= 1u << ((v >> 4) & 15u);
+        } else {
+          ux |= null_x;
+          uc |= null_c;
+          null_placed = true;
+        }
+        __syncthreads();  // everybody has read pool[base + idx] and rem[ra]
+        if (l == 0) {
+          const uint32_t out = j == null_j ? v : ((v & 0x000fffffu) | ((j + copy * xstride) << 20) | (copy << 16));
+          wave_ent[((size_t)t * 64 + tl) * 4 + k] = out;
+          pool[base + idx] = pool[base + n - 1u];      // swap-remove
+          rem[ra] = (uint16_t)(n - 1u);
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
-    if (l < 8) gmask[l] = 0u;
-    __syncthreads();
   }
 }
 
@@ -345,14 +378,17 @@ __global__ __launch_bounds__(64) void pk_column_kernel(const uint32_t* a, uint32
   }
   const uint32_t f = (uint32_t)r0;
   uint32_t* e = ent + ((((size_t)st * NW + w) * T + 0) * 64 + l) * 4;
-  e[0] |= ((f & 7u) << 1) | (((f >> 3) & 15u) << 16);
-  e[1] |= ((f >> 7) & 15u) | (((f >> 11) & 15u) << 16);
+  e[0] |= (f & 7u) << 1;
+  e[1] |= (f >> 3) & 15u;
+  e[2] |= (f >> 7) & 15u;
+  e[3] |= (f >> 11) & 15u;
 }
 
 // inverse of the repack: canonical codes [M][in_groups] from a packed buffer (lossless; used to drop / restore the
 // canonical codes of inference-only models and by the tests).  One wave per (stream, wave range).
 __global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, const uint32_t* winfo, uint16_t* codes, int M,
                                                        int in_groups, int RG, int NW, int T) {
+  const int xstride = pk_x_stride(in_groups);
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
   const int g = (int)(st / PK_S), s = (int)(st % PK_S);
@@ -362,13 +398,13 @@ __global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, cons
   int local = 0;
   for (int t = 0; t < steps; ++t) {
     const uint32_t* e = col + (size_t)t * 256;
-    const uint32_t e0 = e[0], e1 = e[1];
-    if (t == 0) local = (int)(((e0 >> 1) & 7u) | (((e0 >> 16) & 15u) << 3) | ((e1 & 15u) << 7) | (((e1 >> 16) & 15u) << 11));
+    const uint32_t e0 = e[0];
+    if (t == 0) local = (int)pk_get_start_row(e0, e[1], e[2], e[3]);
     const int row = g * RG + local;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t v = e[k];
-      const int j = (int)(v >> 20);
+      const int j = (int)(v >> 20) - (int)((v >> 16) & 3u) * xstride;
       if (j < in_groups && row < M) codes[(size_t)row * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | ((v >> 4) & 0xfffu));
     }
     local += (int)(e0 & 1u);
@@ -384,7 +420,7 @@ struct PackedGemvParams {
   const uint16_t* x;
   float* partial;  // [S][B][M]
   long x_row_stride;
-  int M, in_groups, RG, NW, T;
+  int M, in_groups, RG, NW, T, XC;
   uint32_t ent_bytes;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
@@ -466,6 +502,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 
   // ---- prologue: everything that needs no other data is issued first, in one burst -------------------------------
   const uint32_t XP = LDS::plane(p.in_groups);
+  const uint32_t xstride16 = (uint32_t)pk_x_stride(p.in_groups) * 16u;
   // (1) LDS-DMA: the 64 KiB slice (shared by the 16 workgroups of the XCD that hold it -> L2 hits) and x
   {
     const uint8_t* src = p.codebook + (size_t)slice * PK_SLICE_BYTES;
@@ -473,12 +510,15 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
       __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + i * 1024 + lane * 16),
                                        (lds_void_ptr)(size_t)(LDS::SLICE + (uint32_t)i * 1024u), 16, 0, 0);
     const int nchunk = (p.in_groups + 63) >> 6;  // KiB pieces per row of x
-    for (int c = wave; c < nchunk * B; c += NWB) {
-      const int b = B == 1 ? 0 : c / nchunk, i = c - b * nchunk;
+    // B == 1: XC rotated copies of the row (copy c at slot c * xstride); B > 1: one plane per row
+    const int ncopy = B == 1 ? p.XC : B;
+    for (int c = wave; c < nchunk * ncopy; c += NWB) {
+      const int b = c / nchunk, i = c - b * nchunk;
       const int idx = i * 64 + lane;
+      const uint32_t dst = LDS::X + (uint32_t)b * (B == 1 ? xstride16 : XP) + (uint32_t)i * 1024u;
       if (idx < p.in_groups)
-        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.x + (size_t)b * p.x_row_stride + (size_t)idx * 8),
-                                         (lds_void_ptr)(size_t)(LDS::X + (uint32_t)b * XP + (uint32_t)i * 1024u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.x + (B == 1 ? (size_t)0 : (size_t)b * p.x_row_stride) + (size_t)idx * 8),
+                                         (lds_void_ptr)(size_t)dst, 16, 0, 0);
     }
     // the stream's row starts (needed by the epilogue only; as an LDS-DMA they are older than the ring loads, see (5)).
     // Rows of the table are only 4-B aligned -> dword DMA, 256 B per wave-instruction.
@@ -531,7 +571,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
       const u32x4 xv = *(lds_u32x4_ptr)(size_t)(a_x + LDS::X);
       acc[0] = dot8<T_>(e, xv, acc[0]);
     } else {
-      a_x += LDS::X;
+      a_x += LDS::X - ((w >> 16) & 3u) * xstride16;  // the entry names a copy of x; the planes hold one
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         const u32x4 xv = *(lds_u32x4_ptr)(size_t)(a_x + (uint32_t)b * XP);
@@ -557,8 +597,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 
   if (steps > 0) {
     {  // the column's starting row rides in the spare bits of its first lane-step
-      const uint32_t e0 = ring[0].x, e1 = ring[0].y;
-      const uint32_t f = ((e0 >> 1) & 7u) | (((e0 >> 16) & 15u) << 3) | ((e1 & 15u) << 7) | (((e1 >> 16) & 15u) << 11);
+      const uint32_t f = pk_get_start_row(ring[0].x, ring[0].y, ring[0].z, ring[0].w);
       row_addr = rowval_off + f * 4u;
     }
     int t = 0;
@@ -622,7 +661,7 @@ struct PackedSegment {
   const uint32_t* rowstart;
   const uint8_t* codebook;
   float* partial;
-  int M, RG, NW, T;
+  int M, RG, NW, T, XC;
   uint32_t ent_bytes;
 };
 
@@ -652,6 +691,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const Pack
       p.RG = mp.seg[k].RG;
       p.NW = mp.seg[k].NW;
       p.T = mp.seg[k].T;
+      p.XC = mp.seg[k].XC;
       p.ent_bytes = mp.seg[k].ent_bytes;
     }
   }
@@ -823,8 +863,11 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
   const int NW = choose_waves(maxL);
   const int T = (int)((maxL + 64u * NW - 1) / (64u * NW));
+  const bool arrange = tuning().packed_arrange && T <= PK_ARR_MAX_T;
+  int XC = arrange ? pk_max_x_copies(in_groups) : 1;
+  if (tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(XC, tuning().packed_xcopies);
   PackedLayout L;
-  if (!packed_layout(M, in_features, NW, T, L) || L.used > packed_bytes) {
+  if (!packed_layout(M, in_features, NW, T, L, XC) || L.used > packed_bytes) {
     set_last_error("aqlm_hip_prepack_1x16: codes too unevenly spread over the codebook slices for the packed format "
                    "(longest stream %u lane-steps, %d steps per wave)", maxL, T);
     return AQLM_HIP_E_UNSUPPORTED;
@@ -841,13 +884,14 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   d.steps = T;
   d.entry_bytes = 4;
   d.used_bytes = L.used;
+  d.x_copies = (uint64_t)XC;
   if (int e = check_hip(hipMemcpyAsync(base, &d, sizeof(d), hipMemcpyHostToDevice, stream), "prepack header")) return e;
   const uint32_t null_entry = (uint32_t)in_groups << 20;
   hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L.ent_bytes / 4, null_entry);
   hipLaunchKernelGGL(pk_scatter_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, ent, M, in_groups, RG, NW, T);
-  if (tuning().packed_arrange && T <= PK_ARR_MAX_T)
-    hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 128 + 64, stream, a,
-                       ent, M, in_groups, RG, NW, T);
+  if (arrange)
+    hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 256, stream, a,
+                       ent, M, in_groups, RG, NW, T, XC);
   hipLaunchKernelGGL(pk_flag_kernel, dim3((RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, M, RG, NW, T);
   hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, M, RG, NW, T);
   if (int e = check_hip(hipGetLastError(), "prepack launch")) return e;
@@ -936,6 +980,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
     p.RG = L.RG;
     p.NW = L.NW;
     p.T = L.T;
+    p.XC = L.XC;
     p.ent_bytes = (uint32_t)L.ent_bytes;
 #ifdef AQLM_PACKED_TRACE
     p.trace = workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
@@ -1015,6 +1060,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     ps.RG = L.RG;
     ps.NW = L.NW;
     ps.T = L.T;
+    ps.XC = L.XC;
     ps.ent_bytes = (uint32_t)L.ent_bytes;
     mp.in_groups = L.in_groups;
     max_rg = std::max(max_rg, L.RG);

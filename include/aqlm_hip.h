@@ -185,7 +185,7 @@ typedef struct aqlm_hip_packed_desc {
   int32_t steps;       /* KiB steps per wave range */
   int32_t entry_bytes; /* 4 */
   uint64_t used_bytes;
-  uint64_t reserved;
+  uint64_t x_copies;   /* rotated copies of x the batch-1 kernel keeps in LDS (1..4); entries name the copy they read */
 } aqlm_hip_packed_desc;
 
 size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size);

@@ -31,11 +31,15 @@ def align_up(v, a):
 
 def choose_waves(max_lane_steps):
     q = (max_lane_steps + 63) // 64  # wave-steps of work per workgroup
-    if q >= 64:
+    if q >= 48:
         return 16
-    if q >= 24:
-        return 8
-    return 4
+    best, best_cost = 8, 1 << 30
+    for nw in range(8, 3, -1):
+        t = (q + nw - 1) // nw
+        cost = (nw * t - q) * 8 + (8 - nw)
+        if cost < best_cost:
+            best, best_cost = nw, cost
+    return best
 
 
 def layout(M, in_groups, NW, T):

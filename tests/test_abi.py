@@ -100,7 +100,7 @@ def test_segment_struct_and_multi_validation(native):
     rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(bad), p, p, p, None, p, p, 1, 512, 64, native.F16, p, 1 << 20, None)
     assert rc == native.E_INVALID and "descriptor" in native.last_error()
     # 64 rows -> 4 per row group; winfo (sized for 16 waves) + row starts (256 x 5 u32) end at 70 KiB, then 256 x 4 x 1 KiB
-    good = native.PackedDesc(0x35505141, 5, 64, 512, 4, 4, 1, 4, 1024 * (70 + 1024), 0)
+    good = native.PackedDesc(0x35505141, 5, 64, 512, 4, 4, 1, 4, 1024 * (70 + 1024), 4)   # ... and 4 copies of x
     back = native.PackedDesc.from_ints(good.as_ints())
     assert bytes(back) == bytes(good)
     rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(good), p, p, p, None, p, p, 9, 512, 64, native.F16, p, 1 << 20, None)
