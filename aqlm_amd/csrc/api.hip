@@ -59,6 +59,8 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "packed_prefetch")) return &t.packed_prefetch;
   if (!strcmp(key, "packed_arrange")) return &t.packed_arrange;
   if (!strcmp(key, "packed_xcopies")) return &t.packed_xcopies;
+  if (!strcmp(key, "packed_entry_bytes")) return &t.packed_entry_bytes;
+  if (!strcmp(key, "packed_debug")) return &t.packed_debug;
   return nullptr;
 }
 

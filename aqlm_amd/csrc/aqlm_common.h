@@ -137,7 +137,9 @@ struct Tuning {
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
   int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel), 0 = ascending j
-  int packed_xcopies = 0;        // prepack: cap on the rotated copies of x the batch-1 kernel keeps (1..4); 0 = as many as fit
+  int packed_xcopies = 0;        // prepack: rotated copies of x the batch-1 kernel keeps in LDS (1..4, capped by what fits); 0 = 1
+  int packed_entry_bytes = 0;    // prepack: 0 / 4 = 32-bit entries; 3 = 24-bit entries (wave ranges of <= 32 steps)
+  int packed_debug = 0;          // profiling builds (-DAQLM_PACKED_TRACE) only: 1 = no LDS reads / dots, 2 = no entry stream
   int packed_prefetch = 0;       // packed 1x16 kernel: steps of the entry stream in flight per wave (4 / 8); 0 = heuristic
 };
 Tuning& tuning();

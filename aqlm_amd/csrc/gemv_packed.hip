@@ -58,8 +58,11 @@ __host__ __device__ static inline uint32_t pk_get_start_row(uint32_t e0, uint32_
   return ((e0 >> 1) & 7u) | ((e1 & 15u) << 3) | ((e2 & 15u) << 7) | ((e3 & 15u) << 11);
 }
 
+constexpr int PK_STEP3 = 768;   // bytes of one wave step of 3-byte entries (64 lanes x 12 B)
+constexpr int PK_WREG3 = 776;   // ... per step incl. its 8-B row-end flag word (flag words lead the wave range)
+
 struct PackedLayout {
-  int M, in_groups, RG, NW, T, XC;
+  int M, in_groups, RG, NW, T, XC, EB;
   size_t nst, off_winfo, off_rowstart, off_ent, ent_bytes, used;
 };
 
@@ -70,10 +73,12 @@ static bool packed_shape_ok(int out_features, int in_features, int g) {
          (out_features + PK_NG - 1) / PK_NG <= 32767 - PK_MAX_NW;
 }
 
-static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1) {
+static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1, int EB = 4) {
   if (!packed_shape_ok(out_features, in_features, 8) || NW < 1 || NW > PK_MAX_NW || T < 1 || T > PK_MAX_T) return false;
   if (XC < 1 || XC > pk_max_x_copies(in_features / 8)) return false;
+  if (EB != 4 && !(EB == 3 && T <= 32)) return false;  // 3-byte entries: the row-end flags of a column are one 32-bit mask
   L.XC = XC;
+  L.EB = EB;
   L.M = out_features;
   L.in_groups = in_features / 8;
   L.RG = (out_features + PK_NG - 1) / PK_NG;
@@ -83,14 +88,15 @@ static bool packed_layout(int out_features, int in_features, int NW, int T, Pack
   L.off_winfo = 256;
   L.off_rowstart = align_up(L.off_winfo + L.nst * PK_MAX_NW * 16, 256);         // [nst][RG + 1] u32 (offset independent of NW)
   L.off_ent = align_up(L.off_rowstart + L.nst * (size_t)(L.RG + 1) * 4, 1024);
-  L.ent_bytes = L.nst * NW * T * 1024;
+  L.ent_bytes = L.nst * NW * T * (EB == 3 ? (size_t)PK_WREG3 : (size_t)1024);
   L.used = L.off_ent + L.ent_bytes;
   return L.ent_bytes < ((size_t)1 << 32);  // 32-bit buffer offsets
 }
 
 static bool desc_layout(const aqlm_hip_packed_desc* d, PackedLayout& L) {
-  return d && d->magic == PK_MAGIC && d->version == 5 && d->entry_bytes == 4 && d->slices_log2 == PK_S_LOG &&
-         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L, (int)d->x_copies) && L.used == d->used_bytes;
+  return d && d->magic == PK_MAGIC && d->version == 5 && d->slices_log2 == PK_S_LOG &&
+         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L, (int)d->x_copies, d->entry_bytes) &&
+         L.used == d->used_bytes;
 }
 
 // Wave-steps of work in the longest stream -> waves per workgroup.  Large layers: 16 waves (measured: 13-15 waves with
@@ -384,6 +390,75 @@ __global__ __launch_bounds__(64) void pk_column_kernel(const uint32_t* a, uint32
   e[3] |= (f >> 11) & 15u;
 }
 
+// K6 (3-byte entries): the repack works on the 4-byte layout; this pass squeezes it.  A wave range becomes
+// [T flag words of 8 B: bit l = lane l's lane-step t ends a row][T steps of 64 x 12 B]; an entry is slot << 12 | code
+// (24 bits), four of them in three dwords.  The start row of a column is no longer stored: the kernel derives it from
+// winfo[3] (start row of the wave range's first column) and the flag words.
+__device__ __forceinline__ void pk_pack3(const u32x4& v, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+  auto e24 = [](uint32_t x) { return ((x >> 20) << 12) | ((x >> 4) & 0xfffu); };
+  const uint32_t e0 = e24(v.x), e1 = e24(v.y), e2 = e24(v.z), e3 = e24(v.w);
+  w0 = e0 | (e1 << 24);
+  w1 = (e1 >> 8) | (e2 << 16);
+  w2 = (e2 >> 16) | (e3 << 8);
+}
+__device__ __forceinline__ void pk_unpack3(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t (&e)[4]) {
+  e[0] = w0 & 0xffffffu;
+  e[1] = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+  e[2] = (w1 >> 16) | ((w2 & 0xffu) << 16);
+  e[3] = w2 >> 8;
+}
+
+__global__ __launch_bounds__(64) void pk_compress_kernel(const uint32_t* ent4, uint8_t* ent3, uint32_t* winfo, int M, int RG,
+                                                         int NW, int T) {
+  const size_t st = blockIdx.x;
+  const int w = blockIdx.y, l = threadIdx.x;
+  const int g = (int)(st / PK_S);
+  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  const uint32_t* src = ent4 + (((size_t)st * NW + w) * T) * 256;
+  uint8_t* dst = ent3 + ((size_t)st * NW + w) * T * PK_WREG3;
+  uint32_t* wi = winfo + (st * NW + w) * 4;
+  for (int t = 0; t < T; ++t) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((size_t)t * 64 + l) * 4);
+    if (t == 0 && l == 0) wi[3] = wi[2] ? pk_get_start_row(v.x, v.y, v.z, v.w) : (uint32_t)nrows;
+    uint32_t w0, w1, w2;
+    pk_pack3(v, w0, w1, w2);
+    uint32_t* o = reinterpret_cast<uint32_t*>(dst + (size_t)T * 8 + (size_t)t * PK_STEP3 + (size_t)l * 12);
+    o[0] = w0; o[1] = w1; o[2] = w2;
+    const unsigned long long fl = __ballot((v.x & 1u) != 0u);
+    if (l == 0) *reinterpret_cast<unsigned long long*>(dst + (size_t)t * 8) = fl;
+  }
+}
+
+__global__ __launch_bounds__(64) void pk_unpack3_kernel(const uint8_t* ent3, const uint32_t* winfo, uint16_t* codes, int M,
+                                                        int in_groups, int RG, int NW, int T) {
+  const int xstride = pk_x_stride(in_groups);
+  const size_t st = blockIdx.x;
+  const int w = blockIdx.y, l = threadIdx.x;
+  const int g = (int)(st / PK_S), s = (int)(st % PK_S);
+  const uint32_t* wi = winfo + (st * NW + w) * 4;
+  const int steps = (int)wi[2];
+  const uint8_t* base = ent3 + ((size_t)st * NW + w) * T * PK_WREG3;
+  // start row of this column: the wave range's start row + the row ends in the columns before it
+  int row = (int)wi[3];
+  for (int t = 0; t < steps; ++t) {
+    const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(base + (size_t)t * 8);
+    row += __popcll(fl & ((1ull << l) - 1ull));
+  }
+  for (int t = 0; t < steps; ++t) {
+    const uint32_t* p3 = reinterpret_cast<const uint32_t*>(base + (size_t)T * 8 + (size_t)t * PK_STEP3 + (size_t)l * 12);
+    uint32_t e[4];
+    pk_unpack3(p3[0], p3[1], p3[2], e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int slot = (int)(e[k] >> 12);
+      const int j = slot % xstride;
+      if (j < in_groups && g * RG + row < M) codes[(size_t)(g * RG + row) * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | (e[k] & 0xfffu));
+    }
+    const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(base + (size_t)t * 8);
+    row += (int)((fl >> l) & 1ull);
+  }
+}
+
 // inverse of the repack: canonical codes [M][in_groups] from a packed buffer (lossless; used to drop / restore the
 // canonical codes of inference-only models and by the tests).  One wave per (stream, wave range).
 __global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, const uint32_t* winfo, uint16_t* codes, int M,
@@ -424,9 +499,11 @@ struct PackedGemvParams {
   uint32_t ent_bytes;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
+  int dbg;                    // bit 0: skip the LDS reads + dot products, bit 1: no entry stream (out-of-range loads)
 #endif
 };
 
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) const u32x4* lds_u32x4_ptr;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(1))) const void* gbl_void_ptr;
@@ -471,9 +548,10 @@ struct PackedLds {
 };
 
 // `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
-template <class T_, int B, int PD, uint32_t XWIN>
+template <class T_, int B, int PD, uint32_t XWIN, int EB>
 __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
   using LDS = PackedLds<B, XWIN>;
+  using ring_t = typename std::conditional<EB == 3, u32x3, u32x4>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int NT = (int)blockDim.x;
@@ -503,6 +581,15 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // ---- prologue: everything that needs no other data is issued first, in one burst -------------------------------
   const uint32_t XP = LDS::plane(p.in_groups);
   const uint32_t xstride16 = (uint32_t)pk_x_stride(p.in_groups) * 16u;
+  __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
+  const int wv = wave < p.NW ? wave : p.NW - 1;  // waves beyond the stream's wave count (shared-input launches) idle
+  const uint32_t wbase = (uint32_t)(((size_t)block * p.NW + wv) * p.T) * (EB == 3 ? (uint32_t)PK_WREG3 : 1024u);
+  const int Tm1 = p.T - 1;
+  // (0) 3-byte entries: the row-end flag words of this wave range, word t in lane t -- the OLDEST load of the queue, so
+  // it has landed whenever the wait of (5) returns
+  u32x2 flagw = {0u, 0u};
+  if constexpr (EB == 3)
+    flagw = __builtin_amdgcn_raw_buffer_load_b64(rs_ent, (uint32_t)(lane < Tm1 ? lane : Tm1) * 8u, wbase, 0);
   // (1) LDS-DMA: the 64 KiB slice (shared by the 16 workgroups of the XCD that hold it -> L2 hits) and x
   {
     const uint8_t* src = p.codebook + (size_t)slice * PK_SLICE_BYTES;
@@ -530,21 +617,25 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     }
   }
   // (2) the entry stream of this wave: fixed addresses, PD steps ahead in a register ring with compile-time slots
-  __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
-  const int wv = wave < p.NW ? wave : p.NW - 1;  // waves beyond the stream's wave count (shared-input launches) idle
-  const uint32_t wbase = (uint32_t)(((size_t)block * p.NW + wv) * p.T) * 1024u;
-  const uint32_t voff = (uint32_t)lane * 16u;
-  const int Tm1 = p.T - 1;
-  auto fetch = [&](int t) -> u32x4 {  // unconditional; steps past the end re-read the last step (never consumed)
-    const int tc = t < Tm1 ? t : Tm1;
-    return __builtin_amdgcn_raw_buffer_load_b128(rs_ent, voff, wbase + (uint32_t)tc * 1024u, AUX_NT);
+  const uint32_t voff = (uint32_t)lane * (EB == 3 ? 12u : 16u);
+  const uint32_t ebase = EB == 3 ? wbase + (uint32_t)p.T * 8u : wbase;
+  auto fetch = [&](int t) -> ring_t {  // unconditional (a load under a branch derails hipcc's wait counts); steps past the
+    // end of the range get an out-of-range offset: the buffer unit answers them with zeros and touches no memory
+#ifdef AQLM_PACKED_TRACE
+    const uint32_t vo = (t <= Tm1 && !(p.dbg & 2)) ? voff : 0xfffffff0u;
+#else
+    const uint32_t vo = t <= Tm1 ? voff : 0xfffffff0u;
+#endif
+    if constexpr (EB == 3) return __builtin_amdgcn_raw_buffer_load_b96(rs_ent, vo, ebase + (uint32_t)t * (uint32_t)PK_STEP3, AUX_NT);
+    else return __builtin_amdgcn_raw_buffer_load_b128(rs_ent, vo, ebase + (uint32_t)t * 1024u, AUX_NT);
   };
-  u32x4 ring[PD];
+  ring_t ring[PD];
 #pragma unroll
   for (int k = 0; k < PD; ++k) ring[k] = fetch(k);
   // (3) steps of this wave through the scalar cache (not a VMEM op: it must not sit in the vmcnt queue, see (5))
   const const_u32_ptr wi = (const_u32_ptr)(uintptr_t)(p.winfo + ((size_t)block * p.NW + wv) * 4);
   const int steps = wave < p.NW ? (int)wi[2] : 0;
+  const uint32_t wave_start_row = wi[3];
   // (4) LDS that needs no data: the zero vectors the null entries point at
   if (tid < B) *reinterpret_cast<u32x4*>(smem_raw + LDS::X + (uint32_t)tid * XP + (uint32_t)p.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};
   AQLM_TRACE(1);  // every load of the prologue has been issued
@@ -558,47 +649,109 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 
   uint32_t mask = 0xfff0u;
   asm volatile("" : "+v"(mask));  // the SDWA operand must sit in a VGPR
-  float acc[B];
+  // One accumulator chain per row of x for every batch size: a row's result must not depend on how many rows share the
+  // launch (tested bit for bit).  Several independent chains per row were measured: no gain (the loop is not bound by
+  // the dependent latency of v_dot2c).
+  constexpr int NA = 1;
+  float acc[B][NA];
 #pragma unroll
-  for (int b = 0; b < B; ++b) acc[b] = 0.f;
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[b][a] = 0.f;
   uint32_t row_addr = 0;  // LDS byte address of rowval[0][current row of this column]
 
-  auto entry = [&](uint32_t w) {
-    const uint32_t a_cb = half_and<0>(w, mask);
-    uint32_t a_x = half_and<1>(w, mask);
-    const u32x4 e = *(lds_u32x4_ptr)(size_t)(a_cb + LDS::SLICE);
-    if constexpr (B == 1) {
-      const u32x4 xv = *(lds_u32x4_ptr)(size_t)(a_x + LDS::X);
-      acc[0] = dot8<T_>(e, xv, acc[0]);
-    } else {
-      a_x += LDS::X - ((w >> 16) & 3u) * xstride16;  // the entry names a copy of x; the planes hold one
+  // One lane-step = 4 entries.  Per entry: a_cb / a_x = LDS byte offsets of the codebook vector (inside the slice) and of
+  // x[j] (inside the x area; for B > 1 `copy` is the x copy the entry names -- the planes hold one, so its offset is
+  // taken out again).  ALL LDS reads of a group of entries are issued before the first dot product: with 2 waves per SIMD
+  // the loop is bound by LDS latency, not bandwidth (traced: 0.3 us per step with two entries in flight per wave).
+  constexpr int EG = B <= 2 ? 4 : (B <= 4 ? 2 : 1);  // entries per read batch (registers: EG * (1 + B) * 4)
+  auto entries = [&](const uint32_t (&a_cb)[4], const uint32_t (&a_x)[4], const uint32_t (&copy)[4]) {
+#ifdef AQLM_PACKED_TRACE
+    if (p.dbg & 1) { acc[0][0] += __uint_as_float(a_cb[0] ^ a_x[1] ^ a_cb[2] ^ a_x[3]); return; }
+#endif
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const u32x4 xv = *(lds_u32x4_ptr)(size_t)(a_x + (uint32_t)b * XP);
-        acc[b] = dot8<T_>(e, xv, acc[b]);
+    for (int g0 = 0; g0 < 4; g0 += EG) {
+      u32x4 ev[EG], xv[EG][B];
+#pragma unroll
+      for (int k = 0; k < EG; ++k) {
+        ev[k] = *(lds_u32x4_ptr)(size_t)(a_cb[g0 + k] + LDS::SLICE);
+        if constexpr (B == 1) {
+          xv[k][0] = *(lds_u32x4_ptr)(size_t)(a_x[g0 + k] + LDS::X);
+        } else {
+          const uint32_t ax = a_x[g0 + k] + LDS::X - copy[g0 + k] * xstride16;
+#pragma unroll
+          for (int b = 0; b < B; ++b) xv[k][b] = *(lds_u32x4_ptr)(size_t)(ax + (uint32_t)b * XP);
+        }
       }
+#pragma unroll
+      for (int k = 0; k < EG; ++k)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[b][(g0 + k) % NA] = dot8<T_>(ev[k], xv[k][b], acc[b][(g0 + k) % NA]);
     }
   };
-  auto step = [&](const u32x4& e) {
-    const uint32_t row_ends = e.x & 1u;
-    entry(e.x);
-    entry(e.y);
-    entry(e.z);
-    entry(e.w);
-    if (row_ends) {  // a row ends here: exactly one lane-step per row does, so the store has a unique writer
+  auto total = [&](int b) -> float {  // fixed summation order of the chains
+    float v = acc[b][0];
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        lds_store_f32(row_addr + (uint32_t)(b * RG1) * 4u, acc[b]);
-        acc[b] = 0.f;
+    for (int a = 1; a < NA; ++a) v += acc[b][a];
+    return v;
+  };
+  auto flush = [&]() {  // a row ends here: exactly one lane-step per row does, so the store has a unique writer
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      lds_store_f32(row_addr + (uint32_t)(b * RG1) * 4u, total(b));
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[b][a] = 0.f;
+    }
+    row_addr += 4u;
+  };
+  uint32_t cmask = 0u;  // 3-byte entries: bit t = this column's lane-step t ends a row
+  [[maybe_unused]] uint32_t xrecip = 0u;
+  if constexpr (EB == 3 && B > 1) xrecip = 0xffffffffu / (xstride16 >> 4) + 1u;  // slot / stride == mulhi(slot, xrecip) for slot < 2^16
+  auto step = [&](const ring_t& e) {
+    uint32_t a_cb[4], a_x[4], copy[4] = {0u, 0u, 0u, 0u};
+    if constexpr (EB == 4) {
+      const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a_cb[k] = half_and<0>(w[k], mask);
+        a_x[k] = half_and<1>(w[k], mask);
+        if constexpr (B > 1) copy[k] = (w[k] >> 16) & 3u;
       }
-      row_addr += 4u;
+      entries(a_cb, a_x, copy);
+      if (e.x & 1u) flush();
+    } else {
+      // 96 bits = 4 x (slot:12 | code:12), entry k at bit 24 k
+      const uint32_t w0 = e.x, w1 = e.y, w2 = e.z;
+      const uint32_t t1 = __builtin_amdgcn_alignbit(w1, w0, 24);   // bits 24.. : code 1 in [11:0]
+      const uint32_t t2 = __builtin_amdgcn_alignbit(w2, w1, 28);   // bits 60.. : slot 2 in [11:0]
+      a_cb[0] = (w0 << 4) & 0xfff0u;   a_x[0] = (w0 >> 8) & 0xfff0u;
+      a_cb[1] = (t1 << 4) & 0xfff0u;   a_x[1] = w1 & 0xfff0u;
+      a_cb[2] = (w1 >> 12) & 0xfff0u;  a_x[2] = (t2 << 4) & 0xfff0u;
+      a_cb[3] = (w2 >> 4) & 0xfff0u;   a_x[3] = half_and<1>(w2, mask);
+      if constexpr (B > 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) copy[k] = __umulhi(a_x[k] >> 4, xrecip);
+      }
+      entries(a_cb, a_x, copy);
+      if (cmask & 1u) flush();
+      cmask >>= 1;
     }
   };
 
   if (steps > 0) {
-    {  // the column's starting row rides in the spare bits of its first lane-step
+    if constexpr (EB == 4) {  // the column's starting row rides in the spare bits of its first lane-step
       const uint32_t f = pk_get_start_row(ring[0].x, ring[0].y, ring[0].z, ring[0].w);
       row_addr = rowval_off + f * 4u;
+    } else {  // flag word t sits in lane t: collect this lane's bit of every word, and count the row ends of the columns before it
+      uint32_t pre = 0u;
+      const uint32_t l31 = (uint32_t)lane & 31u;
+      for (int t = 0; t < steps; ++t) {
+        const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)flagw.x, t), shi = (uint32_t)__builtin_amdgcn_readlane((int)flagw.y, t);
+        const uint32_t sel = lane >= 32 ? shi : slo;
+        cmask |= ((sel >> l31) & 1u) << t;
+        pre = __builtin_amdgcn_mbcnt_hi(shi, __builtin_amdgcn_mbcnt_lo(slo, pre));
+      }
+      row_addr = rowval_off + (wave_start_row + pre) * 4u;
     }
     int t = 0;
     for (; t + PD <= steps; t += PD) {
@@ -616,7 +769,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // what the column gathered after its last row end belongs to a row that continues in the next column (0 otherwise)
   if (wave < p.NW) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) lds_store_f32(colend_off + (uint32_t)((b * PK_MAX_NW + wave) * 64 + lane) * 4u, acc[b]);
+    for (int b = 0; b < B; ++b) lds_store_f32(colend_off + (uint32_t)((b * PK_MAX_NW + wave) * 64 + lane) * 4u, total(b));
   }
   AQLM_TRACE(4);
   asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");  // the asm LDS stores above are invisible to the compiler's counters
@@ -648,9 +801,9 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #endif
 }
 
-template <class T_, int B, int PD, uint32_t XWIN>
+template <class T_, int B, int PD, uint32_t XWIN, int EB>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
-  gemv_1x16_packed_body<T_, B, PD, XWIN>(p, blockIdx.x);
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, blockIdx.x);
 }
 
 // Several prepacked layers that multiply the same x (q/k/v, gate/up) in one launch of 256 workgroups per layer; the
@@ -672,7 +825,7 @@ struct PackedMultiParams {
   PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
-template <class T_, int B, int PD, uint32_t XWIN>
+template <class T_, int B, int PD, uint32_t XWIN, int EB>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const PackedMultiParams mp) {
   const int sidx = (int)blockIdx.x >> 8;
   PackedGemvParams p{};
@@ -695,7 +848,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const Pack
       p.ent_bytes = mp.seg[k].ent_bytes;
     }
   }
-  gemv_1x16_packed_body<T_, B, PD, XWIN>(p, (int)blockIdx.x & 255);
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, (int)blockIdx.x & 255);
 }
 
 struct PackedFinalizeParams {
@@ -752,22 +905,27 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const Pac
 // ---------------------------------------------------------------------------------------------- host launch helpers
 static int pick_pd(const PackedLayout& L) {
   const int t = tuning().packed_prefetch;
-  if (t == 4 || t == 8) return t;
-  return (L.NW >= 16 || L.T < 8) ? 4 : 8;
+  if (t == 3 || t == 4 || t == 8) return t;
+  // measured (profiles/r02_mb_packed_variants.log): 3 steps in flight per wave are best or within 1 % of best on every
+  // shape; 8 are 5-10 % slower (the bigger burst of the prologue delays the codebook slice, which gates the loop)
+  return 3;
 }
 
+// Instantiations: (dtype, B, PD, entry bytes).  Only the batch-1 kernels come with the deeper ring (PD = 8): with more
+// rows the loop is LDS-bound and 4 steps in flight cover the stream.
 template <class KP, class Launch>
-static int dispatch_packed(int dtype, int batch, int pd, Launch&& launch) {
-  // launch(kernel, lds_bytes_fn): instantiations are (dtype, B, PD); XWIN is the full window for now
-#define AQLM_PK_CASE(BB)                                                                                               \
-  case BB:                                                                                                             \
-    if (dtype == AQLM_HIP_F16)                                                                                         \
-      return pd == 8 ? launch(KP::template get<F16, BB, 8>(), PackedLds<BB, PK_XWIN_FULL>{})                           \
-                     : launch(KP::template get<F16, BB, 4>(), PackedLds<BB, PK_XWIN_FULL>{});                          \
-    return pd == 8 ? launch(KP::template get<BF16, BB, 8>(), PackedLds<BB, PK_XWIN_FULL>{})                            \
-                   : launch(KP::template get<BF16, BB, 4>(), PackedLds<BB, PK_XWIN_FULL>{});
+static int dispatch_packed(int dtype, int batch, int pd, int eb, Launch&& launch) {
+#define AQLM_PK_GO(TT, BB, PP, EE) launch(KP::template get<TT, BB, PP, EE>(), PackedLds<BB, PK_XWIN_FULL>{})
+#define AQLM_PK_CASE(BB)                                                                                      \
+  case BB:                                                                                                    \
+    if (dtype == AQLM_HIP_F16) return eb == 3 ? AQLM_PK_GO(F16, BB, 4, 3) : AQLM_PK_GO(F16, BB, 4, 4);          \
+    return eb == 3 ? AQLM_PK_GO(BF16, BB, 4, 3) : AQLM_PK_GO(BF16, BB, 4, 4);
   switch (batch) {
-    AQLM_PK_CASE(1)
+    case 1:
+#define AQLM_PK_B1(TT, EE) (pd == 8 ? AQLM_PK_GO(TT, 1, 8, EE) : (pd == 4 ? AQLM_PK_GO(TT, 1, 4, EE) : AQLM_PK_GO(TT, 1, 3, EE)))
+      if (dtype == AQLM_HIP_F16) return eb == 3 ? AQLM_PK_B1(F16, 3) : AQLM_PK_B1(F16, 4);
+      return eb == 3 ? AQLM_PK_B1(BF16, 3) : AQLM_PK_B1(BF16, 4);
+#undef AQLM_PK_B1
     AQLM_PK_CASE(2)
     AQLM_PK_CASE(3)
     AQLM_PK_CASE(4)
@@ -777,16 +935,17 @@ static int dispatch_packed(int dtype, int batch, int pd, Launch&& launch) {
     AQLM_PK_CASE(8)
   }
 #undef AQLM_PK_CASE
+#undef AQLM_PK_GO
   return AQLM_HIP_E_INVALID;
 }
 
 struct SingleKernels {
-  template <class T_, int B, int PD>
-  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL>; }
+  template <class T_, int B, int PD, int EB>
+  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL, EB>; }
 };
 struct MultiKernels {
-  template <class T_, int B, int PD>
-  static auto get() { return gemv_1x16_packed_multi_kernel<T_, B, PD, PK_XWIN_FULL>; }
+  template <class T_, int B, int PD, int EB>
+  static auto get() { return gemv_1x16_packed_multi_kernel<T_, B, PD, PK_XWIN_FULL, EB>; }
 };
 
 // largest batch whose LDS image fits the CU
@@ -824,7 +983,8 @@ extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features,
   const size_t lane_steps = RG * in_groups / (4 * PK_S) * 5 / 4 + RG + 64;   // per stream
   const size_t ent = nst * (lane_steps * 16 + 16 * 1024);
   const size_t meta = 2048 + nst * PK_MAX_NW * 16 + nst * (RG + 1) * 4;
-  return align_up(meta + ent, 1024);
+  // 3-byte entries: the repack builds the 4-byte layout in the tail of the buffer and squeezes it to the front
+  return align_up(meta + ent + ent * PK_WREG3 / 1024 + 4096, 1024);
 }
 
 extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
@@ -864,16 +1024,23 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   const int NW = choose_waves(maxL);
   const int T = (int)((maxL + 64u * NW - 1) / (64u * NW));
   const bool arrange = tuning().packed_arrange && T <= PK_ARR_MAX_T;
-  int XC = arrange ? pk_max_x_copies(in_groups) : 1;
-  if (tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(XC, tuning().packed_xcopies);
-  PackedLayout L;
-  if (!packed_layout(M, in_features, NW, T, L, XC) || L.used > packed_bytes) {
+  // rotated copies of x: 1 by default -- with the row pools the x reads are already spread well, and up to 4 copies
+  // measured within +-1 % (profiles/r02_mb_packed_variants.log); the knob keeps the mechanism testable
+  int XC = 1;
+  if (arrange && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
+  // 32-bit entries by default (1-3 % faster: two operations instead of four to form an entry's addresses); 24-bit entries
+  // (-23 % bytes; wave ranges of at most 32 steps) are the compact choice for inference-only deployments
+  const int EB = (tuning().packed_entry_bytes == 3 && T <= 32) ? 3 : 4;
+  PackedLayout L, L4;
+  if (!packed_layout(M, in_features, NW, T, L, XC, EB) || !packed_layout(M, in_features, NW, T, L4, XC, 4) ||
+      L.used + (EB == 3 ? L4.ent_bytes + 1024 : 0) > packed_bytes) {
     set_last_error("aqlm_hip_prepack_1x16: codes too unevenly spread over the codebook slices for the packed format "
                    "(longest stream %u lane-steps, %d steps per wave)", maxL, T);
     return AQLM_HIP_E_UNSUPPORTED;
   }
   uint32_t* winfo = (uint32_t*)(base + L.off_winfo);
-  uint32_t* ent = (uint32_t*)(base + L.off_ent);
+  // the 4-byte working layout: in place for 4-byte entries, else in the tail of the capacity
+  uint32_t* ent = EB == 4 ? (uint32_t*)(base + L.off_ent) : (uint32_t*)(base + (packed_bytes - L4.ent_bytes) / 1024 * 1024);
   aqlm_hip_packed_desc d{};
   d.magic = PK_MAGIC;
   d.version = 5;
@@ -882,18 +1049,20 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   d.slices_log2 = PK_S_LOG;
   d.waves = NW;
   d.steps = T;
-  d.entry_bytes = 4;
+  d.entry_bytes = EB;
   d.used_bytes = L.used;
   d.x_copies = (uint64_t)XC;
   if (int e = check_hip(hipMemcpyAsync(base, &d, sizeof(d), hipMemcpyHostToDevice, stream), "prepack header")) return e;
   const uint32_t null_entry = (uint32_t)in_groups << 20;
-  hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L.ent_bytes / 4, null_entry);
+  hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4, null_entry);
   hipLaunchKernelGGL(pk_scatter_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, ent, M, in_groups, RG, NW, T);
   if (arrange)
     hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 256, stream, a,
                        ent, M, in_groups, RG, NW, T, XC);
   hipLaunchKernelGGL(pk_flag_kernel, dim3((RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, M, RG, NW, T);
   hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, M, RG, NW, T);
+  if (EB == 3)
+    hipLaunchKernelGGL(pk_compress_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, ent, base + L.off_ent, winfo, M, RG, NW, T);
   if (int e = check_hip(hipGetLastError(), "prepack launch")) return e;
   if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;  // `d` is on the stack
   *desc = d;
@@ -924,8 +1093,12 @@ extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void
     return AQLM_HIP_E_INVALID;
   }
   const uint8_t* base = (const uint8_t*)packed;
-  hipLaunchKernelGGL(pk_unpack_kernel, dim3((unsigned)L.nst, L.NW), dim3(64), 0, stream, (const uint32_t*)(base + L.off_ent),
-                     (const uint32_t*)(base + L.off_winfo), (uint16_t*)codes, L.M, L.in_groups, L.RG, L.NW, L.T);
+  if (L.EB == 3)
+    hipLaunchKernelGGL(pk_unpack3_kernel, dim3((unsigned)L.nst, L.NW), dim3(64), 0, stream, base + L.off_ent,
+                       (const uint32_t*)(base + L.off_winfo), (uint16_t*)codes, L.M, L.in_groups, L.RG, L.NW, L.T);
+  else
+    hipLaunchKernelGGL(pk_unpack_kernel, dim3((unsigned)L.nst, L.NW), dim3(64), 0, stream, (const uint32_t*)(base + L.off_ent),
+                       (const uint32_t*)(base + L.off_winfo), (uint16_t*)codes, L.M, L.in_groups, L.RG, L.NW, L.T);
   return check_hip(hipGetLastError(), "unpack launch");
 }
 
@@ -984,6 +1157,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
     p.ent_bytes = (uint32_t)L.ent_bytes;
 #ifdef AQLM_PACKED_TRACE
     p.trace = workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+    p.dbg = tuning().packed_debug;
 #endif
     auto launch = [&](auto kern, auto lds_map) -> int {
       const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG);
@@ -991,7 +1165,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
       hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p);
       return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
     };
-    if (int e = dispatch_packed<SingleKernels>(dtype, nb, pd, launch)) return e;
+    if (int e = dispatch_packed<SingleKernels>(dtype, nb, pd, L.EB, launch)) return e;
     PackedFinalizeParams f{};
     f.partial = (const float*)workspace;
     f.scales = (const uint16_t*)scales;
@@ -1035,7 +1209,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
   mp.x_row_stride = x_row_stride;
   mp.nseg = fm.nseg = num_segments;
   size_t need = 0;
-  int fblocks = 0, max_rg = 0, nw = 0, pd = 4;
+  int fblocks = 0, max_rg = 0, nw = 0, pd = 4, eb = 0;
   for (int k = 0; k < num_segments; ++k) {
     const aqlm_hip_segment& sg = segments[k];
     if (!sg.codes || !sg.codebook || !sg.scales || !sg.y) {
@@ -1063,6 +1237,11 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     ps.XC = L.XC;
     ps.ent_bytes = (uint32_t)L.ent_bytes;
     mp.in_groups = L.in_groups;
+    if (eb && eb != L.EB) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi: segments mix 3- and 4-byte entry formats");
+      return AQLM_HIP_E_UNSUPPORTED;
+    }
+    eb = L.EB;
     max_rg = std::max(max_rg, L.RG);
     nw = std::max(nw, L.NW);
     pd = std::max(pd, pick_pd(L));
@@ -1092,7 +1271,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     hipLaunchKernelGGL(kern, dim3(256 * num_segments), dim3(nw * 64), lds, stream, mp);
     return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
   };
-  if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, launch)) return e;
+  if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, eb, launch)) return e;
   if (dtype == AQLM_HIP_F16)
     hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);
   else

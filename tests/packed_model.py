@@ -42,13 +42,13 @@ def choose_waves(max_lane_steps):
     return best
 
 
-def layout(M, in_groups, NW, T):
+def layout(M, in_groups, NW, T, entry_bytes=4):
     RG = (M + NG - 1) // NG
     nst = NG * S
     off_winfo = 256
     off_rowstart = align_up(off_winfo + nst * 16 * 16, 256)
     off_ent = align_up(off_rowstart + nst * (RG + 1) * 4, 1024)
-    ent_bytes = nst * NW * T * 1024
+    ent_bytes = nst * NW * T * (776 if entry_bytes == 3 else 1024)
     return dict(RG=RG, off_winfo=off_winfo, off_rowstart=off_rowstart, off_ent=off_ent, ent_bytes=ent_bytes,
                 used=off_ent + ent_bytes)
 
@@ -223,3 +223,53 @@ def conflict_cycles(P, max_streams=6):
                             tot += np.bincount(slots % 16, minlength=16).max()
                             n += 1
     return tot / max(n, 1)
+
+
+def x_stride(in_groups):
+    return ((in_groups + 1 + 11) & ~15) + 4
+
+
+def decode_device_buffer(raw, M, in_features, NW, T, entry_bytes):
+    """Bytes of a packed buffer (either entry width) -> the arrays of `pack` as the DEVICE holds them: dict with winfo,
+    rowstart, mask [nst, NW, 1, 64] (T <= 32), frow [nst, NW, 64], slot / code [nst, NW, T, 64, 4] (slot = x slot incl.
+    the copy offset), plus the derived j / copy."""
+    in_groups = in_features // 8
+    lay = layout(M, in_groups, NW, T, entry_bytes)
+    assert raw.size == lay["used"], (raw.size, lay["used"])
+    nst = NG * S
+    winfo = raw[lay["off_winfo"]:lay["off_winfo"] + nst * NW * 16].view(np.uint32).reshape(nst, NW, 4)
+    rowstart = raw[lay["off_rowstart"]:lay["off_rowstart"] + nst * (lay["RG"] + 1) * 4].view(np.uint32).reshape(nst, lay["RG"] + 1)
+    region = raw[lay["off_ent"]:]
+    lanes = np.arange(64, dtype=np.uint64)
+    if entry_bytes == 4:
+        ent = region.view(np.uint32).reshape(nst, NW, T, 64, 4)
+        slot, code = ent >> 20, (ent >> 4) & 0xFFF
+        flags = (ent[..., 0] & 1).astype(np.uint32)                                    # [nst, NW, T, 64]
+        e0, e1, e2, e3 = (ent[:, :, 0, :, k].astype(np.uint32) for k in range(4))
+        frow = ((e0 >> 1) & 7) | ((e1 & 15) << 3) | ((e2 & 15) << 7) | ((e3 & 15) << 11)
+        spare_ok = int(((ent >> 18) & 3).max()) == 0
+        copy_bits = (ent >> 16) & 3
+    else:
+        region = region.reshape(nst, NW, T * 776)
+        words = np.ascontiguousarray(region[:, :, :8 * T]).view(np.uint64).reshape(nst, NW, T)
+        w = np.ascontiguousarray(region[:, :, 8 * T:]).view(np.uint32).reshape(nst, NW, T, 64, 3).astype(np.uint64)
+        w0, w1, w2 = w[..., 0], w[..., 1], w[..., 2]
+        e = np.stack([w0 & 0xFFFFFF, (w0 >> 24) | ((w1 & 0xFFFF) << 8), (w1 >> 16) | ((w2 & 0xFF) << 16), w2 >> 8], axis=-1)
+        slot, code = (e >> 12).astype(np.uint32), (e & 0xFFF).astype(np.uint32)
+        flags = ((words[..., None] >> lanes) & np.uint64(1)).astype(np.uint32)             # [nst, NW, T, 64]
+        below = (np.uint64(1) << lanes) - np.uint64(1)
+        pc = np.zeros((nst, NW, 64), dtype=np.int64)
+        for t in range(T):
+            m = words[:, :, t, None] & below
+            pc += np.array([bin(int(v)).count("1") for v in m.reshape(-1)], dtype=np.int64).reshape(nst, NW, 64)
+        frow = (winfo[:, :, 3, None].astype(np.int64) + pc).astype(np.uint32)
+        spare_ok, copy_bits = True, None
+    mask = np.zeros((nst, NW, 1, 64), dtype=np.uint32)
+    for t in range(T):
+        mask[:, :, 0, :] |= flags[:, :, t, :] << np.uint32(t)
+    stride = x_stride(in_groups)
+    copy = slot // stride
+    j = slot - copy * stride
+    if copy_bits is not None:
+        spare_ok = spare_ok and bool((copy_bits == copy).all())
+    return dict(winfo=winfo, rowstart=rowstart, mask=mask, frow=frow, slot=slot, code=code, j=j, copy=copy, spare_ok=spare_ok)

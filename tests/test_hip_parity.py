@@ -353,62 +353,42 @@ def test_raw_c_abi_strided_rows(hk):
 
 
 # ------------------------------------------------------------------ prepacked (slice-bucketed) 1x16 path, format v5
-def _packed_arrays(packed):
-    """(winfo [256, NW, 4] u32, rowstart [256, RG + 1] u32, ent [256, NW, T, 64, 4] u32) views of a PackedCodes buffer."""
-    from tests import packed_model as pm
-
-    raw = packed.buf.cpu().numpy()
-    d = packed.desc
-    NW, T = int(d.waves), int(d.steps)
-    lay = pm.layout(int(d.out_features), int(d.in_features) // 8, NW, T)
-    assert int(d.used_bytes) == raw.size == lay["used"]
-    winfo = raw[lay["off_winfo"]:lay["off_winfo"] + 256 * NW * 16].view(np.uint32).reshape(256, NW, 4)
-    rowstart = raw[lay["off_rowstart"]:lay["off_rowstart"] + 256 * (lay["RG"] + 1) * 4].view(np.uint32).reshape(256, lay["RG"] + 1)
-    ent = raw[lay["off_ent"]:].view(np.uint32).reshape(256, NW, T, 64, 4)
-    return winfo, rowstart, ent
-
-
+@pytest.mark.parametrize("entry_bytes", [3, 4])
 @pytest.mark.parametrize("fin,fout", [(512, 96), (4096, 300), (11008, 64), (64, 40), (14336, 80), (1024, 2000)])
-def test_prepack_matches_the_format_model(hk, fin, fout):
-    """Integer / byte work: the packed buffer must equal the numpy model of format v5 bit for bit, and unpacking it
-    must give the codes back."""
+def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
+    """Integer / byte work: the packed buffer (24-bit and 32-bit entries) is held to the numpy model of format v5 --
+    tables and bookkeeping bit for bit, the entries up to the order inside a row and the x copy they name, which are the
+    repack's bank-aware choice -- and unpacking it must give the codes back."""
+    from aqlm_amd import _native
     from tests import packed_model as pm
 
     L = orc.make_layer(321 + fin, fin, fout, 1, 16, 8, batch=1, bias=False)
     cu = L["codes_unsigned"][:, :, 0].copy()
     cu[1, :] &= 0x0FFF                      # row 1: everything in slice 0 (a row of many lane-steps, empty elsewhere)
     codes = torch.from_numpy(orc.pack_int_data(cu[:, :, None], 16)).to(DEV)
-    packed = hk.prepack_1x16(codes)
+    _native.set_tuning("packed_entry_bytes", entry_bytes)
+    try:
+        packed = hk.prepack_1x16(codes)
+    finally:
+        _native.set_tuning("packed_entry_bytes", 0)
     assert packed is not None
     P = pm.pack(cu)
     d = packed.desc
-    assert (d.magic, d.version, d.out_features, d.in_features, d.slices_log2, d.entry_bytes) == (pm.MAGIC, 5, fout, fin, 4, 4)
+    assert (d.magic, d.version, d.out_features, d.in_features, d.slices_log2, d.entry_bytes) == (pm.MAGIC, 5, fout, fin, 4, entry_bytes)
     assert (d.waves, d.steps) == (P["NW"], P["T"])
-    winfo, rowstart, ent = _packed_arrays(packed)
-    np.testing.assert_array_equal(winfo, P["winfo"])
-    np.testing.assert_array_equal(rowstart, P["rowstart"])
-    # bookkeeping bits (row-end flags, start rows) live in the low nibbles: position-based -> equal to the model's
-    book = np.zeros_like(P["ent"])
-    for st in range(256):
-        for w in range(P["NW"]):
-            for t in range(P["T"]):
-                fl = (P["mask"][st, w, t // 32] >> (t % 32)) & 1
-                book[st, w, t, :, 0] |= fl.astype(np.uint32)
-            f = P["frow"][st, w].astype(np.uint32)
-            book[st, w, 0, :, 0] |= (f & 7) << 1
-            book[st, w, 0, :, 1] |= (f >> 3) & 15
-            book[st, w, 0, :, 2] |= (f >> 7) & 15
-            book[st, w, 0, :, 3] |= (f >> 11) & 15
-    np.testing.assert_array_equal(ent & 0xF, book)
-    # payload: the order inside a row (within a wave range) and the copy of x an entry reads are the repack's choice
-    # (bank-aware), the content is not -- same number of null entries as the model, and walking the buffer like the
-    # kernel does must give the codes back and the right sums
-    stride = ((fin // 8 + 1 + 11) & ~15) + 4
-    copy, slot = (ent >> 16) & 3, ent >> 20
-    assert int(((ent >> 18) & 3).max()) == 0 and int(copy.max()) < int(d.x_copies) <= max(1, min(4, 4095 // stride))
-    j = slot - copy * stride
-    assert int(j.max()) == fin // 8 and int(copy[j == fin // 8].max()) == 0          # nulls name copy 0
-    payload = ((j + pm.XB) << 16) | ((ent >> 4) & 0xFFF)                    # v5 bit layout -> the model's entry encoding
+    G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), entry_bytes)
+    np.testing.assert_array_equal(G["winfo"][:, :, :3], P["winfo"][:, :, :3])
+    np.testing.assert_array_equal(G["rowstart"], P["rowstart"])
+    # bookkeeping (row-end flags, start rows): position-based -> equal to the model's
+    np.testing.assert_array_equal(G["mask"], P["mask"])
+    np.testing.assert_array_equal(G["frow"], P["frow"])
+    # payload: same number of null entries as the model; walking the buffer like the kernel does gives the codes back
+    # and the right sums
+    stride = pm.x_stride(fin // 8)
+    assert G["spare_ok"] and int(G["copy"].max()) < int(d.x_copies) <= max(1, min(4, 4095 // stride))
+    j = G["j"]
+    assert int(j.max()) == fin // 8 and int(G["copy"][j == fin // 8].max()) == 0          # nulls name copy 0
+    payload = ((j + pm.XB) << 16) | G["code"]                                       # -> the model's entry encoding
     assert int((j == fin // 8).sum()) == int((P["ent"] == ((pm.XB + fin // 8) << 16)).sum())
     Pg = dict(P, ent=payload)
     np.testing.assert_array_equal(pm.unpack(Pg), cu)
@@ -417,7 +397,7 @@ def test_prepack_matches_the_format_model(hk, fin, fout):
         cb, xx = rng.standard_normal((65536, 8)), rng.standard_normal((1, fin))
         np.testing.assert_allclose(pm.simulate(Pg, cb, xx), xx @ cb[cu].reshape(fout, fin).T, rtol=0, atol=1e-9)
     # and it must pay off: fewer LDS bank-group collisions per 16-lane service group than the ascending-j order has
-    got = pm.conflict_cycles(dict(P, ent=((slot + pm.XB) << 16) | ((ent >> 4) & 0xFFF)))
+    got = pm.conflict_cycles(dict(P, ent=((G["slot"] + pm.XB) << 16) | G["code"]))
     assert got <= pm.conflict_cycles(P) + 0.02, (got, pm.conflict_cycles(P))
     print(f"LDS cycles per service group and read: packed {got:.3f}, ascending order {pm.conflict_cycles(P):.3f}")
     # lossless, on the GPU and through a re-attached descriptor
@@ -443,8 +423,11 @@ PACKED_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("entry_bytes", [3, 4])
 @pytest.mark.parametrize("fin,fout,dt,bias", PACKED_SHAPES)
-def test_gemv_1x16_packed(hk, fin, fout, dt, bias):
+def test_gemv_1x16_packed(hk, fin, fout, dt, bias, entry_bytes):
+    from aqlm_amd import _native
+
     dtype = tdtype(dt)
     L = orc.make_layer(700 + fin + fout, fin, fout, 1, 16, 8, batch=8, bias=bias,
                        float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
@@ -456,7 +439,12 @@ def test_gemv_1x16_packed(hk, fin, fout, dt, bias):
     cu[fout - 1, :, 0] = (cu[fout - 1, :, 0] & 0x0FFF) | (15 << 12)
     L = dict(L, codes=orc.pack_int_data(cu, 16), codes_unsigned=cu)
     T = to_dev(L, dtype)
-    packed = hk.prepack_1x16(T["codes"])
+    _native.set_tuning("packed_entry_bytes", entry_bytes)
+    try:
+        packed = hk.prepack_1x16(T["codes"])
+    finally:
+        _native.set_tuning("packed_entry_bytes", 0)
+    assert packed.desc.entry_bytes == entry_bytes
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
     y1 = hk.code1x16_matmat_packed(T["x"][:1], packed, T["codebooks"], T["scales"], T["bias"])
     check_close(y1.float().cpu().numpy(), y64[:1], dtype, f"packed 1x16g8 {fin}->{fout}")
@@ -889,7 +877,7 @@ def test_prepack_model_runs_the_load_time_repack_eagerly(hk):
     rep = prepack_model(mods, min_codes=100_000)      # big: 393 216 codes -> repacked now; small: 8192 codes -> not
     assert rep["quantized_linears"] == 2 and rep["prepacked_layers"] == 1
     assert mods["big"]._packed_codes is not None and mods["small"]._packed_codes is None
-    assert 2.0 * 2 * 393216 < rep["prepacked"] < 2.9 * 2 * 393216           # 4 B per code + padding of a small layer
+    assert 1.5 * 2 * 393216 < rep["prepacked"] < 2.9 * 2 * 393216           # 3-4 B per code + padding of a small layer
     import aqlm_amd.inference as inf
     assert inf.PREPACK_MIN_CODES == 1_000_000   # the override did not leak
     for n, m in mods.items():

@@ -419,8 +419,8 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
       if (int rc = aqlm_hip_prepack_1x16(L.codes, out, in, s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
     }
     CK(hipDeviceSynchronize());
-    printf("# packed %d->%d: waves %d steps %d, %.3f B per code (capacity %.1f MB, used %.1f MB)\n", in, out, v[0].desc.waves,
-           v[0].desc.steps, (double)v[0].desc.used_bytes / ((double)out * (in / 8)), pb * 1e-6, v[0].desc.used_bytes * 1e-6);
+    printf("# packed %d->%d: waves %d steps %d entry bytes %d x copies %d, %.3f B per code (capacity %.1f MB, used %.1f MB)\n", in, out,
+           v[0].desc.waves, v[0].desc.steps, v[0].desc.entry_bytes, (int)v[0].desc.x_copies, (double)v[0].desc.used_bytes / ((double)out * (in / 8)), pb * 1e-6, v[0].desc.used_bytes * 1e-6);
   }
   return v;
 }
@@ -473,9 +473,13 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"waves=4", "packed_waves", 4}});
       variants.push_back({{"waves=8", "packed_waves", 8}});
       variants.push_back({{"waves=16", "packed_waves", 16}});
+      variants.push_back({{"prefetch=3", "packed_prefetch", 3}});
       variants.push_back({{"prefetch=4", "packed_prefetch", 4}});
+      variants.push_back({{"entry=3B", "packed_entry_bytes", 3}});
+      variants.push_back({{"xcopies=4", "packed_xcopies", 4}});
       variants.push_back({{"prefetch=8", "packed_prefetch", 8}});
       variants.push_back({{"arrange=0", "packed_arrange", 0}});
+
     } else if (c.s.packed) {
     } else if (c.s.nbits == 8 && c.s.g == 8) {
       variants.push_back({{"replicas=off", "kx8_replicas", 0}});
@@ -506,13 +510,14 @@ static void bench_gemv(int argc, char** argv) {
         }
       }
       for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
-      if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange"))) {  // a format parameter: repack
+      if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange") || !strcmp(var[0].key, "packed_entry_bytes") || !strcmp(var[0].key, "packed_xcopies"))) {  // a format parameter: repack
         const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
         for (auto& L : layers)
           if (int rc = aqlm_hip_prepack_1x16(L.codes, c.out, c.in, c.s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
         one[0] = layers[0];
         for (auto& w : warm) w = layers[0];
-        printf("# repacked: waves %d steps %d\n", layers[0].desc.waves, layers[0].desc.steps);
+        printf("# repacked: waves %d steps %d entry bytes %d x copies %d, %.3f B per code\n", layers[0].desc.waves, layers[0].desc.steps,
+               layers[0].desc.entry_bytes, (int)layers[0].desc.x_copies, (double)layers[0].desc.used_bytes / ((double)c.out * (c.in / 8)));
       }
       for (int batch : {1, 2, 4, 8}) {
         if (batch > 1 && (!var.empty() || quick)) continue;
@@ -543,7 +548,8 @@ static void bench_trace(int in, int out) {
   std::vector<unsigned long long> h(256 * NWMAX * 8);
   const int NW = layers[0].desc.waves;
   const char* names[7] = {"entry", "loads issued", "LDS filled (barrier)", "-", "loop done", "2nd barrier", "end"};
-  for (int rep = 0; rep < 3; ++rep) {
+  for (int rep = 0; rep < 4; ++rep) {
+    aqlm_hip_set_tuning("packed_debug", rep == 0 ? 0 : rep - 1 < 3 ? rep - 1 : 0);  // runs: -, full, no compute, no stream
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
     CK(hipMemset(tr, 0, h.size() * 8));
     CK(hipDeviceSynchronize());
@@ -552,8 +558,8 @@ static void bench_trace(int in, int out) {
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) t0 = std::min(t0, h[(b * NWMAX + w) * 8]);
-    printf("# packed %d->%d cold, run %d (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
-           in, out, rep, NW, layers[0].desc.steps, 256 * NW);
+    printf("# packed %d->%d cold, run %d [debug %d: 0 full, 1 no LDS reads / dots, 2 no entry stream] (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
+           in, out, rep, rep == 0 ? 0 : rep - 1, NW, layers[0].desc.steps, 256 * NW);
     for (int i = 0; i < 7; ++i) {
       if (i == 3) continue;
       double mn = 1e9, mx = 0, sum = 0;
