@@ -1,0 +1,193 @@
+// libaqlm_cpu.so -- native CPU kernels of the AQLM QuantizedLinear path (host-side fallback of the MI355X package).
+//
+// Replaces (behaviour, not code) the reference's numba kernel `numba_gemm_lut` / `aqlm_gemv_lut`
+// (inference_lib/src/aqlm/inference_kernels/numba_kernel.py:10-65, benchmark/matmul_benchmark_cpu.py:100-111) for
+// 8-bit codebooks, and gives 16-bit codebooks a direct kernel where the reference falls back to a full torch
+// dequantisation (kernel_selector.py:99-102).  Plain C ABI (include/aqlm_cpu.h), fp32 in / fp32 out, caller-owned
+// buffers, no allocation except the per-call look-up table the caller passes in as scratch.
+//
+// LUT kernel (K codebooks of 256 entries):   lut[j][c][v] = <codebooks[c][v], x_j>          (in_groups x K x 256 floats)
+//                                            y[i] = scales[i] * sum_j sum_c lut[j][c][codes[j][i][c]] + bias[i]
+// Codes are expected in the layout the reference permutes them to for this kernel, [in_groups][out][K] uint8
+// (inference.py:78-83): consecutive output rows are consecutive bytes, so one input group's codes for a block of
+// rows are one contiguous load and its 2-8 KiB table slab stays in L1 while the block is swept.  Parallel over
+// blocks of output rows (every thread owns its rows: no write sharing -- the reference kernel races on
+// `output_vec[i] +=` inside prange(j), numba_kernel.py:43-46).  The row sweep is vectorised with table gathers.
+//
+// Direct kernel (one codebook of 2^nbits <= 65536 entries, g = 8 | 16): y[i] = scales[i] * sum_j <cb[code[i][j]], x_j>,
+// codebook held in fp32, rows in parallel, 8-wide FMA per code.
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../../include/aqlm_cpu.h"
+
+namespace {
+
+inline int resolve_threads(int nthreads) {
+#ifdef _OPENMP
+  return nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+  (void)nthreads;
+  return 1;
+#endif
+}
+
+// lut[j][c][v] for one input vector; in_groups * K * 256 floats
+void build_lut(const float* x, const float* codebooks, float* lut, int in_groups, int K, int g, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static) collapse(2)
+  for (int j = 0; j < in_groups; ++j) {
+    for (int c = 0; c < K; ++c) {
+      const float* xj = x + (size_t)j * g;
+      const float* cb = codebooks + (size_t)c * 256 * g;
+      float* out = lut + ((size_t)j * K + c) * 256;
+      for (int v = 0; v < 256; ++v) {
+        float s = 0.f;
+        for (int k = 0; k < g; ++k) s += cb[(size_t)v * g + k] * xj[k];
+        out[v] = s;
+      }
+    }
+  }
+}
+
+// rows [r0, r1) of y: sum over input groups and codebooks of table look-ups
+template <bool AVX2>
+#if defined(__x86_64__)
+__attribute__((target("avx2,fma")))
+#endif
+void sweep_rows_impl(const float* lut, const uint8_t* codes, float* acc, int r0, int r1, int in_groups, int out_features, int K) {
+  for (int i = r0; i < r1; ++i) acc[i] = 0.f;
+  for (int j = 0; j < in_groups; ++j) {
+    const float* lj = lut + (size_t)j * K * 256;
+    const uint8_t* cj = codes + ((size_t)j * out_features) * K;
+    int i = r0;
+#if defined(__x86_64__)
+    for (; AVX2 && i + 8 <= r1; i += 8) {
+      __m256 a = _mm256_loadu_ps(acc + i);
+      const uint8_t* p = cj + (size_t)i * K;
+      if (K == 1) {
+        const __m256i idx = _mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i*)p));
+        a = _mm256_add_ps(a, _mm256_i32gather_ps(lj, idx, 4));
+      } else if (K == 2) {
+        const __m256i w = _mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)p));  // 8 x (c0 | c1 << 8)
+        const __m256i i0 = _mm256_and_si256(w, _mm256_set1_epi32(255));
+        const __m256i i1 = _mm256_srli_epi32(w, 8);
+        a = _mm256_add_ps(a, _mm256_i32gather_ps(lj, i0, 4));
+        a = _mm256_add_ps(a, _mm256_i32gather_ps(lj + 256, i1, 4));
+      } else {
+        for (int c = 0; c < K; ++c) {
+          alignas(32) int32_t ix[8];
+          for (int q = 0; q < 8; ++q) ix[q] = p[(size_t)q * K + c];
+          a = _mm256_add_ps(a, _mm256_i32gather_ps(lj + (size_t)c * 256, _mm256_load_si256((const __m256i*)ix), 4));
+        }
+      }
+      _mm256_storeu_ps(acc + i, a);
+    }
+#endif
+    for (; i < r1; ++i) {
+      const uint8_t* p = cj + (size_t)i * K;
+      float s = acc[i];
+      for (int c = 0; c < K; ++c) s += lj[(size_t)c * 256 + p[c]];
+      acc[i] = s;
+    }
+  }
+}
+
+void sweep_rows_plain(const float* lut, const uint8_t* codes, float* acc, int r0, int r1, int in_groups, int out_features, int K) {
+  for (int i = r0; i < r1; ++i) acc[i] = 0.f;
+  for (int j = 0; j < in_groups; ++j) {
+    const float* lj = lut + (size_t)j * K * 256;
+    const uint8_t* cj = codes + ((size_t)j * out_features) * K;
+    for (int i = r0; i < r1; ++i) {
+      const uint8_t* p = cj + (size_t)i * K;
+      float s = acc[i];
+      for (int c = 0; c < K; ++c) s += lj[(size_t)c * 256 + p[c]];
+      acc[i] = s;
+    }
+  }
+}
+
+void sweep_rows(const float* lut, const uint8_t* codes, float* acc, int r0, int r1, int in_groups, int out_features, int K) {
+#if defined(__x86_64__)
+  static const bool has_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  if (has_avx2) return sweep_rows_impl<true>(lut, codes, acc, r0, r1, in_groups, out_features, K);
+#endif
+  sweep_rows_plain(lut, codes, acc, r0, r1, in_groups, out_features, K);
+}
+
+}  // namespace
+
+extern "C" int aqlm_cpu_abi_version(void) { return AQLM_CPU_ABI_VERSION; }
+
+extern "C" int aqlm_cpu_max_threads(void) { return resolve_threads(0); }
+
+extern "C" size_t aqlm_cpu_lut_scratch_floats(int in_features, int num_codebooks, int in_group_size) {
+  if (in_features <= 0 || num_codebooks <= 0 || in_group_size <= 0 || in_features % in_group_size) return 0;
+  return (size_t)(in_features / in_group_size) * num_codebooks * 256;
+}
+
+extern "C" int aqlm_cpu_gemv_lut_kx8(const float* x, const float* codebooks, const uint8_t* codes_alt, const float* scales,
+                                     const float* bias, float* y, int batch, long x_row_stride, long y_row_stride,
+                                     int in_features, int out_features, int num_codebooks, int in_group_size, float* scratch,
+                                     int nthreads) {
+  if (!x || !codebooks || !codes_alt || !scales || !y || !scratch) return AQLM_CPU_E_INVALID;
+  if (batch < 1 || in_features <= 0 || out_features <= 0 || num_codebooks < 1 || in_group_size < 1 ||
+      in_features % in_group_size)
+    return AQLM_CPU_E_INVALID;
+  const int in_groups = in_features / in_group_size, K = num_codebooks;
+  const int nt = resolve_threads(nthreads);
+  for (int b = 0; b < batch; ++b) {  // one table per input row (the reference loops over rows too, numba_kernel.py:55-62)
+    const float* xb = x + (size_t)b * x_row_stride;
+    float* yb = y + (size_t)b * y_row_stride;
+    build_lut(xb, codebooks, scratch, in_groups, K, in_group_size, nt);
+    const int block = 256;  // rows per task: 256 x 4 B of accumulators + one table slab per group stay in L1
+    const int nblocks = (out_features + block - 1) / block;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+    for (int t = 0; t < nblocks; ++t) {
+      const int r0 = t * block, r1 = r0 + block < out_features ? r0 + block : out_features;
+      sweep_rows(scratch, codes_alt, yb, r0, r1, in_groups, out_features, K);
+      for (int i = r0; i < r1; ++i) yb[i] = yb[i] * scales[i] + (bias ? bias[i] : 0.f);
+    }
+  }
+  return 0;
+}
+
+extern "C" int aqlm_cpu_gemv_1xn(const float* x, const float* codebook, const void* codes, int code_bytes, const float* scales,
+                                 const float* bias, float* y, int batch, long x_row_stride, long y_row_stride, int in_features,
+                                 int out_features, int nbits, int in_group_size, int nthreads) {
+  if (!x || !codebook || !codes || !scales || !y) return AQLM_CPU_E_INVALID;
+  if (batch < 1 || in_features <= 0 || out_features <= 0 || nbits < 1 || nbits > 16 || (code_bytes != 1 && code_bytes != 2) ||
+      (in_group_size != 8 && in_group_size != 16) || in_features % in_group_size)
+    return AQLM_CPU_E_UNSUPPORTED;
+  const int g = in_group_size, in_groups = in_features / g;
+  const uint32_t mask = (1u << nbits) - 1u;
+  const int nt = resolve_threads(nthreads);
+#pragma omp parallel for num_threads(nt) schedule(static)
+  for (int i = 0; i < out_features; ++i) {
+    for (int b = 0; b < batch; ++b) {
+      const float* xb = x + (size_t)b * x_row_stride;
+      float acc[16];
+      for (int k = 0; k < g; ++k) acc[k] = 0.f;
+      for (int j = 0; j < in_groups; ++j) {
+        const size_t at = (size_t)i * in_groups + j;
+        const uint32_t code = (code_bytes == 2 ? (uint32_t)((const uint16_t*)codes)[at] : (uint32_t)((const uint8_t*)codes)[at]) & mask;
+        const float* v = codebook + (size_t)code * g;
+        const float* xj = xb + (size_t)j * g;
+#pragma omp simd
+        for (int k = 0; k < g; ++k) acc[k] += v[k] * xj[k];
+      }
+      float s = 0.f;
+      for (int k = 0; k < g; ++k) s += acc[k];
+      y[(size_t)b * y_row_stride + i] = s * scales[i] + (bias ? bias[i] : 0.f);
+    }
+  }
+  return 0;
+}

@@ -70,6 +70,7 @@ class QuantizedLinear(nn.Module):
         self._packed_fingerprint = None
         self._codes_dropped = False
         self._codes_shape = None
+        self._cpu_codes_alt = None  # host modules with 8-bit codebooks: codes permuted for the LUT kernel (derived)
         self._prepack_deferred = False
         self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
 
@@ -109,7 +110,7 @@ class QuantizedLinear(nn.Module):
         ``set_module_tensor_to_device``) or when a repack was postponed during graph capture."""
         if self._prepack_deferred:
             return not torch.cuda.is_current_stream_capturing()
-        if self._packed_codes is None or self._codes_dropped:
+        if (self._packed_codes is None and self._cpu_codes_alt is None) or self._codes_dropped:
             return False
         return self._codes_fingerprint() != self._packed_fingerprint
 
@@ -160,18 +161,30 @@ class QuantizedLinear(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self.gemv_op = self.gemm_op = self.use_gemv_rule = None
         self._packed_codes = None
+        self._cpu_codes_alt = None
         self._prepack_deferred = False
         return out
 
     def prepare_matmul_op(self, input: torch.Tensor):
-        """Resolve the decode (gemv) and batch (gemm) operators once (reference inference.py:77-96).  Unlike the
-        reference there is no CPU branch and therefore no in-place permutation of ``codes``."""
-        self.gemv_op = _get_autograd_matmul_op(
-            get_forward_pass_kernel(self.codebooks, False), get_backward_pass_kernel(self.codebooks, False)
-        )
-        self.gemm_op = _get_autograd_matmul_op(
-            get_forward_pass_kernel(self.codebooks, True), get_backward_pass_kernel(self.codebooks, True)
-        )
+        """Resolve the decode (gemv) and batch (gemm) operators once (reference inference.py:77-96).  For host modules
+        with 8-bit codebooks the reference permutes ``codes`` IN PLACE to the LUT kernel's layout (inference.py:78-83,
+        "TODO: fix this thing"); here the permuted copy is a derived buffer and ``codes`` keeps the checkpoint layout."""
+        from .inference_kernels.kernel_selector import cpu_kernel_takes_permuted_codes
+
+        self._cpu_codes_alt = None
+        if cpu_kernel_takes_permuted_codes(self.codebooks):
+            from .inference_kernels.cpu_kernel import permute_codes_for_lut
+
+            self._cpu_codes_alt = permute_codes_for_lut(self.codes)
+            self._packed_fingerprint = self._codes_fingerprint()
+        fwd_gemv, fwd_gemm = get_forward_pass_kernel(self.codebooks, False), get_forward_pass_kernel(self.codebooks, True)
+        if self._cpu_codes_alt is not None:
+            # the LUT kernel reads the permuted copy; the op still receives (and saves for backward) the canonical codes
+            alt, lut_gemv, lut_gemm = self._cpu_codes_alt, fwd_gemv, fwd_gemm
+            fwd_gemv = lambda input, codes, codebooks, scales, bias: lut_gemv(input, alt, codebooks, scales, bias)  # noqa: E731
+            fwd_gemm = lambda input, codes, codebooks, scales, bias: lut_gemm(input, alt, codebooks, scales, bias)  # noqa: E731
+        self.gemv_op = _get_autograd_matmul_op(fwd_gemv, get_backward_pass_kernel(self.codebooks, False))
+        self.gemm_op = _get_autograd_matmul_op(fwd_gemm, get_backward_pass_kernel(self.codebooks, True))
         self.use_gemv_rule = lambda x: math.prod(x.shape[:-1]) <= GEMV_MAX_ROWS
         # load-time re-layout of the codes for the decode kernel (the reference does the analogous thing for its CPU
         # kernel here, inference.py:78-83 -- but in place; we keep `codes` untouched and add a derived buffer)

@@ -1,0 +1,104 @@
+"""CPU kernels of the QuantizedLinear path, backed by libaqlm_cpu.so (include/aqlm_cpu.h).
+
+Host-side mirror of the reference's CPU branch (inference_lib/src/aqlm/inference_kernels/kernel_selector.py:95-102):
+the numba LUT kernel for 8-bit codebooks is replaced by a native OpenMP / AVX2 kernel (no numba dependency), 16-bit
+single-codebook schemes get a direct kernel instead of a full dequantisation, and everything else (out_group_size > 1,
+odd schemes) takes the pure-torch ``dequantize_gemm`` like the reference.  This is the package's fallback for tensors
+that live on the host -- the MI355X kernels are never routed through it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libaqlm_cpu.so")
+ABI_VERSION = 1
+_lib = None
+
+
+def lib():
+    """libaqlm_cpu.so, loaded on first use (built by ``make -C aqlm_amd/csrc_cpu`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: run `make -C aqlm_amd/csrc_cpu` (or __graft_entry__.build())")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cl, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+        L.aqlm_cpu_abi_version.restype = ci
+        L.aqlm_cpu_max_threads.restype = ci
+        L.aqlm_cpu_lut_scratch_floats.restype = sz
+        L.aqlm_cpu_lut_scratch_floats.argtypes = [ci, ci, ci]
+        L.aqlm_cpu_gemv_lut_kx8.restype = ci
+        L.aqlm_cpu_gemv_lut_kx8.argtypes = [vp, vp, vp, vp, vp, vp, ci, cl, cl, ci, ci, ci, ci, vp, ci]
+        L.aqlm_cpu_gemv_1xn.restype = ci
+        L.aqlm_cpu_gemv_1xn.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, cl, cl, ci, ci, ci, ci, ci]
+        if L.aqlm_cpu_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.aqlm_cpu_abi_version()}, expected {ABI_VERSION}; rebuild it")
+        _lib = L
+    return _lib
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def permute_codes_for_lut(codes: torch.Tensor) -> torch.Tensor:
+    """[out, in_groups, K] -> [in_groups, out, K] uint8: the layout of the LUT kernel (what the reference's
+    ``prepare_matmul_op`` does to ``codes`` IN PLACE for CPU modules, inference.py:78-83; here a derived copy)."""
+    return codes.permute(1, 0, 2).contiguous().view(torch.uint8)
+
+
+def cpu_gemm_lut(input: torch.Tensor, codes_alt: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+                 bias: Optional[torch.Tensor], nthreads: int = 0) -> torch.Tensor:
+    """K x 8-bit schemes through per-row look-up tables (reference: ``numba_gemm_lut``, numba_kernel.py:10-65, same
+    contract: ``codes_alt`` is [in_groups, out, K] uint8).  Any floating input dtype; computed in fp32."""
+    K, cbsize, ogs, g = codebooks.shape
+    if cbsize != 256 or ogs != 1:
+        raise NotImplementedError("cpu_gemm_lut needs codebooks [K, 256, 1, g]")
+    in_groups, out_features, k2 = codes_alt.shape
+    if k2 != K or codes_alt.dtype != torch.uint8:
+        raise ValueError("codes_alt must be uint8 [in_groups, out_features, num_codebooks]")
+    in_features = in_groups * g
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _f32(input.reshape(-1, in_features))
+    cb, sc, bi = _f32(codebooks), _f32(scales.reshape(-1)), _f32(bias)
+    y = torch.empty((x.shape[0], out_features), dtype=torch.float32)
+    scratch = torch.empty((lib().aqlm_cpu_lut_scratch_floats(in_features, K, g),), dtype=torch.float32)
+    rc = lib().aqlm_cpu_gemv_lut_kx8(x.data_ptr(), cb.data_ptr(), codes_alt.contiguous().data_ptr(), sc.data_ptr(), _ptr(bi),
+                                     y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, K, g,
+                                     scratch.data_ptr(), nthreads)
+    if rc:
+        raise RuntimeError(f"aqlm_cpu_gemv_lut_kx8 failed with {rc}")
+    return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))
+
+
+def cpu_gemv_1xn(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
+                 bias: Optional[torch.Tensor], nthreads: int = 0) -> torch.Tensor:
+    """One codebook of up to 65536 entries, g = 8 | 16, canonical codes [out, in_groups, 1] (int8 / int16 containers)."""
+    K, cbsize, ogs, g = codebooks.shape
+    nbits = int(cbsize).bit_length() - 1
+    if K != 1 or ogs != 1 or g not in (8, 16) or 2**nbits != cbsize or codes.dtype not in (torch.int8, torch.int16):
+        raise NotImplementedError("cpu_gemv_1xn needs codebooks [1, 2**n, 1, 8 | 16] and 8- / 16-bit code containers")
+    out_features, in_groups = codes.shape[0], codes.shape[1]
+    in_features = in_groups * g
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _f32(input.reshape(-1, in_features))
+    cb, sc, bi = _f32(codebooks), _f32(scales.reshape(-1)), _f32(bias)
+    c = codes.contiguous()
+    y = torch.empty((x.shape[0], out_features), dtype=torch.float32)
+    rc = lib().aqlm_cpu_gemv_1xn(x.data_ptr(), cb.data_ptr(), c.data_ptr(), c.element_size(), sc.data_ptr(), _ptr(bi),
+                                 y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, nbits, g,
+                                 nthreads)
+    if rc:
+        raise RuntimeError(f"aqlm_cpu_gemv_1xn failed with {rc}")
+    return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))

@@ -52,18 +52,18 @@ def test_state_dict_roundtrip_cpu():
     assert torch.equal(m.codes, sd["codes"]) and m.codes.dtype == torch.int8
 
 
-def test_no_cpu_fallback():
-    """The product has no CPU path: asking for a kernel for CPU tensors must raise, not silently dequantise."""
-    m = aqlm.QuantizedLinear(256, 64, 8, 1, 1, 16, bias=False, dtype=torch.float16)
-    with pytest.raises(NotImplementedError, match="MI355X"):
-        m(torch.zeros(1, 256, dtype=torch.float16))
-    with pytest.raises(NotImplementedError):
-        aqlm.get_forward_pass_kernel(torch.zeros(2, 256, 1, 8), False)
-    with pytest.raises(NotImplementedError):
-        aqlm.get_backward_pass_kernel(torch.zeros(2, 256, 1, 8), True)
+def test_host_tensors_take_the_cpu_branch_and_other_devices_raise():
+    """Host tensors are served by the native CPU kernels (reference kernel_selector.py:95-102); a device the package
+    has no kernels for raises instead of silently dequantising."""
+    from aqlm_amd.inference_kernels import cpu_kernel, kernel_selector
+
+    assert aqlm.get_forward_pass_kernel(torch.zeros(2, 256, 1, 8), False) is cpu_kernel.cpu_gemm_lut
+    assert aqlm.get_forward_pass_kernel(torch.zeros(1, 65536, 1, 8), False) is cpu_kernel.cpu_gemv_1xn
+    assert aqlm.get_forward_pass_kernel(torch.zeros(2, 256, 2, 8), False) is kernel_selector._torch_forward   # out_group_size 2
+    assert aqlm.get_backward_pass_kernel(torch.zeros(2, 256, 1, 8), True) is kernel_selector._torch_backward
 
 
-def test_selector_table_on_meta_codebooks_is_gpu_only():
+def test_selector_table_on_meta_codebooks_raises():
     cb = torch.empty(1, 65536, 1, 8, device="meta", dtype=torch.float16)
     with pytest.raises(NotImplementedError):
         aqlm.get_forward_pass_kernel(cb, False)
@@ -173,7 +173,7 @@ def test_shared_input_grouping_rules_on_meta_modules():
     assert model[3].gate_proj._shared_input_group is None and model[3].q_proj._shared_input_group is None
     assert [n for n, _ in model.named_parameters()] == keys_before   # no parameters added or renamed
     assert aqlm.fuse_shared_input_linears(model) == []
-    # CPU / meta inputs never take the group path (and then hit the usual "GPU only" error of the selector)
+    # CPU / meta inputs never take the group path (host tensors go to the CPU kernels one module at a time)
     assert not groups[0].applicable(torch.zeros(1, 512))
     with pytest.raises(ValueError):
         aqlm.SharedInputGroup([model[0].q_proj])
@@ -234,7 +234,7 @@ def test_checkpoint_tooling_validates_and_upgrades_configs():
     assert any("container range" in p for p in validate_quantized_state_dict(sd12, s12))
     sd12["l.codebooks"][0, 0, 0, 0] = float("nan")
     assert any("non-finite" in p for p in validate_quantized_state_dict(sd12, s12))
-    # memory report / eager repack: CPU models are refused loudly (no CPU kernels)
+    # memory report / eager repack: the MI355X repack refuses host models loudly
     from aqlm.checkpoint import memory_report, prepack_model
 
     rep = memory_report(torch.nn.Sequential(m))
