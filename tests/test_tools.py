@@ -23,7 +23,7 @@ def test_make_pmc_traffic_applies_the_gfx950_correction(tmp_path):
     main = "void aqlm::gemv_1x16_packed_kernel<aqlm::F16, 1, 4, 65520u>(aqlm::PackedGemvParams)"
     fin = "void aqlm::gemv_1x16_packed_finalize<aqlm::F16>(aqlm::PackedFinalizeParams)"
     rows = {"pmc_fetch": [(main, "FETCH_SIZE", 1000.0), (main, "FETCH_SIZE", 3000.0), (fin, "FETCH_SIZE", 10.0),
-                          (fin, "FETCH_SIZE", 10.0), ("aqlm::prepack_count_kernel(...)", "FETCH_SIZE", 9e9)],
+                          (fin, "FETCH_SIZE", 10.0), ("aqlm::pk_count_kernel(...)", "FETCH_SIZE", 9e9)],
             "pmc_write": [(main, "WRITE_SIZE", 100.0), (main, "WRITE_SIZE", 100.0), (fin, "WRITE_SIZE", 4.0), (fin, "WRITE_SIZE", 4.0)]}
     for d, rs in rows.items():
         os.makedirs(tmp_path / d)
@@ -36,6 +36,6 @@ def test_make_pmc_traffic_applies_the_gfx950_correction(tmp_path):
     t = json.loads(out)
     k = t["per_kernel"][main]
     assert k["FETCH_SIZE_KB"] == 2000.0 and k["hbm_bytes"] == 2 * 2000.0 * 1024 + 100.0 * 1024 and k["launches"] == 2
-    assert not any("prepack" in name for name in t["per_kernel"])
+    assert not any("pk_" in name for name in t["per_kernel"])
     per_matvec = (2 * k["hbm_bytes"] + 2 * (2 * 10.0 * 1024 + 4.0 * 1024)) / 2     # main + finalize per matvec
     assert abs(t["gemv_1x16_hbm_bytes_per_launch"] - per_matvec) < 1e-6
