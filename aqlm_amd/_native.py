@@ -56,6 +56,16 @@ class PackedDesc(ctypes.Structure):
 _descp = ctypes.POINTER(PackedDesc)
 _descpp = ctypes.POINTER(_descp)
 
+
+class Xgmi(ctypes.Structure):
+    """aqlm_hip_xgmi (include/aqlm_hip.h): one rank's view of the one-shot all-reduce state."""
+
+    _fields_ = [("peer_pub", _vp), ("peer_flag", _vp), ("epoch", _vp), ("status", _vp), ("rank", _ci), ("world", _ci),
+                ("max_elems", _ci), ("spin_limit", ctypes.c_uint32)]
+
+
+_xgp = ctypes.POINTER(Xgmi)
+
 # name -> (restype, argtypes); mirrors include/aqlm_hip.h one to one
 SIGNATURES = {
     "aqlm_hip_abi_version": (_ci, []),
@@ -70,6 +80,9 @@ SIGNATURES = {
     "aqlm_hip_packed_desc_read": (_ci, [_vp, _sz, _descp]),
     "aqlm_hip_unpack_1x16": (_ci, [_descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_1x16_packed_partials": (_ci, [_descp, _vp, _vp, _vp, _ci, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_xgmi_state_bytes": (_sz, [_ci]),
+    "aqlm_hip_xgmi_finalize": (_ci, [_xgp, _vp, _vp, _vp, _vp, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_8x8_lut": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_8x8_lut_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),

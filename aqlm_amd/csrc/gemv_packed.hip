@@ -1102,70 +1102,89 @@ extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void
   return check_hip(hipGetLastError(), "unpack launch");
 }
 
+// main kernel of one launch (<= packed_max_batch rows): fp32 slice partials [16][nb][M] -> workspace
+static int packed_launch_main(const PackedLayout& L, const void* packed, const void* codebook, const uint16_t* x, int nb,
+                              long x_row_stride, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                              const char* who) {
+  const size_t need = (size_t)PK_S * nb * L.M * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_last_error("%s: workspace of %zu bytes required, got %zu", who, need, workspace_bytes);
+    return AQLM_HIP_E_INVALID;
+  }
+  const uint8_t* base = (const uint8_t*)packed;
+  PackedGemvParams p{};
+  p.ent = (const uint32_t*)(base + L.off_ent);
+  p.winfo = (const uint32_t*)(base + L.off_winfo);
+  p.rowstart = (const uint32_t*)(base + L.off_rowstart);
+  p.codebook = (const uint8_t*)codebook;
+  p.x = x;
+  p.partial = (float*)workspace;
+  p.x_row_stride = x_row_stride;
+  p.M = L.M;
+  p.in_groups = L.in_groups;
+  p.RG = L.RG;
+  p.NW = L.NW;
+  p.T = L.T;
+  p.XC = L.XC;
+  p.ent_bytes = (uint32_t)L.ent_bytes;
+#ifdef AQLM_PACKED_TRACE
+  p.trace = workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+  p.dbg = tuning().packed_debug;
+#endif
+  auto launch = [&](auto kern, auto lds_map) -> int {
+    const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG);
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
+  };
+  return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, launch);
+}
+
+static int packed_check_args(const char* who, const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+                             const void* x, int batch, long x_row_stride, int dtype, PackedLayout& L, int& max_b) {
+  if (!packed || !codebook || !x || !desc) {
+    set_last_error("%s: null pointer argument", who);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
+    set_last_error("%s: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)", who, dtype);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (!desc_layout(desc, L)) {
+    set_last_error("%s: invalid packed descriptor", who);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (batch < 1 || batch > AQLM_HIP_MAX_GEMV_BATCH || !aligned16(packed) || !aligned16(codebook) || !aligned16(x) ||
+      (batch > 1 && x_row_stride % 8 != 0)) {
+    set_last_error("%s: batch must be 1..%d and packed / codebook / x rows 16-B aligned (batch %d)", who,
+                   AQLM_HIP_MAX_GEMV_BATCH, batch);
+    return AQLM_HIP_E_INVALID;
+  }
+  max_b = packed_max_batch(L.in_groups, L.RG);
+  if (max_b == 0) {
+    set_last_error("%s: layer does not fit the LDS image (in_features %d)", who, desc->in_features);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  return 0;
+}
+
 extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
                                          const void* scales, const void* bias, const void* x, void* y, int batch,
                                          long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                          size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!packed || !codebook || !scales || !x || !y || !desc) {
+  PackedLayout L;
+  int max_b = 0;
+  if (!scales || !y) {
     set_last_error("aqlm_hip_gemv_1x16_packed: null pointer argument");
     return AQLM_HIP_E_INVALID;
   }
-  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
-    set_last_error("aqlm_hip_gemv_1x16_packed: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)", dtype);
-    return AQLM_HIP_E_UNSUPPORTED;
-  }
-  PackedLayout L;
-  if (!desc_layout(desc, L)) {
-    set_last_error("aqlm_hip_gemv_1x16_packed: invalid packed descriptor");
-    return AQLM_HIP_E_INVALID;
-  }
-  if (batch < 1 || batch > AQLM_HIP_MAX_GEMV_BATCH || !aligned16(packed) || !aligned16(codebook) || !aligned16(x) ||
-      (batch > 1 && x_row_stride % 8 != 0)) {
-    set_last_error("aqlm_hip_gemv_1x16_packed: batch must be 1..%d and packed / codebook / x rows 16-B aligned (batch %d)",
-                   AQLM_HIP_MAX_GEMV_BATCH, batch);
-    return AQLM_HIP_E_INVALID;
-  }
-  const int max_b = packed_max_batch(L.in_groups, L.RG);
-  if (max_b == 0) {
-    set_last_error("aqlm_hip_gemv_1x16_packed: layer does not fit the LDS image (in_features %d)", desc->in_features);
-    return AQLM_HIP_E_UNSUPPORTED;
-  }
-  const uint8_t* base = (const uint8_t*)packed;
-  const int pd = pick_pd(L);
+  if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b)) return e;
   for (int b0 = 0; b0 < batch; b0 += max_b) {  // rows that do not fit one LDS image go in several launches
     const int nb = std::min(max_b, batch - b0);
-    const size_t need = (size_t)PK_S * nb * L.M * sizeof(float);
-    if (!workspace || workspace_bytes < need) {
-      set_last_error("aqlm_hip_gemv_1x16_packed: workspace of %zu bytes required, got %zu", need, workspace_bytes);
-      return AQLM_HIP_E_INVALID;
-    }
-    PackedGemvParams p{};
-    p.ent = (const uint32_t*)(base + L.off_ent);
-    p.winfo = (const uint32_t*)(base + L.off_winfo);
-    p.rowstart = (const uint32_t*)(base + L.off_rowstart);
-    p.codebook = (const uint8_t*)codebook;
-    p.x = (const uint16_t*)x + (size_t)b0 * x_row_stride;
-    p.partial = (float*)workspace;
-    p.x_row_stride = x_row_stride;
-    p.M = L.M;
-    p.in_groups = L.in_groups;
-    p.RG = L.RG;
-    p.NW = L.NW;
-    p.T = L.T;
-    p.XC = L.XC;
-    p.ent_bytes = (uint32_t)L.ent_bytes;
-#ifdef AQLM_PACKED_TRACE
-    p.trace = workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
-    p.dbg = tuning().packed_debug;
-#endif
-    auto launch = [&](auto kern, auto lds_map) -> int {
-      const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG);
-      if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-      hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p);
-      return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
-    };
-    if (int e = dispatch_packed<SingleKernels>(dtype, nb, pd, L.EB, launch)) return e;
+    if (int e = packed_launch_main(L, packed, codebook, (const uint16_t*)x + (size_t)b0 * x_row_stride, nb, x_row_stride, dtype,
+                                   workspace, workspace_bytes, stream, "aqlm_hip_gemv_1x16_packed"))
+      return e;
     PackedFinalizeParams f{};
     f.partial = (const float*)workspace;
     f.scales = (const uint16_t*)scales;
@@ -1181,6 +1200,22 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
     if (int e = check_hip(hipGetLastError(), "gemv_1x16_packed_finalize launch")) return e;
   }
   return 0;
+}
+
+extern "C" int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+                                                  const void* x, int batch, long x_row_stride, int dtype, void* workspace,
+                                                  size_t workspace_bytes, void* stream_) {
+  PackedLayout L;
+  int max_b = 0;
+  if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed_partials", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b))
+    return e;
+  if (batch > max_b) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_partials: %d rows do not fit one LDS image (at most %d for in_features %d)", batch,
+                   max_b, desc->in_features);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  return packed_launch_main(L, packed, codebook, (const uint16_t*)x, batch, x_row_stride, dtype, workspace, workspace_bytes,
+                            (hipStream_t)stream_, "aqlm_hip_gemv_1x16_packed_partials");
 }
 
 extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,

@@ -19,6 +19,12 @@ large enough (a 1024-wide shard of the 70B layer is 3.7 M codes: 10.8 us prepack
 whatever ``get_forward_pass_kernel`` returns for the shard's codebooks; tests inject a different ``kernel`` to exercise
 the sharding + collective logic on CPU with the gloo backend.
 
+``collective="xgmi"`` (in-split, prepacked shards, one node) replaces the library all-reduce by the fused finalize of
+``aqlm_amd/csrc/xgmi_reduce.hip``: the shard's main kernel leaves fp32 slice partials, every rank publishes their sum in
+IPC-mapped memory and the finalize of every rank adds the R vectors in rank order straight over xGMI -- no extra launch,
+fp32 on the wire, one rounding, replicas of y bit-identical.  The ranks agree collectively at first use whether every
+shard can take that path; otherwise all of them fall back to ``dist.all_reduce``.
+
 Reduction precision of the in-split: partial outputs are fp16 / bf16 tensors; summing 8 of them in the storage dtype
 costs up to ~3 roundings of 2^-11 relative each on top of the per-shard rounding.  ``reduce_dtype=torch.float32`` (default
 for fp16 / bf16 layers) all-reduces fp32 partials (112 KiB instead of 56 KiB for the 70B layer: still latency-bound) and
@@ -26,6 +32,7 @@ rounds once; ``reduce_dtype=None`` keeps the storage dtype on the wire.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Callable, Optional
 
 import torch
@@ -50,8 +57,14 @@ class ShardedQuantizedLinear(nn.Module):
 
     def __init__(self, codes, codebooks, scales, bias, *, mode: str, in_group_size: int, in_lo: int, in_hi: int,
                  out_lo: int, out_hi: int, out_features: int, group=None, gather_output: bool = True,
-                 kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = torch.float32):
+                 kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = torch.float32,
+                 collective: str = "rccl", bias_all: Optional[torch.Tensor] = None):
         super().__init__()
+        assert collective in ("rccl", "xgmi")
+        self.collective = collective
+        self._bias_all = bias_all      # the full bias on every rank (the fused finalize writes the full y everywhere)
+        self._xgmi = None              # OneShotAllReduce, built collectively at first use
+        self._xgmi_ok = None
         assert mode in ("in", "out")
         self.mode = mode
         self.group = group
@@ -70,7 +83,8 @@ class ShardedQuantizedLinear(nn.Module):
 
     @classmethod
     def from_full(cls, codes, codebooks, scales, bias, *, mode: str = "in", group=None, gather_output: bool = True,
-                  kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = torch.float32):
+                  kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = torch.float32,
+                  collective: str = "rccl"):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         out_groups, in_groups, _ = codes.shape
@@ -82,7 +96,8 @@ class ShardedQuantizedLinear(nn.Module):
             b = bias if (bias is not None and rank == 0) else None
             return cls(c, codebooks, scales, b, mode=mode, in_group_size=g, in_lo=j0 * g, in_hi=j1 * g, out_lo=0,
                        out_hi=out_groups, out_features=out_groups, group=group, gather_output=gather_output,
-                       kernel=kernel, reduce_dtype=reduce_dtype)
+                       kernel=kernel, reduce_dtype=reduce_dtype, collective=collective,
+                       bias_all=bias if collective == "xgmi" else None)
         i0, i1 = shard_bounds(out_groups, world, rank)
         return cls(codes[i0:i1].contiguous(), codebooks, scales[i0:i1].contiguous(),
                    None if bias is None else bias[i0:i1].contiguous(), mode=mode, in_group_size=g, in_lo=0,
@@ -114,8 +129,46 @@ class ShardedQuantizedLinear(nn.Module):
             return hip_kernel.code1x16_matmat_packed(x, self._packed, self.codebooks, self.scales, bias)
         return self._k()(x, self.codes, self.codebooks, self.scales, bias)
 
+    def _xgmi_forward(self, xs: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
+        """Shard matvec + fused finalize / all-reduce; None when the ranks agreed to use the library collective."""
+        from . import _native, inference
+        from .inference_kernels import hip_kernel
+        from .xgmi import OneShotAllReduce
+
+        if self._xgmi_ok is None:  # first use: collective decision + state exchange
+            if not self._packed_tried and self.codes.is_cuda and self.codes.shape[1] > 0:
+                self._packed_tried = True
+                if (tuple(self.codebooks.shape[:3]) == (1, 65536, 1) and self.codebooks.shape[3] == 8
+                        and self.codes.shape[0] * self.codes.shape[1] >= inference.PREPACK_MIN_CODES):
+                    self._packed = hip_kernel.prepack_1x16(self.codes, 8)
+            ok = torch.tensor([1 if self._packed is not None else 0], device=xs.device)
+            if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            self._xgmi_ok = bool(int(ok))
+            if self._xgmi_ok:
+                self._xgmi = OneShotAllReduce(_native.MAX_GEMV_BATCH * self.out_features, xs.device, self.group)
+        if not self._xgmi_ok or rows > _native.MAX_GEMV_BATCH or xs.dtype != self.codebooks.dtype:
+            return None
+        x2 = hip_kernel._flat_rows(xs)
+        dt = hip_kernel._dtype_id(xs)
+        y = torch.empty((rows, self.out_features), dtype=xs.dtype, device=xs.device)
+        ws = hip_kernel._workspace(xs.device, 16 * rows * self.out_features * 4)
+        stream = hip_kernel._stream_ptr(xs.device)
+        with torch.cuda.device(xs.device):
+            rc = _native.lib.aqlm_hip_gemv_1x16_packed_partials(ctypes.byref(self._packed.desc), self._packed.data_ptr(),
+                                                                self.codebooks.data_ptr(), x2.data_ptr(), rows, x2.stride(0),
+                                                                dt, ws.data_ptr(), ws.numel() * 4, stream)
+            if rc:
+                _native.check(rc, "aqlm gemv_1x16_packed_partials")
+            self._xgmi.finalize(ws, self.scales, self._bias_all, y, self.out_features, rows, dt, stream)
+        return y.reshape(xs.shape[:-1] + (self.out_features,))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if self.mode == "in" and self.collective == "xgmi" and x.is_cuda and self._kernel is None:
+            y = self._xgmi_forward(x[..., self.in_lo:self.in_hi], x.numel() // x.shape[-1])
+            if y is not None:
+                return y
         if self.mode == "in":
             xs = x[..., self.in_lo:self.in_hi]
             if self.codes.shape[1] == 0:  # more ranks than 8-group blocks: this rank contributes nothing

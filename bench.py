@@ -341,7 +341,56 @@ def sharded_70b(lib, dev, rank, world, steps):
         full_bytes = algorithmic_bytes(fin, fout)
         out.update({"end_to_end_us": e2e_us, "allreduce_bytes": fout * 2,
                     "aggregate_GBps_kernel_only": world * layers[0].bytes / kernel_us * 1e-3,
-                    "aggregate_GBps_end_to_end": full_bytes / e2e_us * 1e-3})
+                    "aggregate_GBps_end_to_end": full_bytes / e2e_us * 1e-3,
+                    "collective": "RCCL all-reduce (fp16, 56 KiB) behind the shard kernel"})
+        # the MI355X-native variant: finalize fused with a one-shot all-reduce over xGMI (aqlm_amd/csrc/xgmi_reduce.hip).
+        # Every rank first agrees that it can run it (peer access to every other GPU of the node); any failure is
+        # reported, never fatal -- the RCCL figure above stands on its own.
+        try:
+            import ctypes
+
+            from aqlm_amd import _native
+            from aqlm_amd.xgmi import OneShotAllReduce
+
+            can = all(r == torch.cuda.current_device() or torch.cuda.can_device_access_peer(torch.cuda.current_device(), r)
+                      for r in range(torch.cuda.device_count())) and all(l.packed is not None for l in layers)
+            flag = torch.tensor([1 if can else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag):
+                ar = OneShotAllReduce(fout, dev)
+                sc = layers[0].scales
+
+                def fused(l):
+                    rc = lib.aqlm_hip_gemv_1x16_packed_partials(ctypes.byref(l.packed.desc), l.packed.data_ptr(),
+                                                                l.codebooks.data_ptr(), l.x.data_ptr(), 1, l.fin, _native.F16,
+                                                                l.ws.data_ptr(), l.ws.numel() * 4, s.cuda_stream)
+                    if rc:
+                        _native.check(rc)
+                    ar.finalize(l.ws, sc, None, l.y, fout, 1, _native.F16, s.cuda_stream)
+
+                for _ in range(5):
+                    fused(layers[0])
+                torch.cuda.synchronize()
+                y_native = layers[0].y.float().clone()
+                layers[0].launch(lib, s.cuda_stream)
+                y32 = layers[0].y.float()
+                dist.all_reduce(y32)
+                rel = float((y_native - y32).abs().mean() / y32.abs().mean())
+                dist.barrier()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    fused(layers[i % len(layers)])
+                torch.cuda.synchronize()
+                dt = torch.tensor([(time.perf_counter() - t0) / n], device=dev)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                x_us = float(dt.item()) * 1e6
+                out["xgmi_one_shot"] = {"end_to_end_us": x_us, "aggregate_GBps_end_to_end": full_bytes / x_us * 1e-3,
+                                        "mean_rel_vs_rccl_fp32_sum": rel, "timed_out": ar.timed_out(),
+                                        "note": "shard kernel -> publish -> finalize-with-reduce; fp32 on the wire, no RCCL launch"}
+            else:
+                out["xgmi_one_shot"] = {"skipped": "no peer access between all GPUs of the node, or a shard is not prepacked"}
+        except Exception as e:  # noqa: BLE001 - diagnostics only
+            out["xgmi_one_shot"] = {"error": f"{type(e).__name__}: {e}"}
     else:
         out["collective"] = "unmeasured (1 GPU)"
     return out

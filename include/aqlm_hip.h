@@ -217,6 +217,35 @@ int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm
                                     int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Row-parallel ("in"-split) layers over several MI355X: the finalize of the prepacked matvec fused with a ONE-SHOT
+ * all-reduce over xGMI (no reference counterpart -- the reference has no tensor parallelism; BASELINE.json north star:
+ * the 70B layer 8192 -> 28672 split over 8 GPUs).  Every rank runs aqlm_hip_gemv_1x16_packed_partials on its shard (the
+ * main kernel only: fp32 slice partials [16][batch][out] in `workspace`), then aqlm_hip_xgmi_finalize: it publishes the
+ * slice-summed vector in a buffer the peers have mapped (IPC), raises a flag, waits (bounded) for the peers' flags, reads
+ * their vectors over xGMI and adds them in rank order, then scale + bias + one rounding -- y is bit-identical on every rank.
+ * State per rank: one device allocation of aqlm_hip_xgmi_state_bytes(max_elems) bytes, zero-filled except epoch = 1, laid
+ * out as  [pub: 2 x max_elems fp32][flag: 2 x u32 at byte 8 * max_elems][epoch, 2 tickets: 3 x u32 at +64][status: u32 at +128];
+ * `peer_pub[r]` / `peer_flag[r]` are DEVICE arrays (world entries) of the peers' pub / flag addresses as mapped into this
+ * process (own entries included).  Collective semantics: every rank calls it the same number of times.  On a time-out
+ * (spin_limit polls, 0 = default ~seconds) status becomes 1 and y is NaN.  Graph-capturable (the epoch lives in device memory).
+ */
+typedef struct aqlm_hip_xgmi {
+  const void* const* peer_pub;   /* device array [world] of float* */
+  const void* const* peer_flag;  /* device array [world] of uint32_t* */
+  void* epoch;                   /* this rank's epoch / ticket words (device) */
+  void* status;                  /* this rank's status word (device) */
+  int rank, world, max_elems;
+  uint32_t spin_limit;
+} aqlm_hip_xgmi;
+
+size_t aqlm_hip_xgmi_state_bytes(int max_elems);
+int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook, const void* x,
+                                       int batch, long x_row_stride, int dtype, void* workspace, size_t workspace_bytes,
+                                       void* stream);
+int aqlm_hip_xgmi_finalize(const aqlm_hip_xgmi* xg, const void* partials, const void* scales, const void* bias, void* y,
+                           int out_features, int batch, long y_row_stride, int dtype, void* stream);
+
+/*
  * Batch-1 matvec for 8 x 8-bit schemes (e.g. the 2-bit 8x8 g32 models; in_group_size 8, 16 or 32) through per-token
  * look-up tables in LDS:  lut[j,c,v] = <codebooks[c,v], x_j>,  y[i] = sum lut[j,c,codes[i,j,c]]  -- the formulation of
  * the reference's CPU kernel (numba_kernel.py:37-48) mapped onto LDS slabs.  Same result contract as aqlm_hip_gemv_kx8

@@ -86,3 +86,54 @@ def test_shard_bounds_cover_and_align():
         for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
             assert a1 == b0 and a0 <= a1
         assert all(lo % mult == 0 for lo, _ in spans)
+
+
+def _oneshot_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.multiprocessing.set_sharing_strategy("file_system")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+
+        from aqlm_amd.xgmi import HostOneShotAllReduce
+
+        n = 1000
+        ar = HostOneShotAllReduce(n)
+        rng = np.random.default_rng(100 + rank)
+        outs = []
+        for it in range(40):
+            # uneven pace: a rank may be a full call ahead of its peers (what the double buffering is for)
+            if (it * 7 + rank * 3) % 5 == 0:
+                time.sleep(0.004 * rng.random())
+            v = torch.from_numpy(np.random.default_rng(1000 * it + rank).standard_normal(n).astype(np.float32))
+            outs.append(ar.all_reduce(v))
+        # expected: the sum in rank order, in fp32
+        ok = True
+        for it in range(40):
+            exp = torch.zeros(n)
+            for r in range(world):
+                exp += torch.from_numpy(np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float32))
+            ok = ok and torch.equal(outs[it], exp)
+        digest = float(torch.stack(outs).double().sum())
+        q.put((rank, ok, digest))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_shot_all_reduce_protocol_on_host_memory(world):
+    """The hand-shake of the fused finalize + all-reduce (aqlm_amd/csrc/xgmi_reduce.hip), played on host shared memory:
+    publish into pub[epoch & 1], raise flag[epoch & 1] = epoch, poll the peers, add in rank order, next epoch.  Ranks run
+    at uneven pace for 40 calls; every replica must hold exactly the rank-ordered fp32 sum, bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert all(ok for _, ok, _ in res)
+    assert len({d for _, _, d in res}) == 1   # bit-identical replicas
