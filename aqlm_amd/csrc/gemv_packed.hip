@@ -672,6 +672,16 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #pragma unroll
     for (int g0 = 0; g0 < 4; g0 += EG) {
       u32x4 ev[EG], xv[EG][B];
+#ifdef AQLM_PACKED_TRACE
+      if (p.dbg & 8) {  // no LDS reads: the dot products run on register garbage (what does the VALU part cost alone?)
+#pragma unroll
+        for (int k = 0; k < EG; ++k) {
+          ev[k] = u32x4{a_cb[g0 + k], a_x[g0 + k], a_cb[g0 + k] ^ 0x3c00u, a_x[g0 + k] ^ 0x3c00u};
+#pragma unroll
+          for (int b = 0; b < B; ++b) xv[k][b] = u32x4{a_x[g0 + k], a_cb[g0 + k], a_x[g0 + k] ^ 0x3c00u, a_cb[g0 + k]};
+        }
+      } else
+#endif
 #pragma unroll
       for (int k = 0; k < EG; ++k) {
         ev[k] = *(lds_u32x4_ptr)(size_t)(a_cb[g0 + k] + LDS::SLICE);
@@ -683,6 +693,13 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
           for (int b = 0; b < B; ++b) xv[k][b] = *(lds_u32x4_ptr)(size_t)(ax + (uint32_t)b * XP);
         }
       }
+#ifdef AQLM_PACKED_TRACE
+      if (p.dbg & 4) {  // LDS reads but no dot products: one op per entry keeps the reads alive
+#pragma unroll
+        for (int k = 0; k < EG; ++k) acc[0][0] += __uint_as_float((ev[k].x ^ xv[k][0].w) & 0x007fffffu);
+        continue;
+      }
+#endif
 #pragma unroll
       for (int k = 0; k < EG; ++k)
 #pragma unroll

@@ -548,8 +548,9 @@ static void bench_trace(int in, int out) {
   std::vector<unsigned long long> h(256 * NWMAX * 8);
   const int NW = layers[0].desc.waves;
   const char* names[7] = {"entry", "loads issued", "LDS filled (barrier)", "-", "loop done", "2nd barrier", "end"};
-  for (int rep = 0; rep < 4; ++rep) {
-    aqlm_hip_set_tuning("packed_debug", rep == 0 ? 0 : rep - 1 < 3 ? rep - 1 : 0);  // runs: -, full, no compute, no stream
+  const int dbgs[6] = {0, 0, 1, 2, 2 | 4, 2 | 8};  // runs: warm-up, full, no compute, no stream, no stream + no dots, no stream + no LDS reads
+  for (int rep = 0; rep < 6; ++rep) {
+    aqlm_hip_set_tuning("packed_debug", dbgs[rep]);
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
     CK(hipMemset(tr, 0, h.size() * 8));
     CK(hipDeviceSynchronize());
@@ -558,8 +559,8 @@ static void bench_trace(int in, int out) {
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) t0 = std::min(t0, h[(b * NWMAX + w) * 8]);
-    printf("# packed %d->%d cold, run %d [debug %d: 0 full, 1 no LDS reads / dots, 2 no entry stream] (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
-           in, out, rep, rep == 0 ? 0 : rep - 1, NW, layers[0].desc.steps, 256 * NW);
+    printf("# packed %d->%d cold, run %d [debug %d: 0 full, 1 no LDS reads / dots, 2 no entry stream, +4 no dots, +8 no LDS reads] (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
+           in, out, rep, dbgs[rep], NW, layers[0].desc.steps, 256 * NW);
     for (int i = 0; i < 7; ++i) {
       if (i == 3) continue;
       double mn = 1e9, mx = 0, sum = 0;
