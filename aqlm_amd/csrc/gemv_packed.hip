@@ -730,7 +730,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
       const uint32_t w[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        a_cb[k] = half_and<0>(w[k], mask);
+        a_cb[k] = half_and<0>(w[k], mask);  // (plain v_and / v_lshrrev instead of the two SDWA ops: measured, no change)
         a_x[k] = half_and<1>(w[k], mask);
         if constexpr (B > 1) copy[k] = (w[k] >> 16) & 3u;
       }

@@ -102,11 +102,11 @@ __global__ __launch_bounds__(1024) void ldsgather(uint32_t entry_mask, int iters
 
 // ---------------------------------------------------------------- VALU / LDS issue rates of the packed kernel's inner loop
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-template <int MODE>  // 0: v_dot2c_f32_f16, 1: v_fma_f32, 2: v_and_b32_sdwa
+template <int MODE>  // 0: v_dot2c_f32_f16, 1: v_fma_f32, 2..8: integer ops (see the chains below)
 __global__ __launch_bounds__(1024) void valu_rate(int iters, float* out) {
   float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f;
-  uint32_t w0 = threadIdx.x * 2654435761u, w1 = w0 ^ 0x3c003c00u;
-  uint32_t m = 0xfff0u;
+  uint32_t w0 = threadIdx.x * 2654435761u, w1 = w0 ^ 0x3c003c00u, w2 = ~w0, w3 = ~w1;
+  uint32_t m = 0xfffffff0u;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -119,16 +119,24 @@ __global__ __launch_bounds__(1024) void valu_rate(int iters, float* out) {
         a0 = __builtin_fmaf(a0, 1.0001f, 0.5f); a1 = __builtin_fmaf(a1, 1.0001f, 0.5f);
         a2 = __builtin_fmaf(a2, 1.0001f, 0.5f); a3 = __builtin_fmaf(a3, 1.0001f, 0.5f);
       } else {
-        uint32_t d0, d1, d2, d3;
-        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d0) : "v"(m), "v"(w0));
-        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d1) : "v"(m), "v"(w0));
-        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d2) : "v"(m), "v"(w1));
-        asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d3) : "v"(m), "v"(w1));
-        w0 ^= d0 ^ d2; w1 ^= d1 ^ d3;
+        // integer ops: four independent self-chains (the values collapse, the issue slots do not)
+#define MB_CHAIN(INSN)                                   \
+        asm volatile(INSN : "+v"(w0) : "v"(m));          \
+        asm volatile(INSN : "+v"(w1) : "v"(m));          \
+        asm volatile(INSN : "+v"(w2) : "v"(m));          \
+        asm volatile(INSN : "+v"(w3) : "v"(m));
+        if (MODE == 2) { MB_CHAIN("v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1") }
+        if (MODE == 3) { MB_CHAIN("v_and_b32 %0, %1, %0") }
+        if (MODE == 4) { MB_CHAIN("v_lshrrev_b32 %0, 1, %0") }
+        if (MODE == 5) { MB_CHAIN("v_pk_lshlrev_b16 %0, 1, %0") }
+        if (MODE == 6) { MB_CHAIN("v_bfe_u32 %0, %0, 1, 31") }
+        if (MODE == 7) { MB_CHAIN("v_and_b32 %0, 0xfffffff0, %0") }
+        if (MODE == 8) { MB_CHAIN("v_xor_b32 %0, %1, %0") }
+#undef MB_CHAIN
       }
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(w0 ^ w1);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(w0 ^ w1 ^ w2 ^ w3);
 }
 
 // ds_read_b128 with the addresses held in registers (no address arithmetic in the loop): MODE 0 random slots,
@@ -289,6 +297,12 @@ static void bench_rates() {
     run("v_dot2c_f32_f16", valu_rate<0>, thr, 32);
     run("v_fma_f32", valu_rate<1>, thr, 32);
     run("v_and_b32_sdwa", valu_rate<2>, thr, 32);
+    run("v_and_b32", valu_rate<3>, thr, 32);
+    run("v_lshrrev_b32", valu_rate<4>, thr, 32);
+    run("v_pk_lshlrev_b16", valu_rate<5>, thr, 32);
+    run("v_bfe_u32", valu_rate<6>, thr, 32);
+    run("v_and_b32 literal", valu_rate<7>, thr, 32);
+    run("v_xor_b32", valu_rate<8>, thr, 32);
   }
   auto runl = [&](const char* name, auto kern, int threads) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
