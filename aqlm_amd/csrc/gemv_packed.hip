@@ -549,13 +549,12 @@ struct PackedLds {
 
 // `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
 template <class T_, int B, int PD, uint32_t XWIN, int EB>
-__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block) {
+__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block, const int NWB) {
   using LDS = PackedLds<B, XWIN>;
   using ring_t = typename std::conditional<EB == 3, u32x3, u32x4>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int NT = (int)blockDim.x;
-  const int NWB = NT >> 6;                                              // waves in the workgroup (>= p.NW)
+  const int NT = NWB << 6;  // NWB = waves in the workgroup (>= p.NW); passed in: blockDim lives in the hidden kernel arguments
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef AQLM_PACKED_TRACE
   unsigned long long tr[7];
@@ -633,9 +632,15 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #pragma unroll
   for (int k = 0; k < PD; ++k) ring[k] = fetch(k);
   // (3) steps of this wave through the scalar cache (not a VMEM op: it must not sit in the vmcnt queue, see (5))
-  const const_u32_ptr wi = (const_u32_ptr)(uintptr_t)(p.winfo + ((size_t)block * p.NW + wv) * 4);
-  const int steps = wave < p.NW ? (int)wi[2] : 0;
-  const uint32_t wave_start_row = wi[3];
+  // 4-byte entries need neither: the start rows ride in the entries, and every wave range runs all T steps (the tail of a
+  // stream is padded with null entries up to T steps -- the workgroup waits for its full ranges anyway)
+  int steps = wave < p.NW ? p.T : 0;
+  [[maybe_unused]] uint32_t wave_start_row = 0u;
+  if constexpr (EB == 3) {
+    const const_u32_ptr wi = (const_u32_ptr)(uintptr_t)(p.winfo + ((size_t)block * p.NW + wv) * 4);
+    steps = wave < p.NW ? (int)wi[2] : 0;
+    wave_start_row = wi[3];
+  }
   // (4) LDS that needs no data: the zero vectors the null entries point at
   if (tid < B) *reinterpret_cast<u32x4*>(smem_raw + LDS::X + (uint32_t)tid * XP + (uint32_t)p.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};
   AQLM_TRACE(1);  // every load of the prologue has been issued
@@ -818,9 +823,45 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #endif
 }
 
+// What the prologue needs before it can issue its first load comes as individual leading arguments: with
+// -amdgpu-kernarg-preload-count (Makefile) the command processor delivers those 14 dwords in SGPRs at wave launch, and
+// the cold s_load round trip of the kernel-argument segment leaves the head of the critical path.  Struct arguments
+// are not preloaded; the rest of the parameters (needed after the LDS fill) stay in one.
+struct PackedGemvRest {
+  const uint32_t* winfo;
+  float* partial;
+  long x_row_stride;
+#ifdef AQLM_PACKED_TRACE
+  unsigned long long* trace;
+  int dbg;
+#endif
+};
+
 template <class T_, int B, int PD, uint32_t XWIN, int EB>
-__global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const PackedGemvParams p) {
-  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, blockIdx.x);
+__global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* codebook, const uint16_t* x, const uint32_t* ent,
+                                                                const uint32_t* rowstart, int in_groups, uint32_t geom, int RG,
+                                                                uint32_t ent_bytes, int M, const PackedGemvRest rest) {
+  const int NW = (int)(geom & 0xffu), XC = (int)((geom >> 8) & 0xffu), T = (int)(geom >> 16);
+  PackedGemvParams p;
+  p.ent = ent;
+  p.winfo = rest.winfo;
+  p.rowstart = rowstart;
+  p.codebook = codebook;
+  p.x = x;
+  p.partial = rest.partial;
+  p.x_row_stride = rest.x_row_stride;
+  p.M = M;
+  p.in_groups = in_groups;
+  p.RG = RG;
+  p.NW = NW;
+  p.T = T;
+  p.XC = XC;
+  p.ent_bytes = ent_bytes;
+#ifdef AQLM_PACKED_TRACE
+  p.trace = rest.trace;
+  p.dbg = rest.dbg;
+#endif
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, blockIdx.x, NW);
 }
 
 // Several prepacked layers that multiply the same x (q/k/v, gate/up) in one launch of 256 workgroups per layer; the
@@ -865,7 +906,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const Pack
       p.ent_bytes = mp.seg[k].ent_bytes;
     }
   }
-  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, (int)blockIdx.x & 255);
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, (int)blockIdx.x & 255, (int)blockDim.x >> 6);
 }
 
 struct PackedFinalizeParams {
@@ -890,8 +931,19 @@ __device__ __forceinline__ void packed_finalize_row(const PackedFinalizeParams& 
   }
 }
 
+// scalar arguments: preloaded into SGPRs at wave launch (see gemv_1x16_packed_kernel); this kernel is one dependent load
+// round trip long, the kernel-argument fetch would be a second one
 template <class T_>
-__global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const PackedFinalizeParams p) {
+__global__ __launch_bounds__(256) void gemv_1x16_packed_finalize(const float* partial, const uint16_t* scales, const uint16_t* bias,
+                                                                 uint16_t* y, long y_row_stride, int M, int B) {
+  PackedFinalizeParams p;
+  p.partial = partial;
+  p.scales = scales;
+  p.bias = bias;
+  p.y = y;
+  p.y_row_stride = y_row_stride;
+  p.M = M;
+  p.B = B;
   packed_finalize_row<T_>(p, blockIdx.x * 256 + threadIdx.x);
 }
 
@@ -1151,7 +1203,16 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   auto launch = [&](auto kern, auto lds_map) -> int {
     const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG);
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p);
+    PackedGemvRest rest{};
+    rest.winfo = p.winfo;
+    rest.partial = p.partial;
+    rest.x_row_stride = p.x_row_stride;
+#ifdef AQLM_PACKED_TRACE
+    rest.trace = p.trace;
+    rest.dbg = p.dbg;
+#endif
+    hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p.codebook, p.x, p.ent, p.rowstart, p.in_groups,
+                       (uint32_t)p.NW | ((uint32_t)p.XC << 8) | ((uint32_t)p.T << 16), p.RG, p.ent_bytes, p.M, rest);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
   return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, launch);
@@ -1211,9 +1272,11 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
     f.M = L.M;
     f.B = nb;
     if (dtype == AQLM_HIP_F16)
-      hipLaunchKernelGGL(gemv_1x16_packed_finalize<F16>, dim3((L.M + 255) / 256), dim3(256), 0, stream, f);
+      hipLaunchKernelGGL(gemv_1x16_packed_finalize<F16>, dim3((L.M + 255) / 256), dim3(256), 0, stream, f.partial, f.scales, f.bias,
+                         f.y, f.y_row_stride, f.M, f.B);
     else
-      hipLaunchKernelGGL(gemv_1x16_packed_finalize<BF16>, dim3((L.M + 255) / 256), dim3(256), 0, stream, f);
+      hipLaunchKernelGGL(gemv_1x16_packed_finalize<BF16>, dim3((L.M + 255) / 256), dim3(256), 0, stream, f.partial, f.scales, f.bias,
+                         f.y, f.y_row_stride, f.M, f.B);
     if (int e = check_hip(hipGetLastError(), "gemv_1x16_packed_finalize launch")) return e;
   }
   return 0;

@@ -1,11 +1,14 @@
 #!/bin/bash
+# A/B: library built with / without kernel-argument preload (tools/microbench/alt/libaqlm_hip.so = PRELOAD=0 build)
 set +e
 OUT=gpurun_out/r2b
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 300 tools/microbench/mb rates > $OUT/mb_rates.log 2>&1; echo "rates rc=$?"
-grep -v "^lds" $OUT/mb_rates.log
-for o in 4096 11008; do
-timeout 900 tools/microbench/mb gemv full 1x16g8P $o > $OUT/mb_var_$o.log 2>&1; echo "mb rc=$?"
-grep -v "^# check" $OUT/mb_var_$o.log | grep -v "device\|empty-kernel\|^scheme\|waves=\|xcopies\|arrange\|repacked\|prefetch\|entry="
+timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "packed" 2>&1 | tail -3
+for rep in 1 2; do
+for alt in 0 1; do
+  if [ $alt = 1 ]; then export LD_LIBRARY_PATH=$PWD/tools/microbench/alt; else unset LD_LIBRARY_PATH; fi
+  timeout 900 tools/microbench/mb gemv quick 1x16g8P > $OUT/mb_quick_alt$alt.log 2>&1; echo "alt=$alt (1 = no preload) rc=$?"
+  grep "default" $OUT/mb_quick_alt$alt.log
+done
 done

@@ -584,6 +584,27 @@ static void bench_trace(int in, int out) {
       }
       printf("  %-22s %7.2f %7.2f %7.2f\n", names[i], mn, sum / (256 * NW), mx);
     }
+    {  // who finishes late?  "loop done" by XCD (block % 8) and by wave index
+      printf("  loop done by block %% 8:");
+      for (int x = 0; x < 8; ++x) {
+        double sum = 0, mx = 0; int cnt = 0;
+        for (int b = x; b < 256; b += 8) for (int w = 0; w < NW; ++w) { const double v = (double)(h[(b * NWMAX + w) * 8 + 4] - t0) * 0.01; sum += v; mx = std::max(mx, v); ++cnt; }
+        printf("  %.1f/%.1f", sum / cnt, mx);
+      }
+      printf("\n  loop done by wave:      ");
+      for (int w = 0; w < NW; ++w) {
+        double sum = 0;
+        for (int b = 0; b < 256; ++b) sum += (double)(h[(b * NWMAX + w) * 8 + 4] - t0) * 0.01;
+        printf(" %.1f", sum / 256);
+      }
+      printf("\n  loop done by block / 32 (mean of the workgroup's last wave):");
+      for (int q = 0; q < 8; ++q) {
+        double sum = 0;
+        for (int b = q * 32; b < q * 32 + 32; ++b) { double mx = 0; for (int w = 0; w < NW; ++w) mx = std::max(mx, (double)(h[(b * NWMAX + w) * 8 + 4] - t0) * 0.01); sum += mx; }
+        printf(" %.1f", sum / 32);
+      }
+      printf("\n");
+    }
   }
   free_layers(layers);
 }
@@ -681,6 +702,21 @@ static void bench_gemm(bool nosync) {
 
 int main(int argc, char** argv) {
   const char* what = argc > 1 ? argv[1] : "all";
+  if (const char* tune = getenv("MB_TUNE")) {  // MB_TUNE="packed_entry_bytes=3,packed_xcopies=4": library tuning knobs for the whole run
+    std::string t(tune);
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t end = t.find(',', pos);
+      if (end == std::string::npos) end = t.size();
+      const std::string kv = t.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos) {
+        const int rc = aqlm_hip_set_tuning(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1));
+        printf("# tuning %s (rc %d)\n", kv.c_str(), rc);
+      }
+      pos = end + 1;
+    }
+  }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s  CUs %d  clock %.0f MHz  L2 %d KiB\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1e3, prop.l2CacheSize >> 10);
