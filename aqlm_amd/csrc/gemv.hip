@@ -237,8 +237,41 @@ __device__ __forceinline__ void gemv_body(const GemvParams& p, const int block) 
   for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(pf[k]));
 }
 
+// Leading scalar arguments = what the prologue needs to issue its first loads: with -amdgpu-kernarg-preload-count
+// (Makefile) they arrive in SGPRs at wave launch instead of through an s_load round trip at the head of the kernel
+// (struct arguments are not preloaded: the rest, used later, stays in one).
+struct GemvRest {
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  long ys;
+  long code_row_bytes;
+  int prefetch;
+  int cb_bytes;
+};
+
 template <class T, int CODE_BYTES, int KC, int G, int U, int NB, bool CB_LDS, int NWAVES, int AUX>
-__global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const GemvParams p) {
+__global__ __launch_bounds__(NWAVES * 64) void gemv_kernel(const uint8_t* codes, const uint8_t* codebooks, const uint16_t* x, int M,
+                                                           int in_groups, int nunits, int iters, int pitch, int rpw, long xs,
+                                                           const GemvRest rest) {
+  GemvParams p;
+  p.codes = codes;
+  p.codebooks = codebooks;
+  p.scales = rest.scales;
+  p.bias = rest.bias;
+  p.x = x;
+  p.y = rest.y;
+  p.M = M;
+  p.in_groups = in_groups;
+  p.nunits = nunits;
+  p.iters = iters;
+  p.pitch = pitch;
+  p.rpw = rpw;
+  p.prefetch = rest.prefetch;
+  p.cb_bytes = rest.cb_bytes;
+  p.xs = xs;
+  p.ys = rest.ys;
+  p.code_row_bytes = rest.code_row_bytes;
   gemv_body<T, CODE_BYTES, KC, G, U, NB, CB_LDS, NWAVES, AUX>(p, blockIdx.x);
 }
 
@@ -354,7 +387,9 @@ static int launch_gemv(const GemvParams& p, hipStream_t stream) {
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   const int rows_per_block = NWAVES * p.rpw;
   const int blocks = (p.M + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVES * 64), lds, stream, p);
+  GemvRest rest{p.scales, p.bias, p.y, p.ys, p.code_row_bytes, p.prefetch, p.cb_bytes};
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVES * 64), lds, stream, p.codes, p.codebooks, p.x, p.M, p.in_groups, p.nunits,
+                     p.iters, p.pitch, p.rpw, p.xs, rest);
   return check_hip(hipGetLastError(), "gemv launch");
 }
 

@@ -123,8 +123,12 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
   }
 }
 
+// scalar arguments (13 dwords): preloaded into SGPRs at wave launch, no kernel-argument fetch at the head of the kernel
 template <class T, int G>
-__global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const LutParams p) {
+__global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const uint8_t* codes, const uint16_t* codebooks, const uint16_t* x,
+                                                            float* partial, int M, int in_groups, int nslabs, int nranges,
+                                                            int rows_per_range) {
+  const LutParams p{codes, codebooks, x, partial, M, in_groups, nslabs, nranges, rows_per_range};
   gemv_8x8_lut_body<T, G>(p, blockIdx.x);
 }
 
@@ -173,7 +177,9 @@ struct LutFinalizeParams {
 };
 
 template <class T>
-__global__ __launch_bounds__(256) void gemv_8x8_lut_finalize(const LutFinalizeParams p) {
+__global__ __launch_bounds__(256) void gemv_8x8_lut_finalize(const float* partial, const uint16_t* scales, const uint16_t* bias_ptr,
+                                                             uint16_t* y, int M, int nslabs) {
+  const LutFinalizeParams p{partial, scales, bias_ptr, y, M, nslabs};
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= p.M) return;
   float s = 0.f;
@@ -224,7 +230,8 @@ static int launch_lut(const LutParams& p, hipStream_t stream) {
   auto kern = gemv_8x8_lut_kernel<T, G>;
   const size_t lds = (size_t)LUT_ENTRIES * 4;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-  hipLaunchKernelGGL(kern, dim3(p.nslabs * p.nranges), dim3(1024), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.nslabs * p.nranges), dim3(1024), lds, stream, p.codes, p.codebooks, p.x, p.partial, p.M,
+                     p.in_groups, p.nslabs, p.nranges, p.rows_per_range);
   return check_hip(hipGetLastError(), "gemv_8x8_lut launch");
 }
 
@@ -259,9 +266,11 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
   f.M = out_features;
   f.nslabs = p.nslabs;
   if (dtype == AQLM_HIP_F16)
-    hipLaunchKernelGGL(gemv_8x8_lut_finalize<F16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(gemv_8x8_lut_finalize<F16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f.partial, f.scales, f.bias,
+                       f.y, f.M, f.nslabs);
   else
-    hipLaunchKernelGGL(gemv_8x8_lut_finalize<BF16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(gemv_8x8_lut_finalize<BF16>, dim3((out_features + 255) / 256), dim3(256), 0, stream, f.partial, f.scales, f.bias,
+                       f.y, f.M, f.nslabs);
   return check_hip(hipGetLastError(), "gemv_8x8_lut_finalize launch");
 }
 

@@ -149,8 +149,31 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
   }
 }
 
+// leading scalar arguments: preloaded into SGPRs at wave launch (see gemv.hip); the epilogue's pointers stay in a struct
+struct RepRest {
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+};
+
 template <class T, int KC, int ITERS>
-__global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const RepParams p) {
+__global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const uint8_t* codes, const uint8_t* codebooks, const uint16_t* x, int M,
+                                                            int in_groups, int nunits, int iters, int pitch, int rows_per_block,
+                                                            long code_row_bytes, const RepRest rest) {
+  RepParams p;
+  p.codes = codes;
+  p.codebooks = codebooks;
+  p.scales = rest.scales;
+  p.bias = rest.bias;
+  p.x = x;
+  p.y = rest.y;
+  p.M = M;
+  p.in_groups = in_groups;
+  p.nunits = nunits;
+  p.iters = iters;
+  p.pitch = pitch;
+  p.rows_per_block = rows_per_block;
+  p.code_row_bytes = code_row_bytes;
   gemv_kx8_rep_body<T, KC, ITERS>(p, blockIdx.x);
 }
 
@@ -214,7 +237,9 @@ static int launch_rep_i(const RepParams& p, int blocks, hipStream_t stream) {
   auto kern = gemv_kx8_rep_kernel<T, KC, ITERS>;
   const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p);
+  RepRest rest{p.scales, p.bias, p.y};
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p.codes, p.codebooks, p.x, p.M, p.in_groups, p.nunits, p.iters,
+                     p.pitch, p.rows_per_block, p.code_row_bytes, rest);
   return check_hip(hipGetLastError(), "gemv_kx8_rep launch");
 }
 
