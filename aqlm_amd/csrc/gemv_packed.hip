@@ -19,18 +19,26 @@
 //   the codebook vector (one v_and_b32_sdwa each).  The spare nibbles carry the bookkeeping: bit 0 of a lane-step's
 //   first entry = "a row ends with this lane-step"; the first lane-step of every column carries the column's starting
 //   slot (15 bits over the remaining spare bits of entries 0 and 1).  null entry: j = in_groups (a zero vector in LDS).
-//   winfo[st][w] = {first row that STARTS in wave w, wave starts inside a row, steps with content, 0}.
-//   4 bytes per code + 6 bytes of padding per (row, slice) on average + < 1 step per wave of tail: ~2.1x the canonical
-//   code bytes for 4096-wide layers.
+//   winfo[st][w] = {first row that STARTS in wave w, wave starts inside a row, steps with content, start row of lane 0}
+//   (read by the 3-byte-entry kernel and the unpacker; the 4-byte kernel runs all T steps of every wave range -- the
+//   tail is null entries -- and finds the start rows in the entries).  rowstart[st][RG + 1] = first lane-step of every
+//   row of the stream (epilogue).  Optional 3-byte entries (entry_bytes = 3, T <= 32): a wave range = T 8-byte row-end
+//   flag words, then T steps of 64 x 12 B holding 4 x (slot:12 | code:12); 3.5 instead of 4.5 B per code, same speed.
+//   4 bytes per code + 6 bytes of padding per (row, slice) on average + < 1 step per wave of tail: 4.5 B per code for
+//   4096-wide layers, 4.2 for 8192-wide ones (canonical: 2 B per code).
 //
 // Kernel: grid = 256 workgroups = 16 groups x 16 slices (slice = block % 16 -> the two slices block % 8 and
-// block % 8 + 8 live in one XCD's L2).  Slice and x go to LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no
-// ds_write pass); the entry stream runs PD steps ahead in a register ring from fixed addresses, so it is in flight
-// before the LDS fill completes.  A lane accumulates its column in fp32; at a row end it adds the sum to the row's LDS
-// slot (ds_add_f32; a row spans 1-3 neighbouring columns of one wave; the part of a row that continues in the next
-// wave goes to that wave's carry slot and is added in wave order afterwards -> the summation order is fixed).  fp32
-// partials [slice][batch][row] -> workspace -> finalize kernel (adds the 16 slices, scale + bias, one rounding).
-// Per entry: 2 v_and_sdwa + 2 ds_read_b128 + 4 v_dot2c (x B for B input rows: one codebook read, B x reads).
+// block % 8 + 8 live in one XCD's L2).  Slice, x and the stream's row-start table go to LDS by LDS-DMA
+// (global_load_lds: no VGPR staging, no ds_write pass); the entry stream runs PD steps ahead in a register ring from
+// fixed addresses, so it is in flight before the LDS fill completes.  A lane accumulates its column in fp32; at the
+// lane-step that ends a row it STORES the sum to rowval[row] (exactly one lane-step per row does: unique writer, no
+// atomics), at the end of its column it stores what it gathered after its last row end to colend[column].  Epilogue:
+// row r = rowval[r] + the colend of the columns the row crosses before its last one, in column order (from the
+// row-start table) -> the summation order is fixed.  fp32 partials [slice][batch][row] -> workspace -> finalize kernel
+// (adds the 16 slices, scale + bias, one rounding).  Per entry: 2 v_and_sdwa + 2 ds_read_b128 + 4 v_dot2c (x B for B
+// input rows: one codebook read, B x reads).  The kernels take their leading parameters as scalar arguments: the
+// command processor preloads them into SGPRs (-amdgpu-kernarg-preload-count), so no kernel-argument fetch precedes the
+// first load.
 #include <algorithm>
 
 #include "aqlm_common.h"
