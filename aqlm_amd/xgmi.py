@@ -38,7 +38,14 @@ def _exchange(state: torch.Tensor, group) -> List[torch.Tensor]:
     if world == 1:
         return [state]
     handles: List[Optional[bytes]] = [None] * world
-    dist.all_gather_object(handles, bytes(ForkingPickler.dumps(state)), group=group)
+    try:  # a rank that cannot export its state still takes part in the collective (the others must not wait for it)
+        mine: Optional[bytes] = bytes(ForkingPickler.dumps(state))
+    except Exception:  # noqa: BLE001
+        mine = None
+    dist.all_gather_object(handles, mine, group=group)
+    missing = [r for r, h in enumerate(handles) if h is None]
+    if missing:
+        raise RuntimeError(f"one-shot all-reduce: ranks {missing} could not export their state over IPC")
     return [state if r == rank else pickle.loads(h) for r, h in enumerate(handles)]
 
 
