@@ -244,11 +244,37 @@ def cpu_baseline(sample_seconds=24.0):
             st, n = _time_calls(lambda: lk(x), budget, 1000, 10 if nbits == 8 else 1)
             protocol[f"{name}_{label}"] = {"ms_mean": st["mean"] * 1e3, "ms_median": st["median"] * 1e3,
                                            "GBps_algorithmic": b / st["mean"] * 1e-9, "iters": n}
+    # the product's own CPU kernels (libaqlm_cpu.so, what `QuantizedLinear` runs for CPU tensors: SURVEY.md 8(f) item 4),
+    # same layers and protocol, fp32 torch tensors through aqlm_amd.inference_kernels.cpu_kernel
+    native = {}
+    try:
+        from aqlm_amd.inference_kernels import cpu_kernel as ck
+
+        for name, (K, nbits) in (("2x8g8", (2, 8)), ("1x16g8", (1, 16))):
+            L = orc.make_layer(1, 4096, 4096, K, nbits, 8, batch=1, bias=False, float_dtype=np.float32, edge_codes=False)
+            xt = torch.from_numpy(np.ascontiguousarray(L["x"][:1]))
+            cbt = torch.from_numpy(np.ascontiguousarray(L["codebooks"]))
+            sct = torch.from_numpy(np.ascontiguousarray(L["scales"]))
+            signed = orc.pack_int_data(L["codes"], nbits)
+            codes_t = torch.from_numpy(np.ascontiguousarray(signed))
+            b = algorithmic_bytes(4096, 4096, K, nbits, 8)
+            for label, nt in (("1_thread", 1), (f"{threads}_threads", 0)):
+                if nbits == 8:
+                    alt = ck.permute_codes_for_lut(codes_t)
+                    fn = lambda: ck.cpu_gemm_lut(xt, alt, cbt, sct, None, nthreads=nt)  # noqa: E731
+                else:
+                    fn = lambda: ck.cpu_gemv_1xn(xt, codes_t, cbt, sct, None, nthreads=nt)  # noqa: E731
+                st, n = _time_calls(fn, budget / 2, 1000, 10)
+                native[f"{name}_{label}"] = {"ms_mean": st["mean"] * 1e3, "ms_median": st["median"] * 1e3,
+                                             "GBps_algorithmic_median": b / st["median"] * 1e-9, "iters": n}
+    except Exception as e:  # noqa: BLE001 - a reported extra, never fatal for the GPU benchmark
+        native = {"error": f"{type(e).__name__}: {e}"}
     return {
         "value": total_bytes / total_time * 1e-9,
         "unit": "GB/s",
         "cores": threads,
         "kind": "port",
+        "native_cpu_path": native,
         "sample": f"oracle C dequant-gemv (what the reference runs on CPU for 1x16), fp32, one 4096->4096 + one 4096->11008 "
                   f"layer, <= 1000 calls or {budget:.0f} s each on {threads} OpenMP threads; `protocol`: the reference "
                   f"benchmark's LUT gemv (matmul_benchmark_cpu.py) restated in C, 4096x4096, 10 warm-up + <= 1000 calls",
