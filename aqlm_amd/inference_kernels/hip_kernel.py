@@ -14,6 +14,7 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from types import SimpleNamespace
@@ -46,6 +47,15 @@ def _stream_ptr(device=None) -> int:
     """The current stream of ``device`` (default: the current device).  Always pass the tensor's device when the call
     is not inside ``torch.cuda.device(...)``: with accelerate's device_map the current device is not the layer's."""
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_NO_GUARD = contextlib.nullcontext()
+
+
+def _device_guard(device: torch.device):
+    """``torch.cuda.device(device)`` only when the tensor is not on the current device: an eager decode loop is host-bound
+    and entering / leaving the guard costs as much as a kernel launch."""
+    return _NO_GUARD if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -84,7 +94,7 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
     B = x.shape[0]
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
     stream = _stream_ptr(input.device)
-    with torch.cuda.device(input.device):
+    with _device_guard(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
             xp = x.data_ptr() + b0 * x.stride(0) * 2
@@ -179,10 +189,10 @@ def unpack_1x16(packed: PackedCodes) -> torch.Tensor:
 _WORKSPACES = {}
 
 
-def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+def _workspace(device: torch.device, nbytes: int, stream: Optional[int] = None) -> torch.Tensor:
     if torch.cuda.is_current_stream_capturing():
         return torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((max(nbytes, 1 << 20) // 4,), dtype=torch.float32, device=device)
@@ -214,9 +224,9 @@ def code1x16_matmat_packed(input, packed: PackedCodes, codebooks, scales, bias=N
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
     nb_max = min(B, _native.MAX_GEMV_BATCH)
     ws_bytes = 16 * nb_max * out_features * 4
-    ws = _workspace(input.device, ws_bytes)
     stream = _stream_ptr(input.device)
-    with torch.cuda.device(input.device):
+    ws = _workspace(input.device, ws_bytes, stream)
+    with _device_guard(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
             rc = _lib.aqlm_hip_gemv_1x16_packed(ctypes.byref(packed.desc), packed.data_ptr(), codebooks.data_ptr(),
@@ -372,10 +382,85 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
     return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
 
 
+# Transparent prepack for the RAW op.  `aqlm::code1x16_matmat` is stateless in the reference (cuda_kernel.cpp:148-182); here
+# the fast kernel needs the slice-bucketed layout of the codes (3-5x faster on layers of >= 1 M codes).  `QuantizedLinear`
+# keeps that derived buffer itself; callers of the raw op -- the reference's own benchmark/matmul_benchmark.py:103, vLLM-style
+# integrations -- get it from this cache: keyed by the identity of the `codes` tensor object (a weak reference drops the
+# entry when the tensor dies, so an address reused by a new tensor can never alias it), validated on every hit against
+# (data_ptr, _version, shape), bounded in bytes.  A caller that passes a fresh view object on every call never hits: after
+# RAW_OP_PREPACK_MAX_MISSES packs without a single hit the cache switches itself off.  Nothing is packed while a hipGraph is
+# being captured (the pack synchronises); outputs equal the direct kernel's up to fp32 summation order.
+RAW_OP_PREPACK = True                 # set False to keep the raw op on the direct kernel
+RAW_OP_PREPACK_MIN_CODES = 1_000_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
+RAW_OP_PREPACK_MAX_BYTES = 16 << 30
+RAW_OP_PREPACK_MAX_MISSES = 8
+_RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None)
+_RAW_STATS = {"bytes": 0, "packs_without_hit": 0, "hits": 0, "packs": 0}
+
+
+def _raw_fingerprint(codes):
+    return (codes.data_ptr(), codes._version, tuple(codes.shape), tuple(codes.stride()), codes.dtype, codes.device)
+
+
+def _raw_drop(key):
+    entry = _RAW_PACKED.pop(key, None)
+    if entry is not None and entry[2] is not None:
+        _RAW_STATS["bytes"] -= entry[2].numel()
+
+
+def clear_raw_op_prepack_cache():
+    """Forget every buffer the raw op packed on its own (frees the device memory they hold)."""
+    for key in list(_RAW_PACKED):
+        _raw_drop(key)
+    _RAW_STATS["packs_without_hit"] = 0
+
+
+def _raw_packed_for(codes, codebooks, input):
+    """The cached packed form of `codes`, packing it at first sight; None = use the direct kernel."""
+    if not RAW_OP_PREPACK or not codes.is_cuda or codes.dtype != torch.int16 or codes.dim() != 3 or codes.shape[2] != 1:
+        return None
+    if codebooks.shape[3] != 8 or codes.shape[0] * codes.shape[1] < RAW_OP_PREPACK_MIN_CODES:
+        return None
+    if input.dtype != codebooks.dtype or input.numel() // input.shape[-1] > _native.MAX_GEMV_BATCH:
+        return None
+    key = id(codes)
+    entry = _RAW_PACKED.get(key)
+    fp = _raw_fingerprint(codes)
+    if entry is not None:
+        if entry[0]() is codes and entry[1] == fp:
+            if entry[2] is not None:
+                _RAW_STATS["hits"] += 1
+                _RAW_STATS["packs_without_hit"] = 0
+            return entry[2]
+        _raw_drop(key)  # the tensor was modified in place / rebound: pack again
+    if (_RAW_STATS["packs_without_hit"] >= RAW_OP_PREPACK_MAX_MISSES or torch.cuda.is_current_stream_capturing()
+            or torch.compiler.is_compiling()):
+        return None
+    import weakref
+
+    packed = None
+    cap = _lib.aqlm_hip_prepack_1x16_bytes(codes.shape[0], codes.shape[1] * 8, 8)
+    if cap and _RAW_STATS["bytes"] + cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
+        packed = prepack_1x16(codes, 8)
+    try:
+        ref = weakref.ref(codes, lambda _r, k=key: _raw_drop(k))
+    except TypeError:
+        return None
+    _RAW_PACKED[key] = (ref, fp, packed)  # (None is cached too: a layer the packed path does not cover is not retried)
+    if packed is not None:
+        _RAW_STATS["bytes"] += packed.numel()
+        _RAW_STATS["packs"] += 1
+        _RAW_STATS["packs_without_hit"] += 1
+    return packed
+
+
 def code1x16_matmat(input, codes, codebooks, scales, bias=None):
     """aqlm::code1x16_matmat (cuda_kernel.py:13-22, cuda_kernel.cpp:148-182)."""
     if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536:
         raise NotImplementedError(f"code1x16_matmat needs codebooks [1, 65536, 1, g], got {tuple(codebooks.shape)}")
+    packed = _raw_packed_for(codes, codebooks, input)
+    if packed is not None and scales.dtype == input.dtype and input.device == codes.device:
+        return code1x16_matmat_packed(input, packed, codebooks, scales, bias)
     return _gemv(input, codes, codebooks, scales, bias, "1x16")
 
 

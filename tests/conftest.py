@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "raw_prepack: leave the raw 1x16 op's transparent prepack cache switched on")
 
 
 @pytest.fixture(scope="session")

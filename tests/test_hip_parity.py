@@ -28,6 +28,23 @@ def hk():
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _raw_op_on_the_direct_kernel(request):
+    """`hk.code1x16_matmat` packs large layers on its own (transparent prepack cache).  The tests of this file name the
+    kernel they exercise: the raw op means the DIRECT kernel here, except in the tests marked `raw_prepack`."""
+    if not torch.cuda.is_available():
+        yield
+        return
+    from aqlm_amd.inference_kernels import hip_kernel
+
+    old = hip_kernel.RAW_OP_PREPACK
+    hip_kernel.RAW_OP_PREPACK = request.node.get_closest_marker("raw_prepack") is not None
+    hip_kernel.clear_raw_op_prepack_cache()
+    yield
+    hip_kernel.RAW_OP_PREPACK = old
+    hip_kernel.clear_raw_op_prepack_cache()
+
+
 def tdtype(name):
     return {"float16": torch.float16, "bfloat16": torch.bfloat16}[name]
 
@@ -471,6 +488,73 @@ def test_gemv_1x16_packed(hk, fin, fout, dt, bias, entry_bytes):
 # C restatement of the reference's dequantize_gemm.
 HEADLINE = [(4096, 4096), (4096, 11008), (4096, 14336), (14336, 4096), (4096, 1024), (8192, 28672), (1024, 28672),
             (2048, 28672), (11008, 4096)]
+
+
+@pytest.mark.raw_prepack
+def test_raw_op_packs_large_layers_transparently(hk, monkeypatch):
+    """aqlm::code1x16_matmat with canonical codes (the reference's stateless signature, what its benchmark script calls):
+    large layers run on the prepacked kernel through a cache keyed by the codes tensor; in-place edits and dead tensors
+    invalidate it; nothing is packed during hipGraph capture; fresh view objects on every call switch it off."""
+    import gc
+
+    fin, fout = 4096, 4096
+    L = orc.make_layer(31337, fin, fout, 1, 16, 8, batch=2, bias=True)
+    T = to_dev(L, torch.float16)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    stats = hk._RAW_STATS
+    p0, h0 = stats["packs"], stats["hits"]
+    y_a = torch.ops.aqlm.code1x16_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert stats["packs"] == p0 + 1 and stats["bytes"] > 2 * T["codes"].numel()
+    y_b = hk.code1x16_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert stats["packs"] == p0 + 1 and stats["hits"] == h0 + 1
+    assert torch.equal(y_a, y_b)
+    check_close(y_a.float().cpu().numpy(), y64, torch.float16, "raw op, packed through the cache")
+    y_direct = hk._gemv(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "1x16")
+    check_close(y_a.float().cpu().numpy(), y_direct.float().cpu().numpy().astype(np.float64), torch.float16, "cache vs direct")
+    # more rows than one launch takes, a bf16 input on an fp16 layer: the direct path's behaviour, unchanged
+    x9 = T["x"][:1].expand(9, fin).contiguous()
+    assert torch.equal(hk.code1x16_matmat(x9, T["codes"], T["codebooks"], T["scales"], T["bias"])[0], y_direct[0])
+    with pytest.raises(NotImplementedError):
+        hk.code1x16_matmat(T["x"].bfloat16(), T["codes"], T["codebooks"], T["scales"], T["bias"])
+    # in-place edit of the codes: the cached buffer is stale and must not be used
+    L2 = orc.make_layer(31338, fin, fout, 1, 16, 8, batch=2, bias=True)
+    T["codes"].copy_(torch.from_numpy(L2["codes"]).to(DEV))
+    y_c = hk.code1x16_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert stats["packs"] == p0 + 2
+    y64c = orc.dequantize_gemm(L["x"], L2["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y_c.float().cpu().numpy(), y64c, torch.float16, "raw op after an in-place edit of the codes")
+    # a dead tensor leaves nothing behind
+    key = id(T["codes"])
+    assert key in hk._RAW_PACKED
+    held = stats["bytes"]
+    del T["codes"]
+    gc.collect()
+    assert key not in hk._RAW_PACKED and stats["bytes"] < held
+    # small layers and hipGraph capture: direct kernel, nothing packed
+    Ls = orc.make_layer(5, 512, 256, 1, 16, 8, batch=1, bias=False)
+    Ts = to_dev(Ls, torch.float16)
+    p1 = stats["packs"]
+    hk.code1x16_matmat(Ts["x"], Ts["codes"], Ts["codebooks"], Ts["scales"], None)
+    T3 = to_dev(orc.make_layer(31339, fin, fout, 1, 16, 8, batch=1, bias=False), torch.float16)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hk._gemv(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], None, "1x16")  # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        yg = hk.code1x16_matmat(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], None)
+    g.replay()
+    torch.cuda.synchronize()
+    assert stats["packs"] == p1
+    assert torch.equal(yg, hk._gemv(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], None, "1x16"))
+    # a caller that hands over a new view object every time never hits: the cache gives up instead of packing per call
+    monkeypatch.setattr(hk, "RAW_OP_PREPACK_MAX_MISSES", 3)
+    hk.clear_raw_op_prepack_cache()
+    p2 = stats["packs"]
+    for _ in range(6):
+        hk.code1x16_matmat(T3["x"], T3["codes"].view(fout, fin // 8, 1), T3["codebooks"], T3["scales"], None)
+        gc.collect()
+    assert stats["packs"] == p2 + 3
 
 
 @pytest.mark.parametrize("fin,fout", HEADLINE)
