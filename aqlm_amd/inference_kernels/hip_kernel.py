@@ -272,7 +272,7 @@ def _gemv_multi(input, codes, codebooks, scales, bias, kind):
         segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = c.data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), out_features, out_features
     stream = _stream_ptr(input.device)
-    with torch.cuda.device(input.device):
+    with _device_guard(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
             for k in range(n):
@@ -324,7 +324,7 @@ def _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias):
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), out_features, out_features
         ws_bytes += _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
     ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
+    with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemv_8x8_lut_multi(segs, n, x.data_ptr(), in_features, g, dt, ws.data_ptr(), ws_bytes,
                                               _stream_ptr(input.device))
     if rc:
@@ -374,9 +374,13 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
         segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = packed[k].data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), of, of
         descs[k] = ctypes.pointer(packed[k].desc)
-    with torch.cuda.device(input.device):
+    with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, descs, n, x.data_ptr(), packed[0].in_features, B, x.stride(0), dt,
                                                   ws.data_ptr(), ws.numel() * 4, _stream_ptr(input.device))
+    if rc == _native.E_UNSUPPORTED and B > 1:
+        # the rows do not fit one LDS image next to the codebook slice (very wide inputs): per-layer launches split the
+        # rows themselves; same kernels, same bits
+        return [code1x16_matmat_packed(input, packed[k], codebooks[k], scales[k], bias[k]) for k in range(n)]
     if rc:
         _native.check(rc, "aqlm gemv_1x16_packed_multi")
     return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
@@ -495,7 +499,7 @@ def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
     y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
     ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
     ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
+    with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemv_8x8_lut(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
                                         x.data_ptr(), y.data_ptr(), out_features, in_features, g, dt, ws.data_ptr(),
                                         ws_bytes, _stream_ptr(input.device))
@@ -610,7 +614,7 @@ def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
     ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMM_1X16_MFMA, B, out_features, in_features)
     ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
+    with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemm_1x16_mfma(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
                                           x.data_ptr(), y.data_ptr(), B, out_features, in_features, in_group_size,
                                           x.stride(0), out_features, dt, ws.data_ptr(), ws.numel() * 4, _stream_ptr(input.device))

@@ -596,6 +596,26 @@ def main():
             "launches": gf.n, "matvecs": gp.n, "ms_per_token": msf, "tokens_per_s": 1e3 / msf,
             "algorithmic_GBps": gf.bytes / msf * 1e-6, "speedup_vs_one_launch_per_layer": ms / msf}
         del gp, gf, fused, tok
+        # Llama-3-70B on ONE MI355X (2-bit codes: 17.5 GB canonical, 39 GB prepacked): 80 x [q,o 8192->8192; k,v 8192->1024;
+        # gate,up 8192->28672; down 28672->8192].  8 distinct blocks (5 GB of packed codes, far beyond every cache) replayed
+        # 10 times inside one graph = the 80 blocks of a token.
+        shapes70 = [(8192, 8192), (8192, 1024), (8192, 1024), (8192, 8192), (8192, 28672), (8192, 28672), (28672, 8192)]
+        blk = [[Layer(fi, fo, 1, 16, 8, 7500 + rank * 10000 + 7 * b + j, dev) for j, (fi, fo) in enumerate(shapes70)] for b in range(8)]
+        tok70 = [l for _ in range(10) for b in blk for l in b]
+        gp = GraphedPass(tok70, lib)
+        ms = gp.time_replays(max(2, reps // 2))
+        fused70 = []
+        for _ in range(10):
+            for q, k, v, o, gate, up, down in blk:
+                fused70 += [FusedLayers([q, k, v]), o, FusedLayers([gate, up]), down]
+        gf = GraphedPass(fused70, lib)
+        msf = gf.time_replays(max(2, reps // 2))
+        detail["llama3_70b_1x16g8_linear_stack_one_gpu"] = {
+            "launches": gp.n, "ms_per_token": ms, "tokens_per_s": 1e3 / ms, "algorithmic_GBps": gp.bytes / ms * 1e-6,
+            "frac_of_8TBps": gp.bytes / ms * 1e-6 / HBM_PEAK_GBPS,
+            "shared_input_launches": {"launches": gf.n, "ms_per_token": msf, "tokens_per_s": 1e3 / msf},
+            "note": "8 distinct decoder blocks x 10 replays per token; every layer on the prepacked kernel"}
+        del gp, gf, fused70, tok70, blk
         # q/k/v of a Llama-2-7B block (3 x 4096->4096): separate launches vs one launch, direct and prepacked
         keep_min, PACK_MIN_OUT = PACK_MIN_OUT, 0   # start from canonical codes only: the direct kernel
         qkv = [Layer(4096, 4096, 1, 16, 8, 8000 + rank * 10000 + i, dev) for i in range(3 * 40)]

@@ -487,7 +487,7 @@ def test_gemv_1x16_packed(hk, fin, fout, dt, bias, entry_bytes):
 # The shipped kernel at the shapes the bench and the 70B configuration run (BASELINE.json configs 2 and 5), against the
 # C restatement of the reference's dequantize_gemm.
 HEADLINE = [(4096, 4096), (4096, 11008), (4096, 14336), (14336, 4096), (4096, 1024), (8192, 28672), (1024, 28672),
-            (2048, 28672), (11008, 4096)]
+            (2048, 28672), (11008, 4096), (8192, 8192), (28672, 8192), (5120, 13824)]
 
 
 @pytest.mark.raw_prepack

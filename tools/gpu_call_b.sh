@@ -1,16 +1,14 @@
 #!/bin/bash
-# A/B: default library vs tools/microbench/alt/libaqlm_hip.so (an alternative build)
 set +e
 OUT=gpurun_out/r2b
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "packed or prepack or sharded or fus" > $OUT/pytest.log 2>&1; grep -E "passed|failed|error" $OUT/pytest.log | tail -3
-for rep in 1 2; do
-for alt in 0 1; do
-  if [ $alt = 1 ]; then export LD_LIBRARY_PATH=$PWD/tools/microbench/alt; else unset LD_LIBRARY_PATH; fi
-  for o in 4096 11008; do
-  timeout 900 tools/microbench/mb gemv full 1x16g8P $o > $OUT/mb_var_${o}_alt$alt.log 2>&1; echo "alt=$alt rc=$?"
-  grep " default" $OUT/mb_var_${o}_alt$alt.log
-  done
-done
-done
+timeout 900 tools/microbench/mb gemv quick 1x16g8P 8192 > $OUT/mb_70b_a.log 2>&1; grep "default\|^# packed" $OUT/mb_70b_a.log
+timeout 900 tools/microbench/mb gemv quick 1x16g8P 1024 > $OUT/mb_70b_b.log 2>&1; grep "default\|^# packed" $OUT/mb_70b_b.log
+timeout 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "headline" 2>&1 | tail -2
+timeout 900 python bench.py --no-cpu > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r2b/bench.json'))
+print(d['value'], d['detail']['llama3_70b_1x16g8_linear_stack_one_gpu'])
+PY

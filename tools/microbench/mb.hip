@@ -451,7 +451,7 @@ static void bench_gemv(int argc, char** argv) {
   const Scheme S8x8L{"8x8g32LUT", 8, 8, 32, false, false, true};
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
-  std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672}, {S1x16P, 1024, 28672}, {S1x16P, 2048, 28672},
+  std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672}, {S1x16P, 1024, 28672}, {S1x16P, 2048, 28672}, {S1x16P, 8192, 8192}, {S1x16P, 28672, 8192}, {S1x16P, 8192, 1024},
                              {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
                              {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
                              {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}, {S8x8L, 4096, 4096}, {S8x8L, 4096, 11008}, {S8x8L, 11008, 4096}};
