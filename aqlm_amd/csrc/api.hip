@@ -56,6 +56,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "gemm_splitk_free")) return &t.gemm_splitk_free;
   if (!strcmp(key, "force_generic")) return &t.force_generic;
   if (!strcmp(key, "packed_waves")) return &t.packed_waves;
+  if (!strcmp(key, "packed_fused_finalize")) return &t.packed_fused_finalize;
   if (!strcmp(key, "packed_prefetch")) return &t.packed_prefetch;
   if (!strcmp(key, "packed_arrange")) return &t.packed_arrange;
   if (!strcmp(key, "packed_xcopies")) return &t.packed_xcopies;

@@ -135,6 +135,7 @@ struct Tuning {
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
   int gemm_splitk_free = 0;      // 1: large-batch 1x16 op uses the split-K-free 16x16x32 kernel when in % 256 == 0
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
+  int packed_fused_finalize = 0;  // experiment: 1 = finalize inside the main kernel (one returning atomic per row)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
   int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel), 0 = ascending j
   int packed_xcopies = 0;        // prepack: rotated copies of x the batch-1 kernel keeps in LDS (1..4, capped by what fits); 0 = 1

@@ -505,6 +505,12 @@ struct PackedGemvParams {
   long x_row_stride;
   int M, in_groups, RG, NW, T, XC;
   uint32_t ent_bytes;
+  // fused finalize (acc != nullptr): the 16 slice workgroups of a row meet in ONE 64-bit cell per (input row, output row)
+  unsigned long long* acc;  // [B][M], zero at rest
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  long y_row_stride;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
   int dbg;                    // bit 0: skip the LDS reads + dot products, bit 1: no entry stream (out-of-range loads)
@@ -814,11 +820,43 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     for (int r = tid; r < nrows; r += NT) {
       const uint32_t q0 = rs[r], q1 = rs[r + 1];
       const uint32_t c0 = q0 / T, c1 = (q1 - 1u) / T;  // first / last column the row touches (column = wave * 64 + lane)
+      float v[B];
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        float v = rowval[b * RG1 + r];
-        for (uint32_t c = c0; c < c1; ++c) v += colend[(size_t)b * PK_MAX_NW * 64 + c];
-        p.partial[((size_t)slice * B + b) * p.M + row_begin + r] = v;
+        v[b] = rowval[b * RG1 + r];
+        for (uint32_t c = c0; c < c1; ++c) v[b] += colend[(size_t)b * PK_MAX_NW * 64 + c];
+      }
+      if (p.acc == nullptr) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) p.partial[((size_t)slice * B + b) * p.M + row_begin + r] = v[b];
+      } else {
+        // Fused finalize.  The slice sum goes into the row's cell as a fixed-point number, 2^-30 units in bits 63..10
+        // (integer adds commute: the result does not depend on the order the 16 workgroups arrive in), together with
+        // +1 in the arrival counter (bits 4..0) and +1 in bits 9..5 if the value does not fit (|v| >= 2^22, Inf, NaN).
+        // ONE returning atomic per cell is the whole hand-shake: whoever reads 15 earlier arrivals owns the total,
+        // applies scale and bias, rounds once, writes y and puts the cell back to zero for the next launch.
+        const int row = row_begin + r;
+        unsigned long long old[B], mine[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const bool fits = fabsf(v[b]) < 4194304.f;  // false for NaN
+          const long long q = fits ? __float2ll_rn(v[b] * 1073741824.f) : 0ll;
+          mine[b] = ((unsigned long long)q << 10) + (fits ? 1ull : 33ull);
+          old[b] = __hip_atomic_fetch_add(p.acc + (size_t)b * p.M + row, mine[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float scale = T_::to_float(p.scales[row]);
+        const float bias = p.bias ? T_::to_float(p.bias[row]) : 0.f;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          if ((old[b] & 31ull) == (unsigned long long)(PK_S - 1)) {
+            const unsigned long long cell = old[b] + mine[b];
+            const long long sum = (long long)cell >> 10;
+            float sv = (float)((double)sum * 0x1p-30);
+            if ((cell >> 5) & 31ull) sv = __builtin_nanf("");
+            p.y[(size_t)b * p.y_row_stride + row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
+            __hip_atomic_store(p.acc + (size_t)b * p.M + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
   }
@@ -839,6 +877,11 @@ struct PackedGemvRest {
   const uint32_t* winfo;
   float* partial;
   long x_row_stride;
+  unsigned long long* acc;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  long y_row_stride;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;
   int dbg;
@@ -857,6 +900,11 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* c
   p.codebook = codebook;
   p.x = x;
   p.partial = rest.partial;
+  p.acc = rest.acc;
+  p.scales = rest.scales;
+  p.bias = rest.bias;
+  p.y = rest.y;
+  p.y_row_stride = rest.y_row_stride;
   p.x_row_stride = rest.x_row_stride;
   p.M = M;
   p.in_groups = in_groups;
@@ -1180,10 +1228,17 @@ extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void
 }
 
 // main kernel of one launch (<= packed_max_batch rows): fp32 slice partials [16][nb][M] -> workspace
+struct PackedFused {  // fused finalize: where y goes (nullptr members = the two-kernel form with fp32 partials)
+  const void* scales = nullptr;
+  const void* bias = nullptr;
+  void* y = nullptr;
+  long y_row_stride = 0;
+};
+
 static int packed_launch_main(const PackedLayout& L, const void* packed, const void* codebook, const uint16_t* x, int nb,
                               long x_row_stride, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                              const char* who) {
-  const size_t need = (size_t)PK_S * nb * L.M * sizeof(float);
+                              const char* who, const PackedFused& fused = PackedFused{}) {
+  const size_t need = fused.y ? (size_t)nb * L.M * 8 : (size_t)PK_S * nb * L.M * sizeof(float);
   if (!workspace || workspace_bytes < need) {
     set_last_error("%s: workspace of %zu bytes required, got %zu", who, need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
@@ -1196,6 +1251,13 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.codebook = (const uint8_t*)codebook;
   p.x = x;
   p.partial = (float*)workspace;
+  if (fused.y) {
+    p.acc = (unsigned long long*)workspace;
+    p.scales = (const uint16_t*)fused.scales;
+    p.bias = (const uint16_t*)fused.bias;
+    p.y = (uint16_t*)fused.y;
+    p.y_row_stride = fused.y_row_stride;
+  }
   p.x_row_stride = x_row_stride;
   p.M = L.M;
   p.in_groups = L.in_groups;
@@ -1215,6 +1277,11 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
     rest.winfo = p.winfo;
     rest.partial = p.partial;
     rest.x_row_stride = p.x_row_stride;
+    rest.acc = p.acc;
+    rest.scales = p.scales;
+    rest.bias = p.bias;
+    rest.y = p.y;
+    rest.y_row_stride = p.y_row_stride;
 #ifdef AQLM_PACKED_TRACE
     rest.trace = p.trace;
     rest.dbg = p.dbg;
@@ -1268,6 +1335,17 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
   if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b)) return e;
   for (int b0 = 0; b0 < batch; b0 += max_b) {  // rows that do not fit one LDS image go in several launches
     const int nb = std::min(max_b, batch - b0);
+    if (tuning().packed_fused_finalize) {  // experiment: the workspace holds the zero-at-rest accumulator cells
+      PackedFused fz;
+      fz.scales = scales;
+      fz.bias = bias;
+      fz.y = (uint16_t*)y + (size_t)b0 * y_row_stride;
+      fz.y_row_stride = y_row_stride;
+      if (int e = packed_launch_main(L, packed, codebook, (const uint16_t*)x + (size_t)b0 * x_row_stride, nb, x_row_stride, dtype,
+                                     workspace, workspace_bytes, stream, "aqlm_hip_gemv_1x16_packed", fz))
+        return e;
+      continue;
+    }
     if (int e = packed_launch_main(L, packed, codebook, (const uint16_t*)x + (size_t)b0 * x_row_stride, nb, x_row_stride, dtype,
                                    workspace, workspace_bytes, stream, "aqlm_hip_gemv_1x16_packed"))
       return e;

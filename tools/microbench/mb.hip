@@ -484,6 +484,8 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
     } else if (c.s.packed && !quick) {
+      variants.push_back({{"fused finalize", "packed_fused_finalize", 1}});
+      variants.push_back({{"fused finalize (again)", "packed_fused_finalize", 1}});
       variants.push_back({{"waves=4", "packed_waves", 4}});
       variants.push_back({{"waves=8", "packed_waves", 8}});
       variants.push_back({{"waves=16", "packed_waves", 16}});
@@ -524,6 +526,7 @@ static void bench_gemv(int argc, char** argv) {
         }
       }
       for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
+      if (c.s.packed && !var.empty() && !strcmp(var[0].key, "packed_fused_finalize")) check_packed(c.s, layers[0], c.in, c.out);
       if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange") || !strcmp(var[0].key, "packed_entry_bytes") || !strcmp(var[0].key, "packed_xcopies"))) {  // a format parameter: repack
         const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
         for (auto& L : layers)
