@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaqlm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
@@ -41,16 +41,22 @@ class PackedDesc(ctypes.Structure):
     _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint32), ("out_features", ctypes.c_int32),
                 ("in_features", ctypes.c_int32), ("slices_log2", ctypes.c_int32), ("waves", ctypes.c_int32),
                 ("steps", ctypes.c_int32), ("entry_bytes", ctypes.c_int32), ("used_bytes", ctypes.c_uint64),
-                ("x_copies", ctypes.c_uint64)]
+                ("x_copies", ctypes.c_uint32), ("codebook_absmax", ctypes.c_float)]
 
     def as_ints(self):
+        """The descriptor as a list of ints (what the registered torch op takes); the float travels as its bit pattern."""
+        import struct
+
         return [int(self.magic), int(self.version), int(self.out_features), int(self.in_features),
                 int(self.slices_log2), int(self.waves), int(self.steps), int(self.entry_bytes), int(self.used_bytes),
-                int(self.x_copies)]
+                int(self.x_copies), struct.unpack("<I", struct.pack("<f", float(self.codebook_absmax)))[0]]
 
     @classmethod
     def from_ints(cls, v):
-        return cls(*[int(x) for x in v[:10]])
+        import struct
+
+        absmax = struct.unpack("<f", struct.pack("<I", int(v[10]) & 0xFFFFFFFF))[0] if len(v) > 10 else 0.0
+        return cls(*[int(x) for x in v[:10]], absmax)
 
 
 _descp = ctypes.POINTER(PackedDesc)

@@ -109,6 +109,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// maximum over the wave of an unsigned value (DPP within the rows, scalar across them); wave-uniform result
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  uint32_t o;
+  o = dpp_u32<0xB1>(v);  v = o > v ? o : v;
+  o = dpp_u32<0x4E>(v);  v = o > v ? o : v;
+  o = dpp_u32<0x141>(v); v = o > v ? o : v;
+  o = dpp_u32<0x140>(v); v = o > v ? o : v;
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
+
 // compile-time extraction of code #idx from the dwords of one code word
 template <int CODE_BYTES, int N>
 __device__ __forceinline__ uint32_t code_at(const uint32_t (&cw)[N], int idx) {
@@ -135,7 +152,7 @@ struct Tuning {
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
   int gemm_splitk_free = 0;      // 1: large-batch 1x16 op uses the split-K-free 16x16x32 kernel when in % 256 == 0
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
-  int packed_fused_finalize = 0;  // experiment: 1 = finalize inside the main kernel (one returning atomic per row)
+  int packed_fused_finalize = 1;  // 0 = two-kernel finalize even when the descriptor carries the codebook range (A/B runs)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
   int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel), 0 = ascending j
   int packed_xcopies = 0;        // prepack: rotated copies of x the batch-1 kernel keeps in LDS (1..4, capped by what fits); 0 = 1

@@ -54,7 +54,8 @@ constexpr uint32_t PK_SLICE_BYTES = PK_SLICE_ENTRIES * 16;
 constexpr int PK_MAX_NW = 16;
 constexpr int PK_MAX_T = 1024;
 constexpr int PK_MAX_GROUPS = 4094;          // j needs 12 bits, in_groups itself is the null slot
-constexpr uint32_t PK_MAGIC = 0x35505141u;   // "AQP5"
+constexpr uint32_t PK_MAGIC = 0x36505141u;   // "AQP6"
+constexpr int PK_VERSION = 6;
 constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (x first, slice behind it)
 
 // x copies (batch-1 kernel): copy c of x starts at 16-B slot c * stride with stride = 4 (mod 16), i.e. its bank-group
@@ -71,10 +72,10 @@ constexpr int PK_WREG3 = 776;   // ... per step incl. its 8-B row-end flag word 
 
 struct PackedLayout {
   int M, in_groups, RG, NW, T, XC, EB;
-  size_t nst, off_winfo, off_rowstart, off_ent, ent_bytes, used;
+  size_t nst, off_winfo, off_rowstart, off_acc, off_ent, ent_bytes, used;
 };
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static bool packed_shape_ok(int out_features, int in_features, int g) {
   return g == 8 && out_features > 0 && in_features > 0 && in_features % 8 == 0 && in_features / 8 <= PK_MAX_GROUPS &&
@@ -95,14 +96,16 @@ static bool packed_layout(int out_features, int in_features, int NW, int T, Pack
   L.nst = (size_t)PK_NG * PK_S;
   L.off_winfo = 256;
   L.off_rowstart = align_up(L.off_winfo + L.nst * PK_MAX_NW * 16, 256);         // [nst][RG + 1] u32 (offset independent of NW)
-  L.off_ent = align_up(L.off_rowstart + L.nst * (size_t)(L.RG + 1) * 4, 1024);
+  // accumulator cells of the fused finalize: [AQLM_HIP_MAX_GEMV_BATCH][M] u64, zero at rest (offset independent of NW, T)
+  L.off_acc = align_up(L.off_rowstart + L.nst * (size_t)(L.RG + 1) * 4, 256);
+  L.off_ent = align_up(L.off_acc + (size_t)AQLM_HIP_MAX_GEMV_BATCH * out_features * 8, 1024);
   L.ent_bytes = L.nst * NW * T * (EB == 3 ? (size_t)PK_WREG3 : (size_t)1024);
   L.used = L.off_ent + L.ent_bytes;
   return L.ent_bytes < ((size_t)1 << 32);  // 32-bit buffer offsets
 }
 
 static bool desc_layout(const aqlm_hip_packed_desc* d, PackedLayout& L) {
-  return d && d->magic == PK_MAGIC && d->version == 5 && d->slices_log2 == PK_S_LOG &&
+  return d && d->magic == PK_MAGIC && d->version == PK_VERSION && d->slices_log2 == PK_S_LOG &&
          packed_layout(d->out_features, d->in_features, d->waves, d->steps, L, (int)d->x_copies, d->entry_bytes) &&
          L.used == d->used_bytes;
 }
@@ -507,6 +510,7 @@ struct PackedGemvParams {
   uint32_t ent_bytes;
   // fused finalize (acc != nullptr): the 16 slice workgroups of a row meet in ONE 64-bit cell per (input row, output row)
   unsigned long long* acc;  // [B][M], zero at rest
+  float cb_absmax;          // largest |codebook entry| of the layer (bounds the slice sums)
   const uint16_t* scales;
   const uint16_t* bias;
   uint16_t* y;
@@ -556,8 +560,11 @@ struct PackedLds {
   __host__ __device__ static uint32_t rs_bytes(int RG) { return ((uint32_t)(RG + 1) * 4u + 1023u) & ~1023u; }  // whole DMA pieces
   __host__ __device__ static uint32_t rowval(int in_groups, int RG) { return rowstart(in_groups) + rs_bytes(RG); }
   __host__ __device__ static uint32_t colend(int in_groups, int RG) { return rowval(in_groups, RG) + (uint32_t)B * (RG + 1) * 4u; }
+  __host__ __device__ static uint32_t xmax(int in_groups, int RG) {  // 16-B aligned: read with ds_read_b128
+    return (colend(in_groups, RG) + (uint32_t)B * PK_MAX_NW * 64 * 4 + 15u) & ~15u;
+  }
   __host__ __device__ static size_t total(int in_groups, int RG) {
-    return (size_t)colend(in_groups, RG) + (size_t)B * PK_MAX_NW * 64 * 4;
+    return (size_t)xmax(in_groups, RG) + (size_t)B * PK_MAX_NW * 4;  // xmax[B][16 waves] u32: largest |x| seen by each wave (fused finalize)
   }
 };
 
@@ -657,11 +664,16 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   }
   // (4) LDS that needs no data: the zero vectors the null entries point at
   if (tid < B) *reinterpret_cast<u32x4*>(smem_raw + LDS::X + (uint32_t)tid * XP + (uint32_t)p.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};
+  const uint32_t xmax_off = LDS::xmax(p.in_groups, p.RG);
+  if (tid < B * PK_MAX_NW) *reinterpret_cast<uint32_t*>(smem_raw + xmax_off + (uint32_t)tid * 4u) = 0u;  // slots of absent waves
   AQLM_TRACE(1);  // every load of the prologue has been issued
   // (5) the slice and x are older in the VMEM queue than the PD ring loads: wait for everything BUT the ring, so the
   // stream keeps flowing while the loop starts (a __syncthreads() here would emit vmcnt(0) and drain it)
   // (the builtin, not an asm string: hipcc's wait-count pass must learn that the LDS-DMA ops have retired, or it guards
   // the first use of the ring with vmcnt(0))
+  // the parameters of the epilogue (the non-preloaded tail of the kernel arguments) are fetched NOW, under the LDS fill:
+  // left to the compiler their s_load sits at the first use, behind the loop, with its whole latency exposed (0.3 us)
+  asm volatile("" : : "s"(p.acc), "s"(p.partial), "s"(p.scales), "s"(p.bias), "s"(p.y), "s"(p.y_row_stride), "s"(p.cb_absmax));
   __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD) lgkmcnt(0)
   __builtin_amdgcn_s_barrier();
   AQLM_TRACE(2);
@@ -802,6 +814,28 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     for (int k = 0; k < PD - 1; ++k)
       if (k < rem) step(ring[k]);
   }
+  // Fused finalize: the largest |x| of every input row, as the 15-bit magnitude pattern of the storage type (integer
+  // order == magnitude order; a NaN compares above Inf, so it surfaces).  x sits in LDS and every workgroup of the layer
+  // sees the same x, so all of them derive the same fixed-point scale from it in the epilogue.  Done AFTER the loop: the
+  // waves finish it at different times (the SIMDs favour their older waves), so for most of them this is idle time, and
+  // right behind the fill barrier it would stand between every wave and its first lane-step (measured: 0.35 us).
+  if (p.acc != nullptr) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      us2 m = {0, 0};
+      for (int idx = tid; idx < p.in_groups; idx += NT) {
+        const u32x4 v = *(lds_u32x4_ptr)(size_t)(LDS::X + (uint32_t)b * (B == 1 ? 0u : XP) + (uint32_t)idx * 16u);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(us2, w[k] & 0x7fff7fffu));
+      }
+      // wave maximum on the VALU (DPP), one slot per wave: no LDS atomics, no shuffle round trips on the way to the loop
+      const uint32_t mm = wave_max_u32(m.x > m.y ? (uint32_t)m.x : (uint32_t)m.y);
+      if (lane == 0) *reinterpret_cast<uint32_t*>(smem_raw + xmax_off + (uint32_t)(b * PK_MAX_NW + wave) * 4u) = mm;
+    }
+  }
+
   // what the column gathered after its last row end belongs to a row that continues in the next column (0 otherwise)
   if (wave < p.NW) {
 #pragma unroll
@@ -830,18 +864,39 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #pragma unroll
         for (int b = 0; b < B; ++b) p.partial[((size_t)slice * B + b) * p.M + row_begin + r] = v[b];
       } else {
-        // Fused finalize.  The slice sum goes into the row's cell as a fixed-point number, 2^-30 units in bits 63..10
-        // (integer adds commute: the result does not depend on the order the 16 workgroups arrive in), together with
-        // +1 in the arrival counter (bits 4..0) and +1 in bits 9..5 if the value does not fit (|v| >= 2^22, Inf, NaN).
-        // ONE returning atomic per cell is the whole hand-shake: whoever reads 15 earlier arrivals owns the total,
-        // applies scale and bias, rounds once, writes y and puts the cell back to zero for the next launch.
+        // Fused finalize.  The slice sum goes into the row's cell as a fixed-point number in bits 63..10 (integer adds
+        // commute: the total does not depend on the order the 16 workgroups arrive in), together with +1 in the arrival
+        // counter (bits 4..0) and +1 in bits 9..5 if the value is not finite.  The unit 2^-sh comes from a bound every
+        // workgroup of the layer computes identically: |slice sum| <= in_features * max|codebook| * max|x| < 2^e, so
+        // with sh = 47 - e sixteen addends stay below 2^52 -- no overflow whatever the data, and ~2^-47 of the bound as
+        // resolution (fp32 partials carry 2^-24 of their own magnitude).  ONE returning atomic per cell is the whole
+        // hand-shake: whoever reads 15 earlier arrivals owns the total, applies scale and bias, rounds once, writes y and
+        // puts the cell back to zero for the next launch.
         const int row = row_begin + r;
         unsigned long long old[B], mine[B];
+        int sh[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-          const bool fits = fabsf(v[b]) < 4194304.f;  // false for NaN
-          const long long q = fits ? __float2ll_rn(v[b] * 1073741824.f) : 0ll;
-          mine[b] = ((unsigned long long)q << 10) + (fits ? 1ull : 33ull);
+          uint32_t xm = 0u;  // every wave of the workgroup left the maximum of its share of x
+          {                  // (16 slots = four 16-B reads in flight together)
+            static_assert(PK_MAX_NW == 16, "four 16-byte reads cover the slots");
+            u32x4 sl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sl[q] = *(lds_u32x4_ptr)(size_t)(xmax_off + (uint32_t)(b * PK_MAX_NW + q * 4) * 4u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t a = sl[q].x > sl[q].y ? sl[q].x : sl[q].y, c = sl[q].z > sl[q].w ? sl[q].z : sl[q].w;
+              const uint32_t d = a > c ? a : c;
+              xm = d > xm ? d : xm;
+            }
+          }
+          const float bound = (float)p.in_groups * 8.f * p.cb_absmax * T_::to_float((uint16_t)xm);
+          int e = 0;
+          (void)frexpf(bound, &e);                               // bound < 2^e (e = 0 for bound == 0)
+          const bool finite = bound < __builtin_inff() && fabsf(v[b]) <= 2.f * bound;  // false for NaN / Inf anywhere
+          sh[b] = 47 - e;
+          const long long q = finite ? __float2ll_rn(ldexpf(v[b], sh[b])) : 0ll;
+          mine[b] = ((unsigned long long)q << 10) + (finite ? 1ull : 33ull);
           old[b] = __hip_atomic_fetch_add(p.acc + (size_t)b * p.M + row, mine[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const float scale = T_::to_float(p.scales[row]);
@@ -851,7 +906,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
           if ((old[b] & 31ull) == (unsigned long long)(PK_S - 1)) {
             const unsigned long long cell = old[b] + mine[b];
             const long long sum = (long long)cell >> 10;
-            float sv = (float)((double)sum * 0x1p-30);
+            float sv = (float)ldexp((double)sum, -sh[b]);
             if ((cell >> 5) & 31ull) sv = __builtin_nanf("");
             p.y[(size_t)b * p.y_row_stride + row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
             __hip_atomic_store(p.acc + (size_t)b * p.M + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -882,6 +937,7 @@ struct PackedGemvRest {
   const uint16_t* bias;
   uint16_t* y;
   long y_row_stride;
+  float cb_absmax;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;
   int dbg;
@@ -901,6 +957,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* c
   p.x = x;
   p.partial = rest.partial;
   p.acc = rest.acc;
+  p.cb_absmax = rest.cb_absmax;
   p.scales = rest.scales;
   p.bias = rest.bias;
   p.y = rest.y;
@@ -930,6 +987,13 @@ struct PackedSegment {
   float* partial;
   int M, RG, NW, T, XC;
   uint32_t ent_bytes;
+  // fused finalize (acc != nullptr)
+  unsigned long long* acc;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+  long y_row_stride;
+  float cb_absmax;
 };
 
 struct PackedMultiParams {
@@ -960,6 +1024,12 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const Pack
       p.T = mp.seg[k].T;
       p.XC = mp.seg[k].XC;
       p.ent_bytes = mp.seg[k].ent_bytes;
+      p.acc = mp.seg[k].acc;
+      p.scales = mp.seg[k].scales;
+      p.bias = mp.seg[k].bias;
+      p.y = mp.seg[k].y;
+      p.y_row_stride = mp.seg[k].y_row_stride;
+      p.cb_absmax = mp.seg[k].cb_absmax;
     }
   }
   gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, (int)blockIdx.x & 255, (int)blockDim.x >> 6);
@@ -1107,7 +1177,7 @@ extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features,
   const size_t in_groups = (size_t)in_features / 8;
   const size_t lane_steps = RG * in_groups / (4 * PK_S) * 5 / 4 + RG + 64;   // per stream
   const size_t ent = nst * (lane_steps * 16 + 16 * 1024);
-  const size_t meta = 2048 + nst * PK_MAX_NW * 16 + nst * (RG + 1) * 4;
+  const size_t meta = 4096 + nst * PK_MAX_NW * 16 + nst * (RG + 1) * 4 + (size_t)AQLM_HIP_MAX_GEMV_BATCH * out_features * 8;
   // 3-byte entries: the repack builds the 4-byte layout in the tail of the buffer and squeezes it to the front
   return align_up(meta + ent + ent * PK_WREG3 / 1024 + 4096, 1024);
 }
@@ -1168,7 +1238,7 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   uint32_t* ent = EB == 4 ? (uint32_t*)(base + L.off_ent) : (uint32_t*)(base + (packed_bytes - L4.ent_bytes) / 1024 * 1024);
   aqlm_hip_packed_desc d{};
   d.magic = PK_MAGIC;
-  d.version = 5;
+  d.version = PK_VERSION;
   d.out_features = M;
   d.in_features = in_features;
   d.slices_log2 = PK_S_LOG;
@@ -1176,7 +1246,8 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   d.steps = T;
   d.entry_bytes = EB;
   d.used_bytes = L.used;
-  d.x_copies = (uint64_t)XC;
+  d.x_copies = (uint32_t)XC;
+  d.codebook_absmax = 0.f;  // unknown: the caller sets it (see include/aqlm_hip.h) to enable the fused finalize
   if (int e = check_hip(hipMemcpyAsync(base, &d, sizeof(d), hipMemcpyHostToDevice, stream), "prepack header")) return e;
   const uint32_t null_entry = (uint32_t)in_groups << 20;
   hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4, null_entry);
@@ -1227,19 +1298,26 @@ extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void
   return check_hip(hipGetLastError(), "unpack launch");
 }
 
-// main kernel of one launch (<= packed_max_batch rows): fp32 slice partials [16][nb][M] -> workspace
-struct PackedFused {  // fused finalize: where y goes (nullptr members = the two-kernel form with fp32 partials)
+// The fused finalize needs the layer's codebook range (descriptor field) and can be switched off for A/B runs.
+static bool packed_fused(const aqlm_hip_packed_desc* desc) {
+  return tuning().packed_fused_finalize != 0 && desc->codebook_absmax > 0.f && desc->codebook_absmax < __builtin_inff();
+}
+
+// main kernel of one launch (<= packed_max_batch rows).  With `fused.y` it also finalizes (accumulator cells inside the
+// packed buffer, no workspace); without, it leaves fp32 slice partials [16][nb][M] in the workspace.
+struct PackedFused {
   const void* scales = nullptr;
   const void* bias = nullptr;
   void* y = nullptr;
   long y_row_stride = 0;
+  float cb_absmax = 0.f;
 };
 
 static int packed_launch_main(const PackedLayout& L, const void* packed, const void* codebook, const uint16_t* x, int nb,
                               long x_row_stride, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream,
                               const char* who, const PackedFused& fused = PackedFused{}) {
-  const size_t need = fused.y ? (size_t)nb * L.M * 8 : (size_t)PK_S * nb * L.M * sizeof(float);
-  if (!workspace || workspace_bytes < need) {
+  const size_t need = fused.y ? 0 : (size_t)PK_S * nb * L.M * sizeof(float);
+  if (need && (!workspace || workspace_bytes < need)) {
     set_last_error("%s: workspace of %zu bytes required, got %zu", who, need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
   }
@@ -1252,7 +1330,8 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.x = x;
   p.partial = (float*)workspace;
   if (fused.y) {
-    p.acc = (unsigned long long*)workspace;
+    p.acc = (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
+    p.cb_absmax = fused.cb_absmax;
     p.scales = (const uint16_t*)fused.scales;
     p.bias = (const uint16_t*)fused.bias;
     p.y = (uint16_t*)fused.y;
@@ -1267,7 +1346,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.XC = L.XC;
   p.ent_bytes = (uint32_t)L.ent_bytes;
 #ifdef AQLM_PACKED_TRACE
-  p.trace = workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+  p.trace = workspace && workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
   p.dbg = tuning().packed_debug;
 #endif
   auto launch = [&](auto kern, auto lds_map) -> int {
@@ -1278,6 +1357,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
     rest.partial = p.partial;
     rest.x_row_stride = p.x_row_stride;
     rest.acc = p.acc;
+    rest.cb_absmax = p.cb_absmax;
     rest.scales = p.scales;
     rest.bias = p.bias;
     rest.y = p.y;
@@ -1321,7 +1401,7 @@ static int packed_check_args(const char* who, const aqlm_hip_packed_desc* desc, 
   return 0;
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                          const void* scales, const void* bias, const void* x, void* y, int batch,
                                          long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                          size_t workspace_bytes, void* stream_) {
@@ -1335,8 +1415,9 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const
   if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b)) return e;
   for (int b0 = 0; b0 < batch; b0 += max_b) {  // rows that do not fit one LDS image go in several launches
     const int nb = std::min(max_b, batch - b0);
-    if (tuning().packed_fused_finalize) {  // experiment: the workspace holds the zero-at-rest accumulator cells
+    if (packed_fused(desc)) {
       PackedFused fz;
+      fz.cb_absmax = desc->codebook_absmax;
       fz.scales = scales;
       fz.bias = bias;
       fz.y = (uint16_t*)y + (size_t)b0 * y_row_stride;
@@ -1411,6 +1492,8 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
   mp.nseg = fm.nseg = num_segments;
   size_t need = 0;
   int fblocks = 0, max_rg = 0, nw = 0, pd = 4, eb = 0;
+  bool fused = true;  // every segment must know its codebook range
+  for (int k = 0; k < num_segments; ++k) fused = fused && descs[k] && packed_fused(descs[k]);
   for (int k = 0; k < num_segments; ++k) {
     const aqlm_hip_segment& sg = segments[k];
     if (!sg.codes || !sg.codebook || !sg.scales || !sg.y) {
@@ -1430,7 +1513,15 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     ps.winfo = (const uint32_t*)(base + L.off_winfo);
     ps.rowstart = (const uint32_t*)(base + L.off_rowstart);
     ps.codebook = (const uint8_t*)sg.codebook;
-    ps.partial = (float*)((uint8_t*)workspace + need);
+    ps.partial = fused ? nullptr : (float*)((uint8_t*)workspace + need);
+    if (fused) {
+      ps.acc = (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
+      ps.scales = (const uint16_t*)sg.scales;
+      ps.bias = (const uint16_t*)sg.bias;
+      ps.y = (uint16_t*)sg.y;
+      ps.y_row_stride = sg.y_row_stride;
+      ps.cb_absmax = descs[k]->codebook_absmax;
+    }
     ps.M = L.M;
     ps.RG = L.RG;
     ps.NW = L.NW;
@@ -1458,7 +1549,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     fblocks += (sg.out_features + 255) / 256;
     need += (size_t)PK_S * batch * sg.out_features * sizeof(float);
   }
-  if (!workspace || workspace_bytes < need) {
+  if (!fused && (!workspace || workspace_bytes < need)) {
     set_last_error("aqlm_hip_gemv_1x16_packed_multi: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
   }
@@ -1473,6 +1564,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
   };
   if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, eb, launch)) return e;
+  if (fused) return 0;
   if (dtype == AQLM_HIP_F16)
     hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);
   else

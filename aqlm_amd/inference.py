@@ -202,7 +202,7 @@ class QuantizedLinear(nn.Module):
                 return
             from .inference_kernels import hip_kernel
 
-            self._packed_codes = hip_kernel.prepack_1x16(self.codes, 8)
+            self._packed_codes = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
             self._packed_fingerprint = self._codes_fingerprint()
 
 

@@ -118,18 +118,31 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
 
 
 # ------------------------------------------------------------------------------------------------------
-# prepacked 1x16 g8 path (format v5): 1..8 input rows per launch on slice-bucketed codes
+# prepacked 1x16 g8 path (format v6): 1..8 input rows per launch on slice-bucketed codes
 # ------------------------------------------------------------------------------------------------------
 class PackedCodes:
     """A prepacked 1x16 g8 code buffer (``aqlm_hip_prepack_1x16``): device bytes + the host-side descriptor the
     kernels are launched with.  Derived from ``codes`` (lossless: ``unpack_1x16`` gives them back); never saved."""
 
-    __slots__ = ("buf", "desc", "out_features", "in_features", "_ints")
+    __slots__ = ("buf", "desc", "out_features", "in_features", "_ints", "_range_of")
 
     def __init__(self, buf: torch.Tensor, desc: "_native.PackedDesc"):
         self.buf, self.desc = buf, desc
         self.out_features, self.in_features = int(desc.out_features), int(desc.in_features)
         self._ints = desc.as_ints()
+        self._range_of = None  # fingerprint of the codebook tensor `desc.codebook_absmax` was taken from
+
+    def set_codebook_range(self, codebooks: torch.Tensor) -> None:
+        """Record max |codebook entry| in the descriptor: it lets the kernel finalize in the same launch (the slice sums
+        meet in fixed-point cells whose scale is derived from this bound and the input's magnitude; include/aqlm_hip.h).
+        One small reduction + a host read-back: load-time work, never issued while a hipGraph is being captured."""
+        absmax = float(codebooks.detach().abs().max().float().item())
+        self.desc.codebook_absmax = absmax if absmax == absmax and absmax != float("inf") else 0.0
+        self._ints = self.desc.as_ints()
+        self._range_of = (codebooks.data_ptr(), codebooks._version)
+
+    def range_is_current(self, codebooks: torch.Tensor) -> bool:
+        return self._range_of == (codebooks.data_ptr(), codebooks._version)
 
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
@@ -151,10 +164,11 @@ class PackedCodes:
         return cls(buf, desc)
 
 
-def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8) -> Optional[PackedCodes]:
+def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8, codebooks: Optional[torch.Tensor] = None) -> Optional[PackedCodes]:
     """Repack 1x16 g8 codes [out, in/8, 1] (int16) into the slice-bucketed buffer of aqlm_hip_gemv_1x16_packed.
     Returns None when the packed path does not cover the layer.  One-off, at load / first use (the counterpart of the
-    reference's load-time code permutation for its CPU kernel, inference.py:78-83)."""
+    reference's load-time code permutation for its CPU kernel, inference.py:78-83).  With ``codebooks`` the descriptor
+    also gets the layer's codebook range (``PackedCodes.set_codebook_range``): single-kernel matvecs."""
     out_features, in_features = codes.shape[0], codes.shape[1] * in_group_size
     cap = _lib.aqlm_hip_prepack_1x16_bytes(out_features, in_features, in_group_size)
     if cap == 0:
@@ -169,7 +183,10 @@ def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8) -> Optional[Packed
         return None  # codes too unevenly spread over the codebook slices: the direct kernel serves this layer
     if rc:
         _native.check(rc, "aqlm prepack_1x16")
-    return PackedCodes(scratch[: int(desc.used_bytes)].clone(), desc)  # keep only the bytes in use
+    packed = PackedCodes(scratch[: int(desc.used_bytes)].clone(), desc)  # keep only the bytes in use
+    if codebooks is not None:
+        packed.set_codebook_range(codebooks)
+    return packed
 
 
 def unpack_1x16(packed: PackedCodes) -> torch.Tensor:
@@ -200,6 +217,31 @@ def _workspace(device: torch.device, nbytes: int, stream: Optional[int] = None) 
     return ws
 
 
+FUSED_FINALIZE = True  # mirror of the library knob `packed_fused_finalize` (set both through set_fused_finalize)
+
+
+def set_fused_finalize(on: bool) -> None:
+    """A/B switch: finalize inside the prepacked kernel (default) or in a second kernel through an fp32 workspace."""
+    global FUSED_FINALIZE
+    _native.set_tuning("packed_fused_finalize", 1 if on else 0)
+    FUSED_FINALIZE = bool(on)
+
+
+def _refresh_range(packed: PackedCodes, codebooks: torch.Tensor) -> None:
+    """Keep ``desc.codebook_absmax`` in step with the codebook tensor the op is called with (first use, or the codebook
+    was retrained / rebound).  While a hipGraph is being captured nothing can be read back: an unknown range means the
+    two-kernel path for that call."""
+    if packed.range_is_current(codebooks):
+        return
+    if torch.cuda.is_current_stream_capturing() or torch.compiler.is_compiling():
+        if packed._range_of is not None:  # stale, not merely missing: do not trust it
+            packed.desc.codebook_absmax = 0.0
+            packed._ints = packed.desc.as_ints()
+            packed._range_of = None
+        return
+    packed.set_codebook_range(codebooks)
+
+
 def _check_packed_args(input, packed, codebooks, scales):
     dt = _dtype_id(input)
     if codebooks.dtype != input.dtype or scales.dtype != input.dtype:
@@ -223,16 +265,20 @@ def code1x16_matmat_packed(input, packed: PackedCodes, codebooks, scales, bias=N
     B = x.shape[0]
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
     nb_max = min(B, _native.MAX_GEMV_BATCH)
-    ws_bytes = 16 * nb_max * out_features * 4
     stream = _stream_ptr(input.device)
-    ws = _workspace(input.device, ws_bytes, stream)
+    _refresh_range(packed, codebooks)
+    if FUSED_FINALIZE and packed.desc.codebook_absmax > 0.0:   # single kernel: the accumulator cells live in the packed buffer
+        ws_ptr, ws_len = None, 0
+    else:                                   # two kernels: fp32 slice partials in a workspace
+        ws = _workspace(input.device, 16 * nb_max * out_features * 4, stream)
+        ws_ptr, ws_len = ws.data_ptr(), ws.numel() * 4
     with _device_guard(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
             rc = _lib.aqlm_hip_gemv_1x16_packed(ctypes.byref(packed.desc), packed.data_ptr(), codebooks.data_ptr(),
                                                 scales.data_ptr(), _ptr(bias), x.data_ptr() + b0 * x.stride(0) * 2,
                                                 y.data_ptr() + b0 * out_features * 2, nb, x.stride(0), out_features, dt,
-                                                ws.data_ptr(), ws.numel() * 4, stream)
+                                                ws_ptr, ws_len, stream)
             if rc:
                 _native.check(rc, "aqlm gemv_1x16_packed")
     return y.reshape(input.shape[:-1] + (out_features,))
@@ -360,11 +406,10 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
     descs = (_native._descp * n)()
     keep, outs = [], []
     total = sum(pk.out_features for pk in packed)
-    ws_bytes = 16 * B * total * 4
-    ws = _workspace(input.device, ws_bytes)
     dt = None
     for k in range(n):
         dt = _check_packed_args(input, packed[k], codebooks[k], scales[k])
+        _refresh_range(packed[k], codebooks[k])
         cb, sc = _c(codebooks[k]), _c(scales[k])
         bi = None if bias[k] is None else _c(bias[k])
         of = packed[k].out_features
@@ -374,9 +419,15 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
         segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = packed[k].data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), of, of
         descs[k] = ctypes.pointer(packed[k].desc)
+    stream = _stream_ptr(input.device)
+    if FUSED_FINALIZE and all(pk.desc.codebook_absmax > 0.0 for pk in packed):  # single kernel, no workspace
+        ws_ptr, ws_len = None, 0
+    else:
+        ws = _workspace(input.device, 16 * B * total * 4, stream)
+        ws_ptr, ws_len = ws.data_ptr(), ws.numel() * 4
     with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, descs, n, x.data_ptr(), packed[0].in_features, B, x.stride(0), dt,
-                                                  ws.data_ptr(), ws.numel() * 4, _stream_ptr(input.device))
+                                                  ws_ptr, ws_len, stream)
     if rc == _native.E_UNSUPPORTED and B > 1:
         # the rows do not fit one LDS image next to the codebook slice (very wide inputs): per-layer launches split the
         # rows themselves; same kernels, same bits
@@ -734,7 +785,9 @@ for _name, _impl in (("code1x16_matmat_multi", code1x16_matmat_multi), ("codekx8
 # the prepacked op as a dispatcher op, so that a QuantizedLinear on the packed path traces under torch.compile
 # (the descriptor travels as a list of ints; eager calls skip the dispatcher and use code1x16_matmat_packed directly)
 def _packed_op(input, packed, codebooks, scales, bias, desc):
-    return code1x16_matmat_packed(input, PackedCodes(packed, _native.PackedDesc.from_ints(desc)), codebooks, scales, bias)
+    pk = PackedCodes(packed, _native.PackedDesc.from_ints(desc))
+    pk._range_of = (codebooks.data_ptr(), codebooks._version)  # the caller's descriptor is taken at its word (0 = unknown)
+    return code1x16_matmat_packed(input, pk, codebooks, scales, bias)
 
 
 def _fake_packed(input, packed, codebooks, scales, bias, desc):

@@ -121,7 +121,7 @@ class ShardedQuantizedLinear(nn.Module):
             from .inference_kernels import hip_kernel
 
             self._packed_tried = True
-            self._packed = hip_kernel.prepack_1x16(self.codes, 8)
+            self._packed = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
         if (self._packed is not None and x.dtype == self.codebooks.dtype
                 and x.numel() // x.shape[-1] <= inference.GEMV_MAX_ROWS):
             from .inference_kernels import hip_kernel
@@ -140,7 +140,7 @@ class ShardedQuantizedLinear(nn.Module):
                 self._packed_tried = True
                 if (tuple(self.codebooks.shape[:3]) == (1, 65536, 1) and self.codebooks.shape[3] == 8
                         and self.codes.shape[0] * self.codes.shape[1] >= inference.PREPACK_MIN_CODES):
-                    self._packed = hip_kernel.prepack_1x16(self.codes, 8)
+                    self._packed = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
             ok = torch.tensor([1 if self._packed is not None else 0], device=xs.device)
             if dist.is_initialized() and dist.get_world_size(self.group) > 1:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)

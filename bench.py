@@ -74,7 +74,7 @@ class Layer:
         """One-off load-time repack for the slice-bucketed decode kernel (layers with >= PACK_MIN_OUT codes)."""
         from aqlm_amd.inference_kernels import hip_kernel as hk
 
-        self.packed = hk.prepack_1x16(self.codes, self.g)
+        self.packed = hk.prepack_1x16(self.codes, self.g, codebooks=self.codebooks)  # + the codebook range: single-kernel matvecs
         if self.packed is not None:
             nb = self.x.shape[0]
             self.ws = torch.empty((16 * nb * self.fout,), dtype=torch.float32, device=self.codes.device)

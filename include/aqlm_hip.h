@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 2
+#define AQLM_HIP_ABI_VERSION 3
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -163,7 +163,7 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
                             size_t workspace_bytes, void* stream);
 
 /*
- * Load-time repack of 1x16 g8 codes into the slice-bucketed format v5 consumed by aqlm_hip_gemv_1x16_packed (layout:
+ * Load-time repack of 1x16 g8 codes into the slice-bucketed format v6 consumed by aqlm_hip_gemv_1x16_packed (layout:
  * aqlm_amd/csrc/gemv_packed.hip, specification tests/packed_model.py; 4 bytes per code + ~6 bytes per (row, slice)).
  * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
  * (inference.py:78-83).
@@ -177,15 +177,20 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
  *   aqlm_hip_unpack_1x16         the inverse: canonical int16 codes [out][in/8] from a packed buffer (lossless).
  */
 typedef struct aqlm_hip_packed_desc {
-  uint32_t magic;   /* "AQP5" */
-  uint32_t version; /* 5 */
+  uint32_t magic;   /* "AQP6" */
+  uint32_t version; /* 6 */
   int32_t out_features, in_features;
   int32_t slices_log2; /* 4: 16 codebook slices of 4096 entries */
   int32_t waves;       /* wave ranges per stream = waves per workgroup of the gemv kernel */
   int32_t steps;       /* KiB steps per wave range */
   int32_t entry_bytes; /* 4 */
   uint64_t used_bytes;
-  uint64_t x_copies;   /* rotated copies of x the batch-1 kernel keeps in LDS (1..4); entries name the copy they read */
+  uint32_t x_copies;   /* rotated copies of x the batch-1 kernel keeps in LDS (1..4); entries name the copy they read */
+  float codebook_absmax; /* max |codebook entry| of the layer, set by the CALLER after prepack (prepack does not see the
+                            codebook; 0 = unknown).  > 0 enables the fused finalize of aqlm_hip_gemv_1x16_packed[_multi]:
+                            it bounds the slice sums, from which the kernel derives an overflow-free fixed-point scale.
+                            Must be >= the true maximum (update it when the codebook is retrained); any finite value
+                            that is too large only costs resolution (the sums keep ~47 bits below the bound). */
 } aqlm_hip_packed_desc;
 
 size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size);
@@ -199,16 +204,23 @@ int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, v
  * codebook in LDS and walks only the codes of that slice; the rows of x share the codes and the gathered codebook
  * vectors.  Same result contract as aqlm_hip_gemv_1x16 (which it replaces for large layers; same reference lines:
  * cuda_kernel.cu:7-95, cuda_kernel.cpp:148-182 incl. the per-row relaunch loop :165-175).  x / y row strides in elements.
+ * Finalize: with desc->codebook_absmax > 0 the 16 slice workgroups of an output row add their sums as fixed-point
+ * integers into one 64-bit cell INSIDE the packed buffer (order-independent, hence deterministic; the cells are zero at rest
+ * and every call leaves them zero), and the last one to arrive writes y -- one kernel, no workspace (`workspace` may be
+ * NULL).  The packed buffer is therefore WRITTEN by the call: do not run the same packed buffer on two streams at once.
+ * With codebook_absmax == 0 the call falls back to two kernels and needs
  * workspace: aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, batch, out, in) bytes of fp32 partials.
  */
-int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                               const void* scales, const void* bias, const void* x, void* y, int batch,
                               long x_row_stride, long y_row_stride, int dtype, void* workspace, size_t workspace_bytes,
                               void* stream);
 
 /*
  * aqlm_hip_gemv_1x16_packed for up to AQLM_HIP_MAX_SEGMENTS prepacked layers that share x, in one launch (+ one
- * finalize); segment.codes is the prepacked buffer, descs[s] its descriptor.  workspace: the sum over segments of
+ * finalize; none when every descriptor carries codebook_absmax: the fused finalize of aqlm_hip_gemv_1x16_packed, which
+ * writes into the packed buffers); segment.codes is the prepacked buffer, descs[s] its descriptor.  workspace (two-kernel
+ * fallback only): the sum over segments of
  * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_1X16_PACKED, batch, out_features_s, in_features), 16-B aligned.  Results
  * are bit-identical to separate aqlm_hip_gemv_1x16_packed calls.
  */

@@ -1,4 +1,4 @@
-"""numpy model of the packed 1x16 g8 format v5 (aqlm_amd/csrc/gemv_packed.hip): the specification that
+"""numpy model of the packed 1x16 g8 format v6 (aqlm_amd/csrc/gemv_packed.hip): the specification that
 aqlm_hip_prepack_1x16 is held to, plus a straight-line simulation of the kernel's traversal (column walk, flag masks,
 LDS slots, carries).  Test infrastructure only.
 
@@ -22,7 +22,7 @@ CODE_BITS = 16 - S_LOG
 SLICE_ENTRIES = 1 << CODE_BITS
 XB = SLICE_ENTRIES
 MAX_T = 128
-MAGIC = 0x35505141  # "AQP5"
+MAGIC = 0x36505141  # "AQP6"
 
 
 def align_up(v, a):
@@ -47,9 +47,10 @@ def layout(M, in_groups, NW, T, entry_bytes=4):
     nst = NG * S
     off_winfo = 256
     off_rowstart = align_up(off_winfo + nst * 16 * 16, 256)
-    off_ent = align_up(off_rowstart + nst * (RG + 1) * 4, 1024)
+    off_acc = align_up(off_rowstart + nst * (RG + 1) * 4, 256)      # [8][M] u64 accumulator cells of the fused finalize, zero at rest
+    off_ent = align_up(off_acc + 8 * M * 8, 1024)
     ent_bytes = nst * NW * T * (776 if entry_bytes == 3 else 1024)
-    return dict(RG=RG, off_winfo=off_winfo, off_rowstart=off_rowstart, off_ent=off_ent, ent_bytes=ent_bytes,
+    return dict(RG=RG, off_winfo=off_winfo, off_rowstart=off_rowstart, off_acc=off_acc, off_ent=off_ent, ent_bytes=ent_bytes,
                 used=off_ent + ent_bytes)
 
 

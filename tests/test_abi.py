@@ -32,7 +32,7 @@ def test_header_and_binding_agree(native):
 
 
 def test_abi_version_and_error_string(native):
-    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 2
+    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 3
     assert isinstance(native.last_error(), str)
 
 
@@ -99,8 +99,9 @@ def test_segment_struct_and_multi_validation(native):
     assert rc == native.E_INVALID and "descriptor" in native.last_error()
     rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(bad), p, p, p, None, p, p, 1, 512, 64, native.F16, p, 1 << 20, None)
     assert rc == native.E_INVALID and "descriptor" in native.last_error()
-    # 64 rows -> 4 per row group; winfo (sized for 16 waves) + row starts (256 x 5 u32) end at 70 KiB, then 256 x 4 x 1 KiB
-    good = native.PackedDesc(0x35505141, 5, 64, 512, 4, 4, 1, 4, 1024 * (70 + 1024), 4)   # ... and 4 copies of x
+    # 64 rows -> 4 per row group; winfo (sized for 16 waves) + row starts (256 x 5 u32) + the accumulator cells of the
+    # fused finalize (8 x 64 u64) end at 74 KiB, then 256 x 4 x 1 KiB of entries
+    good = native.PackedDesc(0x36505141, 6, 64, 512, 4, 4, 1, 4, 1024 * (74 + 1024), 4, 1.5)   # ... 4 copies of x, |codebook| <= 1.5
     back = native.PackedDesc.from_ints(good.as_ints())
     assert bytes(back) == bytes(good)
     rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(good), p, p, p, None, p, p, 9, 512, 64, native.F16, p, 1 << 20, None)

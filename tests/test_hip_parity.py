@@ -369,11 +369,11 @@ def test_raw_c_abi_strided_rows(hk):
     assert (ybuf[:, 128:] == 7.0).all()
 
 
-# ------------------------------------------------------------------ prepacked (slice-bucketed) 1x16 path, format v5
+# ------------------------------------------------------------------ prepacked (slice-bucketed) 1x16 path, format v6
 @pytest.mark.parametrize("entry_bytes", [3, 4])
 @pytest.mark.parametrize("fin,fout", [(512, 96), (4096, 300), (11008, 64), (64, 40), (14336, 80), (1024, 2000)])
 def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
-    """Integer / byte work: the packed buffer (24-bit and 32-bit entries) is held to the numpy model of format v5 --
+    """Integer / byte work: the packed buffer (24-bit and 32-bit entries) is held to the numpy model of format v6 --
     tables and bookkeeping bit for bit, the entries up to the order inside a row and the x copy they name, which are the
     repack's bank-aware choice -- and unpacking it must give the codes back."""
     from aqlm_amd import _native
@@ -391,7 +391,7 @@ def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
     assert packed is not None
     P = pm.pack(cu)
     d = packed.desc
-    assert (d.magic, d.version, d.out_features, d.in_features, d.slices_log2, d.entry_bytes) == (pm.MAGIC, 5, fout, fin, 4, entry_bytes)
+    assert (d.magic, d.version, d.out_features, d.in_features, d.slices_log2, d.entry_bytes) == (pm.MAGIC, 6, fout, fin, 4, entry_bytes)
     assert (d.waves, d.steps) == (P["NW"], P["T"])
     G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), entry_bytes)
     np.testing.assert_array_equal(G["winfo"][:, :, :3], P["winfo"][:, :, :3])
@@ -488,6 +488,83 @@ def test_gemv_1x16_packed(hk, fin, fout, dt, bias, entry_bytes):
 # C restatement of the reference's dequantize_gemm.
 HEADLINE = [(4096, 4096), (4096, 11008), (4096, 14336), (14336, 4096), (4096, 1024), (8192, 28672), (1024, 28672),
             (2048, 28672), (11008, 4096), (8192, 8192), (28672, 8192), (5120, 13824)]
+
+
+@pytest.mark.parametrize("dt", ["float16", "bfloat16"])
+def test_packed_fused_finalize(hk, dt):
+    """The single-kernel form of the prepacked matvec: the 16 slice workgroups of a row add fixed-point slice sums into
+    one 64-bit cell of the packed buffer and the last arrival writes y.  Held to the oracle, to the two-kernel form, to
+    bit-exact repeatability, to "cells are zero at rest", and to inputs at both ends of the storage type's range (the
+    fixed-point scale is derived from max|x| and max|codebook|, so neither overflow nor loss of resolution may occur)."""
+    from aqlm_amd import _native
+    from tests import packed_model as pm
+
+    dtype = tdtype(dt)
+    fin, fout = 4096, 1536
+    L = orc.make_layer(777, fin, fout, 1, 16, 8, batch=8, bias=True, float_dtype=np.float16 if dt == "float16" else "bfloat16")
+    T = to_dev(L, dtype)
+    packed = hk.prepack_1x16(T["codes"])
+    assert packed is not None and packed.desc.codebook_absmax == 0.0
+    lay = pm.layout(fout, fin // 8, int(packed.desc.waves), int(packed.desc.steps), int(packed.desc.entry_bytes))
+    cells = lambda: packed.buf[lay["off_acc"]: lay["off_acc"] + 8 * fout * 8]
+    assert int(cells().max()) == 0 and lay["used"] == packed.buf.numel()
+
+    def run(x):
+        return hk.code1x16_matmat_packed(x, packed, T["codebooks"], T["scales"], T["bias"])
+
+    hk.set_fused_finalize(False)
+    try:
+        y_two = run(T["x"])                       # also records the codebook range in the descriptor
+    finally:
+        hk.set_fused_finalize(True)
+    absmax = float(T["codebooks"].abs().max())
+    assert packed.desc.codebook_absmax == pytest.approx(absmax)
+    y = run(T["x"])
+    assert int(cells().max()) == 0, "the accumulator cells must be back to zero when the kernel has finished"
+    x64 = T["x"].double().cpu().numpy()
+    cb64, sc64, bi64 = (T[k].double().cpu().numpy() for k in ("codebooks", "scales", "bias"))
+    y64 = orc.dequantize_gemm(x64, L["codes"], cb64, sc64, bi64)
+    check_close(y.float().cpu().numpy(), y64, dtype, "fused finalize")
+    check_close(y.float().cpu().numpy(), y_two.double().cpu().numpy(), dtype, "fused vs two-kernel finalize")
+    for b in range(8):                            # a row's result does not depend on its neighbours in the launch
+        assert torch.equal(run(T["x"][b:b + 1])[0], y[b])
+    for _ in range(20):                           # integer adds commute: the arrival order of the workgroups is invisible
+        assert torch.equal(run(T["x"]), y)
+    # magnitudes: the largest finite inputs with tiny scales, and inputs near the bottom of the normal range
+    big = torch.full_like(T["x"], 3.0e4) * torch.sign(T["x"])
+    sc_small = T["scales"] * 1e-4
+    yb = hk.code1x16_matmat_packed(big, packed, T["codebooks"], sc_small, None)
+    yb64 = orc.dequantize_gemm(big.double().cpu().numpy(), L["codes"], cb64, sc_small.double().cpu().numpy(), None)
+    assert np.isfinite(yb64).all() and np.abs(yb64).max() < (6e4 if dt == "float16" else 1e30)
+    check_close(yb.float().cpu().numpy(), yb64, dtype, "fused finalize, |x| = 3e4")
+    small = T["x"] * 2.0 ** -12
+    ys = hk.code1x16_matmat_packed(small, packed, T["codebooks"], T["scales"], None)
+    ys64 = orc.dequantize_gemm(small.double().cpu().numpy(), L["codes"], cb64, sc64, None)
+    check_close(ys.float().cpu().numpy(), ys64, dtype, "fused finalize, |x| ~ 2^-12")
+    assert torch.equal(hk.code1x16_matmat_packed(torch.zeros_like(T["x"][:2]), packed, T["codebooks"], T["scales"], T["bias"]),
+                       T["bias"].expand(2, fout))
+    # non-finite inputs surface as NaN rows of that input row only, and leave clean cells behind
+    xn = T["x"].clone()
+    xn[1, 17] = float("nan")
+    xn[2, 4000] = float("inf")
+    yn = run(xn)
+    assert torch.isnan(yn[1]).all() and not torch.isfinite(yn[2]).any() and torch.equal(yn[0], y[0]) and torch.equal(yn[3:], y[3:])
+    assert int(cells().max()) == 0
+    assert torch.equal(run(T["x"]), y)
+    # a retrained codebook (in-place update): the recorded range is refreshed before the next launch
+    with torch.no_grad():
+        T["codebooks"].mul_(8.0)
+    y8 = run(T["x"])
+    assert packed.desc.codebook_absmax == pytest.approx(8.0 * absmax)
+    y8_64 = orc.dequantize_gemm(x64, L["codes"], 8.0 * cb64, sc64, bi64)
+    check_close(y8.float().cpu().numpy(), y8_64, dtype, "fused finalize after a codebook update")
+    # an unknown range (descriptor says 0) is the two-kernel path, through the raw C ABI as well
+    d0 = _native.PackedDesc.from_ints(packed.desc.as_ints())
+    d0.codebook_absmax = 0.0
+    pk0 = hk.PackedCodes(packed.buf, d0)
+    pk0._range_of = (T["codebooks"].data_ptr(), T["codebooks"]._version)
+    check_close(hk.code1x16_matmat_packed(T["x"], pk0, T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy(), y8_64, dtype,
+                "two-kernel path when the codebook range is unknown")
 
 
 @pytest.mark.raw_prepack
@@ -1211,9 +1288,13 @@ def test_xgmi_fused_finalize_world1(hk):
     finally:
         inf.PREPACK_MIN_CODES = old
     assert m._xgmi is not None and m._xgmi_ok and not m._xgmi.timed_out()
-    for y, b in zip(ys, (1, 4, 2, 1, 3)):
-        ref = hk.code1x16_matmat_packed(T["x"][:b], m._packed, T["codebooks"], T["scales"], T["bias"])
-        assert torch.equal(y, ref), b
+    hk.set_fused_finalize(False)  # the one-shot all-reduce finalizes fp32 slice partials like the two-kernel form: same bits
+    try:
+        for y, b in zip(ys, (1, 4, 2, 1, 3)):
+            ref = hk.code1x16_matmat_packed(T["x"][:b], m._packed, T["codebooks"], T["scales"], T["bias"])
+            assert torch.equal(y, ref), b
+    finally:
+        hk.set_fused_finalize(True)
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
     check_close(ys[1].float().cpu().numpy(), y64, torch.float16, "xgmi world 1")
     # graph capture: the epoch lives in device memory, so replays keep working
@@ -1224,11 +1305,15 @@ def test_xgmi_fused_finalize_world1(hk):
     with torch.cuda.stream(s):
         with torch.cuda.graph(graph, stream=s):
             y_static = m(static_x)
-    for k in range(5):
-        static_x.copy_(T["x"][k % 4:k % 4 + 1])
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(y_static, hk.code1x16_matmat_packed(T["x"][k % 4:k % 4 + 1], m._packed, T["codebooks"], T["scales"], T["bias"]))
+    hk.set_fused_finalize(False)  # reference with the same arithmetic (fp32 slice partials, summed in slice order)
+    try:
+        for k in range(5):
+            static_x.copy_(T["x"][k % 4:k % 4 + 1])
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_static, hk.code1x16_matmat_packed(T["x"][k % 4:k % 4 + 1], m._packed, T["codebooks"], T["scales"], T["bias"]))
+    finally:
+        hk.set_fused_finalize(True)
     assert not m._xgmi.timed_out()
 
 

@@ -4,7 +4,7 @@ set +e
 OUT=gpurun_out/r2d
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 1800 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout 1800 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 python - <<'PY'

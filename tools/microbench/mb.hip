@@ -431,6 +431,7 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     for (auto& L : v) {
       CK(hipMalloc(&L.packed, pb));
       if (int rc = aqlm_hip_prepack_1x16(L.codes, out, in, s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+      L.desc.codebook_absmax = 1.0f;  // fill_half draws from [-1, 1): the fused finalize may rely on it
     }
     CK(hipDeviceSynchronize());
     printf("# packed %d->%d: waves %d steps %d entry bytes %d x copies %d, %.3f B per code (capacity %.1f MB, used %.1f MB)\n", in, out,
@@ -484,8 +485,7 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=8", "gemv_rows_per_wave", 8}});
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
     } else if (c.s.packed && !quick) {
-      variants.push_back({{"fused finalize", "packed_fused_finalize", 1}});
-      variants.push_back({{"fused finalize (again)", "packed_fused_finalize", 1}});
+      variants.push_back({{"two-kernel finalize", "packed_fused_finalize", 0}});
       variants.push_back({{"waves=4", "packed_waves", 4}});
       variants.push_back({{"waves=8", "packed_waves", 8}});
       variants.push_back({{"waves=16", "packed_waves", 16}});
@@ -529,8 +529,10 @@ static void bench_gemv(int argc, char** argv) {
       if (c.s.packed && !var.empty() && !strcmp(var[0].key, "packed_fused_finalize")) check_packed(c.s, layers[0], c.in, c.out);
       if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange") || !strcmp(var[0].key, "packed_entry_bytes") || !strcmp(var[0].key, "packed_xcopies"))) {  // a format parameter: repack
         const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
-        for (auto& L : layers)
+        for (auto& L : layers) {
           if (int rc = aqlm_hip_prepack_1x16(L.codes, c.out, c.in, c.s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+          L.desc.codebook_absmax = 1.0f;
+        }
         one[0] = layers[0];
         for (auto& w : warm) w = layers[0];
         printf("# repacked: waves %d steps %d entry bytes %d x copies %d, %.3f B per code\n", layers[0].desc.waves, layers[0].desc.steps,
@@ -545,7 +547,7 @@ static void bench_gemv(int argc, char** argv) {
                ab / cold * 1e-3 / 80.0);
         fflush(stdout);
       }
-      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange")) ? 1 : 0);
+      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange") || !strcmp(kv.key, "packed_fused_finalize")) ? 1 : 0);
     }
     free_layers(layers);
   }
