@@ -20,11 +20,11 @@ from .utils import get_int_dtype
 GEMV_MAX_ROWS = 6
 
 # 1x16 g8 matvecs (<= GEMV_MAX_ROWS rows) of layers with at least this many codes (out_features * in_features / 8) run on
-# slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): several times faster than the direct L2-gather kernel
-# on MI355X, at the price of a one-off repack at first use and ~2.1x the code bytes (kept next to the original codes
-# unless `drop_canonical_codes()` is called).  0 disables.  Below the threshold the direct kernel's single launch wins
-# (the packed path is two dependent launches).
-PREPACK_MIN_CODES = 1_000_000
+# slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): 1.2-5x faster than the direct L2-gather kernel on
+# MI355X, at the price of a one-off repack at first use and ~2.3x the code bytes (kept next to the original codes unless
+# `drop_canonical_codes()` is called).  0 disables.  Measured cross-over (cold, single launch each): 4096->1024 (0.5 M
+# codes) 4.6 us packed vs 5.3 us direct; below that the fixed cost of the 64 KiB LDS fill per CU dominates.
+PREPACK_MIN_CODES = 500_000
 
 
 class QuantizedLinear(nn.Module):

@@ -438,7 +438,7 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
 
 
 # Transparent prepack for the RAW op.  `aqlm::code1x16_matmat` is stateless in the reference (cuda_kernel.cpp:148-182); here
-# the fast kernel needs the slice-bucketed layout of the codes (3-5x faster on layers of >= 1 M codes).  `QuantizedLinear`
+# the fast kernel needs the slice-bucketed layout of the codes (1.2-5x faster on layers of >= 0.5 M codes).  `QuantizedLinear`
 # keeps that derived buffer itself; callers of the raw op -- the reference's own benchmark/matmul_benchmark.py:103, vLLM-style
 # integrations -- get it from this cache: keyed by the identity of the `codes` tensor object (a weak reference drops the
 # entry when the tensor dies, so an address reused by a new tensor can never alias it), validated on every hit against
@@ -446,7 +446,7 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
 # RAW_OP_PREPACK_MAX_MISSES packs without a single hit the cache switches itself off.  Nothing is packed while a hipGraph is
 # being captured (the pack synchronises); outputs equal the direct kernel's up to fp32 summation order.
 RAW_OP_PREPACK = True                 # set False to keep the raw op on the direct kernel
-RAW_OP_PREPACK_MIN_CODES = 1_000_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
+RAW_OP_PREPACK_MIN_CODES = 500_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
 RAW_OP_PREPACK_MAX_BYTES = 16 << 30
 RAW_OP_PREPACK_MAX_MISSES = 8
 _RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None)

@@ -36,7 +36,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # 1x16 g8 layers with at least this many codes run the prepacked (slice-bucketed) decode kernel, like
 # aqlm_amd.inference.PREPACK_MIN_CODES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
-PACK_MIN_OUT = 1_000_000
+PACK_MIN_OUT = 500_000
 
 
 def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
@@ -525,7 +525,7 @@ def main():
         "config": {"workload": "decode step = 32 blocks x {4096->4096, 4096->11008} 1x16g8 matvec, bs=1, 64 distinct "
                                "layers (own codes + codebook), 564 MB algorithmic bytes/step, hipGraph replay",
                    "scheme": "1x16g8", "batch": 1, "layers_per_step": step.n, "algorithmic_bytes_per_step": step.bytes,
-                   "kernels": ("prepacked slice-bucketed gemv (layers of >= 1 M codes: both shapes); the direct L2-gather gemv "
+                   "kernels": ("prepacked slice-bucketed gemv (layers of >= 0.5 M codes: both shapes); the direct L2-gather gemv "
                                "serves smaller layers and --no-packed" if PACK_MIN_OUT else "direct L2-gather gemv"),
                    "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
         "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
