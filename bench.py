@@ -509,11 +509,11 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": ("aqlm::gemv_1x16_packed_kernel<F16,1,3,65520,4> (+ gemv_1x16_packed_finalize; prepacked codes, both shapes)"
+                "kernel": ("aqlm::gemv_1x16_packed_kernel<F16,1,3,65520,4> (prepacked codes, finalize inside the kernel; both shapes)"
                            if PACK_MIN_OUT else "aqlm::gemv_kernel<F16,1x16,g8,NB=1>"),
                 "avg_launch_us": avg_launch_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "launches_timed": launches,
-                "note": "one launch = one matvec (packed path: main + finalize kernel); duration = HIP-event time of the "
+                "note": "one launch = one matvec = one kernel (packed path, fused finalize); duration = HIP-event time of the "
                         "timed region / matvecs; achieved uses ALGORITHMIC bytes (2 B per code) even where the prepacked "
                         "path really reads ~4.5 B per code (32-bit entries + padding); rocprofv3 per-kernel durations are in profiles/"}
 
