@@ -383,7 +383,7 @@ def sharded_70b(lib, dev, rank, world, steps):
             flag = torch.tensor([1 if can else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag):
-                ar = OneShotAllReduce(fout, dev)
+                ar = OneShotAllReduce(fout, dev, spin_limit=1 << 19)  # ~0.25 s per wait at most: a lost peer must not stall the bench
                 sc = layers[0].scales
 
                 def fused(l):
@@ -394,7 +394,13 @@ def sharded_70b(lib, dev, rank, world, steps):
                         _native.check(rc)
                     ar.finalize(l.ws, sc, None, l.y, fout, 1, _native.F16, s.cuda_stream)
 
-                for _ in range(5):
+                fused(layers[0])
+                torch.cuda.synchronize()
+                bad = torch.tensor([1 if ar.timed_out() else 0], device=dev)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if int(bad):  # every rank leaves together (the collectives below must stay matched)
+                    raise RuntimeError("one-shot all-reduce: a peer's flag never arrived (IPC mapping over xGMI not working here)")
+                for _ in range(4):
                     fused(layers[0])
                 torch.cuda.synchronize()
                 y_native = layers[0].y.float().clone()
