@@ -1,4 +1,4 @@
-// 1x16 g8 matvec (1..8 input rows) on slice-bucketed ("prepacked") codes, gfx950.  Packed format v5.
+// 1x16 g8 matvec (1..8 input rows) on slice-bucketed ("prepacked") codes, gfx950.  Packed format v6.
 //
 // Why a load-time repack: on MI355X a random 16-B codebook gather that hits L2 costs a whole 128-B line of the CU's
 // L1-fill path (0.43 lane-gathers/clk/CU measured, profiles/r01_call1_mb_l2gather.log), which pins the direct kernel
@@ -7,7 +7,7 @@
 // Bucketing the codes by slice ONCE, when the layer is loaded, removes that search.  (The reference also re-lays codes
 // out at load time for its CPU kernel, inference.py:78-83.)
 //
-// Format v5 (built by aqlm_hip_prepack_1x16; specification + simulation: tests/packed_model.py):
+// Format v6 (built by aqlm_hip_prepack_1x16; specification + simulation: tests/packed_model.py):
 //   rows -> NG = 16 row-groups of RG rows; codes -> S = 16 slices by (code >> 12); workgroup (g, s) owns stream (g, s).
 //   In a stream every row's codes of the slice are rounded up to whole LANE-STEPS of 4 entries (>= 1; null entries pad)
 //   and the lane-steps of rows 0, 1, 2, ... are laid end to end.  The sequence is cut into NW wave ranges of 64*T
@@ -34,8 +34,12 @@
 // lane-step that ends a row it STORES the sum to rowval[row] (exactly one lane-step per row does: unique writer, no
 // atomics), at the end of its column it stores what it gathered after its last row end to colend[column].  Epilogue:
 // row r = rowval[r] + the colend of the columns the row crosses before its last one, in column order (from the
-// row-start table) -> the summation order is fixed.  fp32 partials [slice][batch][row] -> workspace -> finalize kernel
-// (adds the 16 slices, scale + bias, one rounding).  Per entry: 2 v_and_sdwa + 2 ds_read_b128 + 4 v_dot2c (x B for B
+// row-start table) -> the summation order inside a workgroup is fixed.  The 16 slice sums of a row then meet in one 64-bit
+// cell of the packed buffer: fixed-point integers added with ONE returning atomic each (order-independent, hence
+// deterministic); the workgroup that finds 15 earlier arrivals applies scale + bias, rounds once, writes y and zeroes
+// the cell.  The fixed-point unit comes from max|x| (taken from the x image in LDS) and the layer's codebook range
+// (descriptor): no overflow whatever the data.  Without a codebook range the kernel leaves fp32 partials
+// [slice][batch][row] in a workspace and a second kernel finalizes.  Per entry: 2 v_and_sdwa + 2 ds_read_b128 + 4 v_dot2c (x B for B
 // input rows: one codebook read, B x reads).  The kernels take their leading parameters as scalar arguments: the
 // command processor preloads them into SGPRs (-amdgpu-kernarg-preload-count), so no kernel-argument fetch precedes the
 // first load.
