@@ -1278,7 +1278,7 @@ extern "C" int aqlm_hip_packed_desc_read(const void* header_host, size_t header_
   memcpy(&d, header_host, sizeof(d));
   PackedLayout L;
   if (!desc_layout(&d, L)) {
-    set_last_error("aqlm_hip_packed_desc_read: not a packed 1x16 buffer of format v5");
+    set_last_error("aqlm_hip_packed_desc_read: not a packed 1x16 buffer of format v6");
     return AQLM_HIP_E_INVALID;
   }
   *desc = d;

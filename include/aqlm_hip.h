@@ -164,7 +164,8 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
 
 /*
  * Load-time repack of 1x16 g8 codes into the slice-bucketed format v6 consumed by aqlm_hip_gemv_1x16_packed (layout:
- * aqlm_amd/csrc/gemv_packed.hip, specification tests/packed_model.py; 4 bytes per code + ~6 bytes per (row, slice)).
+ * aqlm_amd/csrc/gemv_packed.hip, specification tests/packed_model.py; 4 bytes per code + ~6 bytes per (row, slice),
+ * plus 64 bytes per output row of zero-at-rest accumulator cells for the fused finalize).
  * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
  * (inference.py:78-83).
  *   aqlm_hip_prepack_1x16_bytes  capacity the caller must provide (0: shape not covered -- in_group_size != 8 or
