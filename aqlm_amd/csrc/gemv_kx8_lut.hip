@@ -41,7 +41,21 @@ struct LutParams {
   const uint16_t* x;
   float* partial;            // [nslabs][M]
   int M, in_groups, nslabs, nranges, rows_per_range;
+  // fused finalize (cells != nullptr): the slab sums of a row meet in one zero-at-rest 64-bit cell, see the body
+  unsigned long long* cells;  // [M]
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
 };
+
+// magnitude pattern (bits & 0x7fff of every half) maximum of four dwords, folded into `m` (v_pk_max_u16)
+typedef unsigned short lut_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lut_absmax(lut_us2& m, const u32x4& v) {
+  m = __builtin_elementwise_max(m, __builtin_bit_cast(lut_us2, v.x & 0x7fff7fffu));
+  m = __builtin_elementwise_max(m, __builtin_bit_cast(lut_us2, v.y & 0x7fff7fffu));
+  m = __builtin_elementwise_max(m, __builtin_bit_cast(lut_us2, v.z & 0x7fff7fffu));
+  m = __builtin_elementwise_max(m, __builtin_bit_cast(lut_us2, v.w & 0x7fff7fffu));
+}
 
 // `block` = the workgroup's index within its own layer (== blockIdx.x for a single-layer launch)
 template <class T, int G>
@@ -94,12 +108,66 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
       const int cv0 = (wave * 8 + t) * 16 + kg * 4;
       *reinterpret_cast<f32x4*>(lut + col * (LUT_KC * 256) + cv0) = d;
     }
+    if (p.cells != nullptr) {
+      // Fused finalize needs a bound of the slab sums that every workgroup of the layer computes identically:
+      // max|codebook| -- the 16 waves' A fragments are the whole codebook -- and max|x| over ALL input groups (an extra
+      // read of x, a few KiB).  15-bit magnitude patterns (integer order == magnitude order; NaN sorts above Inf).
+      lut_us2 mc = {0, 0}, mx = {0, 0};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) lut_absmax(mc, afrag[t]);
+      const int chunks = p.in_groups * (G / 8);  // 16-B pieces of x
+      for (int i = tid; i < chunks; i += 1024) lut_absmax(mx, reinterpret_cast<const u32x4*>(p.x)[i]);
+      const uint32_t wc = wave_max_u32(mc.x > mc.y ? (uint32_t)mc.x : (uint32_t)mc.y);
+      const uint32_t wx = wave_max_u32(mx.x > mx.y ? (uint32_t)mx.x : (uint32_t)mx.y);
+      if (lane == 0) {
+        uint32_t* slots = reinterpret_cast<uint32_t*>(smem_raw + (size_t)LUT_ENTRIES * 4);  // [16 waves] codebook, [16 waves] x
+        slots[wave] = wc;
+        slots[16 + wave] = wx;
+      }
+    }
   }
   __syncthreads();
+  // fixed-point unit of the fused finalize: |slab sum| <= 16 groups x 8 codebooks x g x max|cb| x max|x| < 2^e; with
+  // sh = 41 - e - ceil(log2(nslabs)) the nslabs addends of a row stay below 2^42 (the sum field is bits 63..20)
+  int sh = 0;
+  float bound = 0.f;
+  if (p.cells != nullptr) {
+    const uint32_t* slots = reinterpret_cast<const uint32_t*>(smem_raw + (size_t)LUT_ENTRIES * 4);
+    uint32_t cm = 0u, xm = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      cm = slots[w] > cm ? slots[w] : cm;
+      xm = slots[16 + w] > xm ? slots[16 + w] : xm;
+    }
+    bound = (float)(LUT_JS * LUT_KC * G) * T::to_float((uint16_t)cm) * T::to_float((uint16_t)xm);
+    int e = 0;
+    (void)frexpf(bound, &e);
+    sh = 41 - e - (32 - __builtin_clz((unsigned)(p.nslabs > 1 ? p.nslabs - 1 : 1)));
+  }
 
   // ---- rows: lane = input group j0 + l16 (8 code bytes), quarter-wave = one row
   const float* const my = lut + l16 * (LUT_KC * 256);
   float* const out = p.partial + (size_t)slab * p.M + row_begin;
+  // Fused finalize: lane 0 of a quarter-wave adds the row's slab sum to the row's cell as a fixed-point integer (bits
+  // 63..20; +1 in the arrival counter, bits 9..0; +1 in bits 19..10 if the value is not finite) with ONE returning
+  // atomic -- integer adds commute, so the total is independent of the arrival order -- and whoever finds
+  // nslabs - 1 earlier arrivals applies scale and bias, rounds once, writes y and zeroes the cell.  The returned values
+  // of a round are looked at one round later, so the atomics' round trip hides behind the next rows' table reads.
+  unsigned long long pend_old[4], pend_mine[4];
+  int pend_row[4] = {-1, -1, -1, -1};
+  auto settle = [&](int k) {
+    if (pend_row[k] >= 0 && (pend_old[k] & 1023ull) == (unsigned long long)(p.nslabs - 1)) {
+      const int row = pend_row[k];
+      const unsigned long long cell = pend_old[k] + pend_mine[k];
+      float sv = (float)ldexp((double)((long long)cell >> 20), -sh);
+      if ((cell >> 10) & 1023ull) sv = __builtin_nanf("");
+      const float scale = T::to_float(p.scales[row]);
+      const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+      p.y[row] = T::from_float(__builtin_fmaf(sv, scale, bias));
+      __hip_atomic_store(p.cells + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pend_row[k] = -1;
+  };
   for (int rbase = r0; __any(rbase < nrows); rbase += 256) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -118,17 +186,39 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
         acc += my[7 * 256 + (cw.y >> 24)];
       }
       acc = row16_sum(acc);
-      if (l16 == 0 && r < nrows) out[r] = acc;
+      if (p.cells == nullptr) {
+        if (l16 == 0 && r < nrows) out[r] = acc;
+      } else {
+        settle(k);  // the previous round's atomic of this slot
+        if (l16 == 0 && r < nrows) {
+          const bool finite = bound < __builtin_inff() && fabsf(acc) <= 2.f * bound;  // false for NaN / Inf anywhere
+          const long long q = finite ? __float2ll_rn(ldexpf(acc, sh)) : 0ll;
+          pend_mine[k] = ((unsigned long long)q << 20) + (finite ? 1ull : 1025ull);
+          pend_row[k] = row_begin + r;
+          pend_old[k] = __hip_atomic_fetch_add(p.cells + pend_row[k], pend_mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
+  }
+  if (p.cells != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) settle(k);
   }
 }
 
 // scalar arguments (13 dwords): preloaded into SGPRs at wave launch, no kernel-argument fetch at the head of the kernel
+struct LutTail {  // what only the fused finalize needs (not preloaded: used at the end of the kernel)
+  unsigned long long* cells;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
+};
+
 template <class T, int G>
 __global__ __launch_bounds__(1024) void gemv_8x8_lut_kernel(const uint8_t* codes, const uint16_t* codebooks, const uint16_t* x,
                                                             float* partial, int M, int in_groups, int nslabs, int nranges,
-                                                            int rows_per_range) {
-  const LutParams p{codes, codebooks, x, partial, M, in_groups, nslabs, nranges, rows_per_range};
+                                                            int rows_per_range, const LutTail tail) {
+  const LutParams p{codes, codebooks, x, partial, M, in_groups, nslabs, nranges, rows_per_range, tail.cells, tail.scales, tail.bias, tail.y};
   gemv_8x8_lut_body<T, G>(p, blockIdx.x);
 }
 
@@ -138,6 +228,10 @@ struct LutSegment {
   const uint16_t* codebooks;
   float* partial;
   int M, nranges, rows_per_range, block_begin;
+  unsigned long long* cells;  // fused finalize (nullptr: partials + finalize kernel)
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* y;
 };
 
 struct LutMultiParams {
@@ -162,6 +256,10 @@ __global__ __launch_bounds__(1024) void gemv_8x8_lut_multi_kernel(const LutMulti
       p.M = mp.seg[k].M;
       p.nranges = mp.seg[k].nranges;
       p.rows_per_range = mp.seg[k].rows_per_range;
+      p.cells = mp.seg[k].cells;
+      p.scales = mp.seg[k].scales;
+      p.bias = mp.seg[k].bias;
+      p.y = mp.seg[k].y;
       begin = mp.seg[k].block_begin;
     }
   }
@@ -228,17 +326,19 @@ size_t gemv_8x8_lut_workspace(int out_features, int in_features, int in_group_si
 template <class T, int G>
 static int launch_lut(const LutParams& p, hipStream_t stream) {
   auto kern = gemv_8x8_lut_kernel<T, G>;
-  const size_t lds = (size_t)LUT_ENTRIES * 4;
+  const size_t lds = (size_t)LUT_ENTRIES * 4 + 128;  // + the 32 maximum slots of the fused finalize
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+  const LutTail tail{p.cells, p.scales, p.bias, p.y};
   hipLaunchKernelGGL(kern, dim3(p.nslabs * p.nranges), dim3(1024), lds, stream, p.codes, p.codebooks, p.x, p.partial, p.M,
-                     p.in_groups, p.nslabs, p.nranges, p.rows_per_range);
+                     p.in_groups, p.nslabs, p.nranges, p.rows_per_range, tail);
   return check_hip(hipGetLastError(), "gemv_8x8_lut launch");
 }
 
 // batch-1 8x8 matvec through LDS look-up tables; AQLM_HIP_E_UNSUPPORTED when the shape does not fit
+// `fused`: workspace = out_features zero-at-rest 64-bit cells (one kernel); else fp32 slab partials + a finalize kernel
 int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x, void* y,
                  int out_features, int in_features, int in_group_size, int dtype, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream) {
+                 hipStream_t stream, bool fused) {
   const int G = in_group_size;
   if (G != 8 && G != 16 && G != 32) return AQLM_HIP_E_UNSUPPORTED;
   LutParams p{};
@@ -249,7 +349,16 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
   p.M = out_features;
   p.in_groups = in_features / G;
   p.nslabs = (p.in_groups + LUT_JS - 1) / LUT_JS;
-  if (workspace_bytes < (size_t)p.nslabs * out_features * sizeof(float) || !workspace) return AQLM_HIP_E_INVALID;
+  if (p.nslabs > 1023) return AQLM_HIP_E_UNSUPPORTED;  // (arrival counter of the fused finalize: 10 bits)
+  if (fused) {
+    if (!workspace || workspace_bytes < (size_t)out_features * 8 || ((uintptr_t)workspace & 7)) return AQLM_HIP_E_INVALID;
+    p.cells = (unsigned long long*)workspace;
+    p.scales = (const uint16_t*)scales;
+    p.bias = (const uint16_t*)bias;
+    p.y = (uint16_t*)y;
+  } else if (workspace_bytes < (size_t)p.nslabs * out_features * sizeof(float) || !workspace) {
+    return AQLM_HIP_E_INVALID;
+  }
   p.nranges = std::max(1, 256 / p.nslabs);
   p.rows_per_range = (out_features + p.nranges - 1) / p.nranges;
   int e;
@@ -257,7 +366,7 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
     e = G == 8 ? launch_lut<F16, 8>(p, stream) : G == 16 ? launch_lut<F16, 16>(p, stream) : launch_lut<F16, 32>(p, stream);
   else
     e = G == 8 ? launch_lut<BF16, 8>(p, stream) : G == 16 ? launch_lut<BF16, 16>(p, stream) : launch_lut<BF16, 32>(p, stream);
-  if (e) return e;
+  if (e || fused) return e;
   LutFinalizeParams f{};
   f.partial = (const float*)workspace;
   f.scales = (const uint16_t*)scales;
@@ -277,7 +386,7 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
 template <class T, int G>
 static int launch_lut_multi(const LutMultiParams& mp, int blocks, hipStream_t stream) {
   auto kern = gemv_8x8_lut_multi_kernel<T, G>;
-  const size_t lds = (size_t)LUT_ENTRIES * 4;
+  const size_t lds = (size_t)LUT_ENTRIES * 4 + 128;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, mp);
   return check_hip(hipGetLastError(), "gemv_8x8_lut_multi launch");
@@ -288,7 +397,7 @@ static int launch_lut_multi(const LutMultiParams& mp, int blocks, hipStream_t st
 // per-row summation order -- only the slab partials are the same, so in fact results ARE identical: a row's value does
 // not depend on its range).  workspace: sum over segments of gemv_8x8_lut_workspace(...).
 int gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
-                       int in_group_size, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                       int in_group_size, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream, bool fused) {
   const int G = in_group_size;
   if (G != 8 && G != 16 && G != 32) return AQLM_HIP_E_UNSUPPORTED;
   LutMultiParams mp{};
@@ -308,6 +417,12 @@ int gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const
     ls.codes = (const uint8_t*)sg.codes;
     ls.codebooks = (const uint16_t*)sg.codebook;
     ls.partial = (float*)((uint8_t*)workspace + need);
+    if (fused) {  // the segment's cells, in segment order
+      ls.cells = (unsigned long long*)((uint8_t*)workspace + need);
+      ls.scales = (const uint16_t*)sg.scales;
+      ls.bias = (const uint16_t*)sg.bias;
+      ls.y = (uint16_t*)sg.y;
+    }
     ls.M = sg.out_features;
     ls.nranges = std::max(1, (int)(((long)total_ranges * sg.out_features + total / 2) / total));
     ls.rows_per_range = (sg.out_features + ls.nranges - 1) / ls.nranges;
@@ -323,9 +438,9 @@ int gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const
     fs.f.nslabs = mp.nslabs;
     fs.block_begin = fblocks;
     fblocks += (sg.out_features + 255) / 256;
-    need += (size_t)mp.nslabs * sg.out_features * sizeof(float);
+    need += fused ? (size_t)sg.out_features * 8 : (size_t)mp.nslabs * sg.out_features * sizeof(float);
   }
-  if (!workspace || workspace_bytes < need) return AQLM_HIP_E_INVALID;
+  if (!workspace || workspace_bytes < need || mp.nslabs > 1023 || (fused && ((uintptr_t)workspace & 7))) return AQLM_HIP_E_INVALID;
   int e;
   if (dtype == AQLM_HIP_F16)
     e = G == 8 ? launch_lut_multi<F16, 8>(mp, blocks, stream) : G == 16 ? launch_lut_multi<F16, 16>(mp, blocks, stream)
@@ -333,7 +448,7 @@ int gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const
   else
     e = G == 8 ? launch_lut_multi<BF16, 8>(mp, blocks, stream) : G == 16 ? launch_lut_multi<BF16, 16>(mp, blocks, stream)
                                                                           : launch_lut_multi<BF16, 32>(mp, blocks, stream);
-  if (e) return e;
+  if (e || fused) return e;
   if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(gemv_8x8_lut_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);
   else hipLaunchKernelGGL(gemv_8x8_lut_finalize_multi<BF16>, dim3(fblocks), dim3(256), 0, stream, fm);
   return check_hip(hipGetLastError(), "gemv_8x8_lut_finalize_multi launch");
@@ -343,9 +458,8 @@ int gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const
 
 using namespace aqlm;
 
-extern "C" int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
-                                           int in_features, int in_group_size, int dtype, void* workspace,
-                                           size_t workspace_bytes, void* stream) {
+static int lut_multi_entry(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features, int in_group_size,
+                           int dtype, void* workspace, size_t workspace_bytes, void* stream, bool fused) {
   if (!segments || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS || !x) {
     set_last_error("aqlm_hip_gemv_8x8_lut_multi: 1..%d segments and a non-null x required (got %d)", AQLM_HIP_MAX_SEGMENTS,
                    num_segments);
@@ -375,15 +489,27 @@ extern "C" int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int
     return AQLM_HIP_E_UNSUPPORTED;
   }
   const int e = gemv_8x8_lut_multi(segments, num_segments, x, in_features, in_group_size, dtype, workspace, workspace_bytes,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, fused);
   if (e == AQLM_HIP_E_UNSUPPORTED) set_last_error("aqlm_hip_gemv_8x8_lut_multi: in_group_size %d not in {8,16,32}", in_group_size);
   if (e == AQLM_HIP_E_INVALID) set_last_error("aqlm_hip_gemv_8x8_lut_multi: workspace too small (sum of aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_8X8_LUT, ...) over the segments)");
   return e;
 }
 
-extern "C" int aqlm_hip_gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias,
-                                     const void* x, void* y, int out_features, int in_features, int in_group_size,
-                                     int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                           int in_features, int in_group_size, int dtype, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  return lut_multi_entry(segments, num_segments, x, in_features, in_group_size, dtype, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int aqlm_hip_gemv_8x8_lut_multi_fused(const aqlm_hip_segment* segments, int num_segments, const void* x,
+                                                 int in_features, int in_group_size, int dtype, void* cells,
+                                                 size_t cells_bytes, void* stream) {
+  return lut_multi_entry(segments, num_segments, x, in_features, in_group_size, dtype, cells, cells_bytes, stream, true);
+}
+
+static int lut_entry(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x, void* y,
+                     int out_features, int in_features, int in_group_size, int dtype, void* workspace, size_t workspace_bytes,
+                     void* stream, bool fused) {
   if (!codes || !codebooks || !scales || !x || !y) {
     set_last_error("aqlm_hip_gemv_8x8_lut: null pointer argument");
     return AQLM_HIP_E_INVALID;
@@ -401,8 +527,22 @@ extern "C" int aqlm_hip_gemv_8x8_lut(const void* codes, const void* codebooks, c
     return AQLM_HIP_E_UNSUPPORTED;
   }
   const int e = gemv_8x8_lut(codes, codebooks, scales, bias, x, y, out_features, in_features, in_group_size, dtype,
-                             workspace, workspace_bytes, (hipStream_t)stream);
+                             workspace, workspace_bytes, (hipStream_t)stream, fused);
   if (e == AQLM_HIP_E_UNSUPPORTED) set_last_error("aqlm_hip_gemv_8x8_lut: in_group_size %d not in {8,16,32}", in_group_size);
-  if (e == AQLM_HIP_E_INVALID) set_last_error("aqlm_hip_gemv_8x8_lut: workspace too small or null");
+  if (e == AQLM_HIP_E_INVALID) set_last_error("aqlm_hip_gemv_8x8_lut: workspace / cells too small, null or misaligned");
   return e;
+}
+
+extern "C" int aqlm_hip_gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias,
+                                     const void* x, void* y, int out_features, int in_features, int in_group_size,
+                                     int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  return lut_entry(codes, codebooks, scales, bias, x, y, out_features, in_features, in_group_size, dtype, workspace,
+                   workspace_bytes, stream, false);
+}
+
+extern "C" int aqlm_hip_gemv_8x8_lut_fused(const void* codes, const void* codebooks, const void* scales, const void* bias,
+                                           const void* x, void* y, int out_features, int in_features, int in_group_size,
+                                           int dtype, void* cells, size_t cells_bytes, void* stream) {
+  return lut_entry(codes, codebooks, scales, bias, x, y, out_features, in_features, in_group_size, dtype, cells, cells_bytes,
+                   stream, true);
 }

@@ -344,6 +344,27 @@ def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
     return _gemv_multi(input, codes, codebooks, scales, bias, "1x16")
 
 
+# Zero-at-rest accumulator cells of the single-kernel look-up-table matvec (aqlm_hip_gemv_8x8_lut_fused): one persistent
+# int64 buffer per (device, stream) -- launches on one stream are ordered, so consecutive layers can share it; every launch
+# leaves it zero.  Never allocated while a hipGraph is being captured (a captured torch.zeros would replay a memset per
+# call): a capture whose stream has not run the op before takes the two-kernel form.
+USE_8X8_LUT_FUSED = True
+_LUT_CELLS = {}
+
+
+def _lut_cells(device: torch.device, stream: int, rows: int) -> Optional[torch.Tensor]:
+    if not USE_8X8_LUT_FUSED:
+        return None
+    key = (device.index, stream)
+    cells = _LUT_CELLS.get(key)
+    if cells is None or cells.numel() < rows:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        cells = torch.zeros((max(rows, 1 << 16),), dtype=torch.int64, device=device)
+        _LUT_CELLS[key] = cells
+    return cells
+
+
 def _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias):
     """Several 8-codebook layers times one single input row through per-token look-up tables in ONE launch
     (aqlm_hip_gemv_8x8_lut_multi); bit-identical to _gemv_8x8_lut per layer."""
@@ -369,6 +390,15 @@ def _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias):
         segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = c.data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), out_features, out_features
         ws_bytes += _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
+    stream = _stream_ptr(input.device)
+    cells = _lut_cells(input.device, stream, sum(y.shape[1] for y in outs))
+    if cells is not None:
+        with _device_guard(input.device):
+            rc = _lib.aqlm_hip_gemv_8x8_lut_multi_fused(segs, n, x.data_ptr(), in_features, g, dt, cells.data_ptr(),
+                                                        cells.numel() * 8, stream)
+        if rc:
+            _native.check(rc, "aqlm gemv_8x8_lut_multi_fused")
+        return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
     ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
     with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemv_8x8_lut_multi(segs, n, x.data_ptr(), in_features, g, dt, ws.data_ptr(), ws_bytes,
@@ -548,12 +578,22 @@ def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
     if bias is not None:
         bias = _c(bias)
     y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
+    stream = _stream_ptr(input.device)
+    cells = _lut_cells(input.device, stream, out_features)
+    if cells is not None:  # one kernel
+        with _device_guard(input.device):
+            rc = _lib.aqlm_hip_gemv_8x8_lut_fused(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
+                                                  x.data_ptr(), y.data_ptr(), out_features, in_features, g, dt,
+                                                  cells.data_ptr(), cells.numel() * 8, stream)
+        if rc:
+            _native.check(rc, "aqlm gemv_8x8_lut_fused")
+        return y.reshape(input.shape[:-1] + (out_features,))
     ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
     ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
     with _device_guard(input.device):
         rc = _lib.aqlm_hip_gemv_8x8_lut(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias),
                                         x.data_ptr(), y.data_ptr(), out_features, in_features, g, dt, ws.data_ptr(),
-                                        ws_bytes, _stream_ptr(input.device))
+                                        ws_bytes, stream)
     if rc:
         _native.check(rc, "aqlm gemv_8x8_lut")
     return y.reshape(input.shape[:-1] + (out_features,))

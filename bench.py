@@ -90,12 +90,11 @@ class Layer:
                                                self.y.data_ptr(), batch, self.fin, self.fout, _native.F16,
                                                self.ws.data_ptr(), self.ws.numel() * 4, stream)
         elif batch == 1 and self.K == 8 and self.nbits == 8:
-            if getattr(self, "lut_ws", None) is None:
-                n = lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, self.g, self.fout, self.fin)
-                self.lut_ws = torch.empty((n // 4,), dtype=torch.float32, device=self.codes.device)
-            rc = lib.aqlm_hip_gemv_8x8_lut(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
-                                           self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, _native.F16,
-                                           self.lut_ws.data_ptr(), self.lut_ws.numel() * 4, stream)
+            if getattr(self, "lut_cells", None) is None:  # zero-at-rest accumulator cells of the single-kernel form
+                self.lut_cells = torch.zeros((self.fout,), dtype=torch.int64, device=self.codes.device)
+            rc = lib.aqlm_hip_gemv_8x8_lut_fused(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
+                                                 self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, _native.F16,
+                                                 self.lut_cells.data_ptr(), self.lut_cells.numel() * 8, stream)
         elif self.nbits == 16:
             rc = lib.aqlm_hip_gemv_1x16(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                         self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, batch,
@@ -143,11 +142,10 @@ class FusedLayers:
 
         if self.members[0].nbits == 8 and self.members[0].K == 8 and batch == 1:
             m0 = self.members[0]
-            if getattr(self, "lut_ws", None) is None:
-                n = sum(lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, m.g, m.fout, m.fin) for m in self.members)
-                self.lut_ws = torch.empty((n // 4,), dtype=torch.float32, device=self.x.device)
-            rc = lib.aqlm_hip_gemv_8x8_lut_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g, _native.F16,
-                                                 self.lut_ws.data_ptr(), self.lut_ws.numel() * 4, stream)
+            if getattr(self, "lut_cells", None) is None:  # zero-at-rest accumulator cells of the single-kernel form
+                self.lut_cells = torch.zeros((sum(m.fout for m in self.members),), dtype=torch.int64, device=self.x.device)
+            rc = lib.aqlm_hip_gemv_8x8_lut_multi_fused(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g,
+                                                       _native.F16, self.lut_cells.data_ptr(), self.lut_cells.numel() * 8, stream)
         elif self.members[0].nbits == 8:
             m0 = self.members[0]
             rc = lib.aqlm_hip_gemv_kx8_multi(self.segs, len(self.members), self.x.data_ptr(), self.fin, m0.K, self.g, batch,

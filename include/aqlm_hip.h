@@ -279,6 +279,22 @@ int aqlm_hip_gemv_8x8_lut(const void* codes_i8, const void* codebooks, const voi
 int aqlm_hip_gemv_8x8_lut_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
                                 int in_group_size, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The same two operations in ONE kernel each (no finalize launch): the slab sums of an output row are added as fixed-point
+ * integers into one 64-bit cell (one returning atomic per slab and row; integer adds commute, so the result does not
+ * depend on the arrival order: deterministic), and the workgroup that finds all other slabs arrived applies scale and
+ * bias, rounds once, writes y and puts the cell back to zero.  The fixed-point unit is derived inside the kernel from
+ * max|codebook| and max|x| (both read by every workgroup): no overflow whatever the data; non-finite inputs give NaN.
+ * `cells`: out_features (multi: the sum over the segments, in segment order) x 8 bytes, 8-B aligned, ZERO-FILLED by the
+ * caller once after allocation; every call leaves them zero.  A set of cells serves one launch at a time (stream order);
+ * keep one per layer, or one per stream.
+ */
+int aqlm_hip_gemv_8x8_lut_fused(const void* codes_i8, const void* codebooks, const void* scales, const void* bias,
+                                const void* x, void* y, int out_features, int in_features, int in_group_size, int dtype,
+                                void* cells, size_t cells_bytes, void* stream);
+int aqlm_hip_gemv_8x8_lut_multi_fused(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
+                                      int in_group_size, int dtype, void* cells, size_t cells_bytes, void* stream);
+
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3
 #define AQLM_HIP_OP_GEMV_8X8_LUT 4

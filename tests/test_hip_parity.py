@@ -777,6 +777,61 @@ def test_gemv_8x8_lut(hk, g, fin, fout, dt, bias):
         assert torch.equal(yz[0], T["bias"])
 
 
+@pytest.mark.parametrize("g,fin,fout,dt", [(32, 4096, 2048, "float16"), (32, 11008, 1000, "bfloat16"), (8, 2048, 300, "float16")])
+def test_gemv_8x8_lut_fused_finalize(hk, g, fin, fout, dt):
+    """Single-kernel form of the look-up-table matvec (fixed-point slab sums in zero-at-rest cells, one returning atomic per
+    slab and row) vs the oracle and vs the two-kernel form; repeatable bit for bit; clean cells; magnitudes; NaN."""
+    dtype = tdtype(dt)
+    L = orc.make_layer(5500 + fin + fout + g, fin, fout, 8, 8, g, batch=1, bias=True,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    run = lambda x: hk._gemv_8x8_lut(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert hk.USE_8X8_LUT_FUSED
+    y = run(T["x"])
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    cells = hk._LUT_CELLS[key]
+    assert int(cells.abs().max()) == 0, "cells must be zero when the kernel has finished"
+    hk.USE_8X8_LUT_FUSED = False
+    try:
+        y_two = run(T["x"])
+    finally:
+        hk.USE_8X8_LUT_FUSED = True
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, dtype, "lut fused finalize")
+    check_close(y.float().cpu().numpy(), y_two.double().cpu().numpy(), dtype, "lut fused vs two-kernel")
+    for _ in range(10):
+        assert torch.equal(run(T["x"]), y)
+    for factor, what in ((2.0 ** 10, "|x| large"), (2.0 ** -12, "|x| small")):
+        xs = T["x"] * factor
+        ys64 = orc.dequantize_gemm(xs.double().cpu().numpy(), L["codes"], T["codebooks"].double().cpu().numpy(),
+                                   (T["scales"] * 2.0 ** -6).double().cpu().numpy(), None)
+        ys = hk._gemv_8x8_lut(xs, T["codes"], T["codebooks"], T["scales"] * 2.0 ** -6, None)
+        check_close(ys.float().cpu().numpy(), ys64, dtype, f"lut fused finalize, {what}")
+    xn = T["x"].clone()
+    xn[0, 5] = float("nan")
+    assert torch.isnan(run(xn)).all() and int(cells.abs().max()) == 0
+    assert torch.equal(run(T["x"]), y)
+    # hipGraph: a stream that has run the op captures the single-kernel form; a fresh one falls back to two kernels
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        run(T["x"])
+    torch.cuda.synchronize()
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph, stream=s):
+        yg = run(T["x"])
+    gph.replay(); gph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y)
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    gph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph2, stream=s2):
+        yg2 = run(T["x"])
+    gph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg2, y_two)
+
+
 def test_ops_trace_under_torch_compile(hk):
     """torch.ops.aqlm.* carry fake impls (like cuda_kernel.py:20-22), so Dynamo traces a QuantizedLinear without
     graph breaks -- what the reference's CUDA-graph notebook relies on (notebooks/aqlm_cuda_graph.ipynb)."""

@@ -3,7 +3,6 @@ set +e
 OUT=gpurun_out/r2b
 mkdir -p $OUT
 export TMPDIR=/tmp
-for o in 4096 11008; do
-  timeout 900 tools/microbench/mb gemv full 1x16g8P $o > $OUT/mb_var_${o}.log 2>&1; echo "rc=$?"
-  grep " 1 default\|two-kernel\|shared workspace\|MISMATCH" $OUT/mb_var_${o}.log
-done
+timeout 1500 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|FAILED|rror" $OUT/pytest_gpu.log | tail -8
+timeout 900 tools/microbench/mb gemv full 8x8g32LUT > $OUT/mb_lut.log 2>&1; echo "rc=$?"
+grep "default\|two-kernel" $OUT/mb_lut.log

@@ -357,6 +357,7 @@ struct Scheme {
 };
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
+static bool g_lut_fused = true;  // 8x8 look-up-table scheme: single-kernel form (cells in g_ws) or main + finalize
 
 static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
   size_t n = (size_t)out * (in / s.g) * s.K * (s.nbits <= 8 ? 1 : 2);
@@ -366,6 +367,8 @@ static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
 }
 
 static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st) {
+  if (s.lut && g_lut_fused)  // g_ws is zero-filled before every variant and left zero by every fused call
+    return aqlm_hip_gemv_8x8_lut_fused(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.lut)
     return aqlm_hip_gemv_8x8_lut(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.nbits == 16 && s.packed)
@@ -497,6 +500,8 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"arrange=0", "packed_arrange", 0}});
 
     } else if (c.s.packed) {
+    } else if (c.s.lut) {
+      variants.push_back({{"two-kernel finalize", "mb_lut_two_kernel", 1}});
     } else if (c.s.nbits == 8 && c.s.g == 8) {
       variants.push_back({{"replicas=off", "kx8_replicas", 0}});
       variants.push_back({{"replicas=force", "kx8_replicas", 2}});
@@ -525,7 +530,11 @@ static void bench_gemv(int argc, char** argv) {
           printf("# variant check rep %d: rc=%d mismatches=%zu of %d\n", rep, rc, bad, c.out);
         }
       }
-      for (const auto& kv : var) { aqlm_hip_set_tuning(kv.key, kv.val); vn += kv.name; }
+      g_lut_fused = true;
+      for (const auto& kv : var) {
+        if (!strcmp(kv.key, "mb_lut_two_kernel")) g_lut_fused = false; else aqlm_hip_set_tuning(kv.key, kv.val);
+        vn += kv.name;
+      }
       if (c.s.packed && !var.empty() && !strcmp(var[0].key, "packed_fused_finalize")) check_packed(c.s, layers[0], c.in, c.out);
       if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange") || !strcmp(var[0].key, "packed_entry_bytes") || !strcmp(var[0].key, "packed_xcopies"))) {  // a format parameter: repack
         const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
@@ -547,7 +556,7 @@ static void bench_gemv(int argc, char** argv) {
                ab / cold * 1e-3 / 80.0);
         fflush(stdout);
       }
-      for (const auto& kv : var) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange") || !strcmp(kv.key, "packed_fused_finalize")) ? 1 : 0);
+      for (const auto& kv : var) if (strcmp(kv.key, "mb_lut_two_kernel")) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange") || !strcmp(kv.key, "packed_fused_finalize")) ? 1 : 0);
     }
     free_layers(layers);
   }
