@@ -52,7 +52,7 @@ def main():
     out["how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 4 --warmup 1 "
                   "--no-detail --no-cpu`, read bytes = 2 x FETCH_SIZE x 1024 (gfx950), tools/make_pmc_traffic.py")
     out["note"] = ("per matvec of the bench step = (all matvec kernels of the timed launches) / number of matvecs; "
-                   "algorithmic bytes per matvec 8 820 224: the prepacked path (format v5, 32-bit entries) reads ~4.5 B per "
+                   "algorithmic bytes per matvec 8 820 224: the prepacked path (format v6, 32-bit entries) reads ~4.5 B per "
                    "code plus the row-start table and the codebook slices")
     json.dump(out, sys.stdout, indent=1)
 
