@@ -489,6 +489,10 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
     } else if (c.s.packed && !quick) {
       variants.push_back({{"two-kernel finalize", "packed_fused_finalize", 0}});
+      variants.push_back({{"waves=9", "packed_waves", 9}});
+      variants.push_back({{"waves=10", "packed_waves", 10}});
+      variants.push_back({{"waves=12", "packed_waves", 12}});
+      variants.push_back({{"waves=6", "packed_waves", 6}});
       variants.push_back({{"waves=4", "packed_waves", 4}});
       variants.push_back({{"waves=8", "packed_waves", 8}});
       variants.push_back({{"waves=16", "packed_waves", 16}});
