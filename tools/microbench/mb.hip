@@ -489,6 +489,9 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
     } else if (c.s.packed && !quick) {
       variants.push_back({{"two-kernel finalize", "packed_fused_finalize", 0}});
+      if (getenv("MB_AB12")) {  // focused A/B: 12 vs 16 waves, three alternations
+        for (int r = 0; r < 3; ++r) { variants.push_back({{"waves=12", "packed_waves", 12}}); variants.push_back({{"waves=16", "packed_waves", 16}}); }
+      } else {
       variants.push_back({{"waves=9", "packed_waves", 9}});
       variants.push_back({{"waves=10", "packed_waves", 10}});
       variants.push_back({{"waves=12", "packed_waves", 12}});
@@ -502,6 +505,7 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"xcopies=4", "packed_xcopies", 4}});
       variants.push_back({{"prefetch=8", "packed_prefetch", 8}});
       variants.push_back({{"arrange=0", "packed_arrange", 0}});
+      }
 
     } else if (c.s.packed) {
     } else if (c.s.lut) {
