@@ -122,10 +122,13 @@ static int choose_waves(uint32_t max_lane_steps) {
   const int q = (int)((max_lane_steps + 63) / 64);
   if (tuning().packed_waves >= 1 && tuning().packed_waves <= PK_MAX_NW) return tuning().packed_waves;
   if (q >= 48) return 16;
+  // ... and a step count that is a multiple of the ring depth (3): a remainder of one or two steps runs through the
+  // kernel's tail code and leaves late requests behind (measured, profiles/r02_mb_wave_counts.log: 4096x4096 with
+  // 6 waves x 6 steps 6.09 us, 7 x 5 6.23 us, 5 x 7 6.22 us; 8192->1024 with 6 x 3 = 7 x 3 5.23 us, 5 x 4 5.55 us)
   int best = 8, best_cost = 1 << 30;
   for (int nw = 8; nw >= 4; --nw) {
     const int t = (q + nw - 1) / nw;
-    const int cost = (nw * t - q) * 8 + (8 - nw);
+    const int cost = (nw * t - q) * 8 + (8 - nw) + ((t >= 3 && t % 3 != 0) ? 12 : 0);
     if (cost < best_cost) { best_cost = cost; best = nw; }
   }
   return best;

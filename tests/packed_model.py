@@ -36,7 +36,7 @@ def choose_waves(max_lane_steps):
     best, best_cost = 8, 1 << 30
     for nw in range(8, 3, -1):
         t = (q + nw - 1) // nw
-        cost = (nw * t - q) * 8 + (8 - nw)
+        cost = (nw * t - q) * 8 + (8 - nw) + (12 if (t >= 3 and t % 3 != 0) else 0)
         if cost < best_cost:
             best, best_cost = nw, cost
     return best

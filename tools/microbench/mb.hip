@@ -489,7 +489,9 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"rpw=4+prefetch", "gemv_rows_per_wave", 4}, {"", "gemv1x16_prefetch_cb", 1}});
     } else if (c.s.packed && !quick) {
       variants.push_back({{"two-kernel finalize", "packed_fused_finalize", 0}});
-      if (getenv("MB_PD")) {  // focused A/B on the default packing: ring depth 3 vs 4, three alternations
+      if (getenv("MB_W67")) {  // focused A/B: small layers, 5 / 6 / 7 waves, three alternations
+        for (int r = 0; r < 3; ++r) { variants.push_back({{"waves=6", "packed_waves", 6}}); variants.push_back({{"waves=7", "packed_waves", 7}}); variants.push_back({{"waves=5", "packed_waves", 5}}); }
+      } else if (getenv("MB_PD")) {  // focused A/B on the default packing: ring depth 3 vs 4, three alternations
         for (int r = 0; r < 3; ++r) { variants.push_back({{"prefetch=4", "packed_prefetch", 4}}); variants.push_back({{"prefetch=3", "packed_prefetch", 3}}); }
       } else if (getenv("MB_AB12")) {  // focused A/B: 12 vs 16 waves, three alternations
         for (int r = 0; r < 3; ++r) { variants.push_back({{"waves=12", "packed_waves", 12}}); variants.push_back({{"waves=16", "packed_waves", 16}}); }
