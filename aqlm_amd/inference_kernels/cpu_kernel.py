@@ -50,6 +50,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _threads(nthreads: int) -> int:
+    """0 = the process's torch thread setting (the knob the reference's CPU benchmark turns together with numba's,
+    matmul_benchmark_cpu.py:77-88) -- not OpenMP's default, which is every logical CPU the host shows even when the
+    container may only use a few of them (measured on the 256-thread GPU host: 250 ms instead of 3 ms per call)."""
+    return int(nthreads) if nthreads and nthreads > 0 else max(1, int(torch.get_num_threads()))
+
+
 def permute_codes_for_lut(codes: torch.Tensor) -> torch.Tensor:
     """[out, in_groups, K] -> [in_groups, out, K] uint8: the layout of the LUT kernel (what the reference's
     ``prepare_matmul_op`` does to ``codes`` IN PLACE for CPU modules, inference.py:78-83; here a derived copy)."""
@@ -75,7 +82,7 @@ def cpu_gemm_lut(input: torch.Tensor, codes_alt: torch.Tensor, codebooks: torch.
     scratch = torch.empty((lib().aqlm_cpu_lut_scratch_floats(in_features, K, g),), dtype=torch.float32)
     rc = lib().aqlm_cpu_gemv_lut_kx8(x.data_ptr(), cb.data_ptr(), codes_alt.contiguous().data_ptr(), sc.data_ptr(), _ptr(bi),
                                      y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, K, g,
-                                     scratch.data_ptr(), nthreads)
+                                     scratch.data_ptr(), _threads(nthreads))
     if rc:
         raise RuntimeError(f"aqlm_cpu_gemv_lut_kx8 failed with {rc}")
     return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))
@@ -98,7 +105,7 @@ def cpu_gemv_1xn(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tens
     y = torch.empty((x.shape[0], out_features), dtype=torch.float32)
     rc = lib().aqlm_cpu_gemv_1xn(x.data_ptr(), cb.data_ptr(), c.data_ptr(), c.element_size(), sc.data_ptr(), _ptr(bi),
                                  y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, nbits, g,
-                                 nthreads)
+                                 _threads(nthreads))
     if rc:
         raise RuntimeError(f"aqlm_cpu_gemv_1xn failed with {rc}")
     return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))

@@ -256,7 +256,7 @@ def cpu_baseline(sample_seconds=24.0):
             signed = orc.pack_int_data(L["codes"], nbits)
             codes_t = torch.from_numpy(np.ascontiguousarray(signed))
             b = algorithmic_bytes(4096, 4096, K, nbits, 8)
-            for label, nt in (("1_thread", 1), (f"{threads}_threads", 0)):
+            for label, nt in (("1_thread", 1), (f"{threads}_threads", threads)):
                 if nbits == 8:
                     alt = ck.permute_codes_for_lut(codes_t)
                     fn = lambda: ck.cpu_gemm_lut(xt, alt, cbt, sct, None, nthreads=nt)  # noqa: E731
