@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaqlm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
@@ -86,6 +86,7 @@ SIGNATURES = {
     "aqlm_hip_packed_desc_read": (_ci, [_vp, _sz, _descp]),
     "aqlm_hip_unpack_1x16": (_ci, [_descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_1x16_packed_chain": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed_partials": (_ci, [_descp, _vp, _vp, _vp, _ci, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_xgmi_state_bytes": (_sz, [_ci]),
     "aqlm_hip_xgmi_finalize": (_ci, [_xgp, _vp, _vp, _vp, _vp, _ci, _ci, _cl, _ci, _vp]),

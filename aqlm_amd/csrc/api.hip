@@ -53,7 +53,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "gemv1x16_aux")) return &t.gemv1x16_aux;
   if (!strcmp(key, "gemv1x16_prefetch_cb")) return &t.gemv1x16_prefetch_cb;
   if (!strcmp(key, "kx8_replicas")) return &t.kx8_replicas;
-  if (!strcmp(key, "gemm_splitk_free")) return &t.gemm_splitk_free;
+  if (!strcmp(key, "gemm_variant")) return &t.gemm_variant;
   if (!strcmp(key, "force_generic")) return &t.force_generic;
   if (!strcmp(key, "packed_waves")) return &t.packed_waves;
   if (!strcmp(key, "packed_fused_finalize")) return &t.packed_fused_finalize;
@@ -62,6 +62,8 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "packed_xcopies")) return &t.packed_xcopies;
   if (!strcmp(key, "packed_entry_bytes")) return &t.packed_entry_bytes;
   if (!strcmp(key, "packed_debug")) return &t.packed_debug;
+  if (!strcmp(key, "packed_fill_rotate")) return &t.packed_fill_rotate;
+  if (!strcmp(key, "packed_prefetch_waves")) return &t.packed_prefetch_waves;
   return nullptr;
 }
 

@@ -150,7 +150,7 @@ struct Tuning {
   int gemv1x16_aux = AUX_DEFAULT;  // cache policy of the codebook gathers: 0 default, 1 sc0, 2 nt, 16 sc1
   int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
-  int gemm_splitk_free = 0;      // 1: large-batch 1x16 op uses the split-K-free 16x16x32 kernel when in % 256 == 0
+  int gemm_variant = 0;          // large-batch 1x16 op: 0 = LDS-DMA pipeline (gemm_1x16_glds_kernel), 1 = register-staged split-K kernel (round 1)
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
   int packed_fused_finalize = 1;  // 0 = two-kernel finalize even when the descriptor carries the codebook range (A/B runs)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
@@ -159,6 +159,8 @@ struct Tuning {
   int packed_entry_bytes = 0;    // prepack: 0 / 4 = 32-bit entries; 3 = 24-bit entries (wave ranges of <= 32 steps)
   int packed_debug = 0;          // profiling builds (-DAQLM_PACKED_TRACE) only: 1 = no LDS reads / dots, 2 = no entry stream
   int packed_prefetch = 0;       // packed 1x16 kernel: steps of the entry stream in flight per wave (4 / 8); 0 = heuristic
+  int packed_fill_rotate = 1;    // packed 1x16 kernel: 1 = the workgroups that share a codebook slice start their LDS fill at different pieces
+  int packed_prefetch_waves = 0; // chain prefetch: extra waves per workgroup that pull the next layer towards L2 (0 = 2, -1 = off)
 };
 Tuning& tuning();
 

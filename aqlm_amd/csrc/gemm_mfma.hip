@@ -240,15 +240,27 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const FinalizeParams
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Split-K-free variant (experimental, opt-in through the `gemm_splitk_free` tuning knob; measured SLOWER than the
-// split-K kernel on MI355X at 4096x4096: 41 vs 30 us at B = 128 -- each block re-streams all of X through L2 and a
-// 4-wave block cannot hide that latency): one block = 16 output rows x the whole K x all batch
-// columns.  The 4 waves split K four ways, each streams ITS quarter of X through a wave-private LDS image (no block
-// barrier in the main loop) and accumulates 16 x Bpad in registers with v_mfma_f32_16x16x32; at the end the 4
-// accumulators are added through LDS and the block writes Y directly (scale, bias, one rounding): no fp32 partials
-// in HBM, no second kernel.  A operand of lane l = 8 consecutive k of row l%16, k-group l/16 = one codebook entry.
-// Cost model per CU (M = 4096: one block per CU): 8192 gathered 128-B lines + B*K*2 bytes of X through the 64 B/clk
-// L1-fill path -> ~8 us + 6.8 us at B = 128.
+// LDS-DMA pipeline (default since round 3): every global read of the main loop is a global_load_lds -- the X tiles,
+// the codes AND the codebook gathers -- so nothing of the stream occupies VGPRs, the wave's VMEM queue holds one kind
+// of operation (hipcc waits with vmcnt(0) for any register load that sits beside an LDS-DMA, cdna_hip_programming.md
+// section 5 trap (b)) and all waits are counted by hand (static counts, raw s_barrier).
+//
+//   block  = 8 waves = 128 output rows (16 per wave) x one K slice x <= 128 batch columns; 1 block per CU
+//   MFMA   = v_mfma_f32_16x16x32: A = W (lane (r, kg): row r, 8 k of k-group kg = ONE codebook vector for g = 8, one
+//            half of one for g = 16), B = X^T (lane (r, kg): batch column 16 t + r, the same 8 k), C = 4 consecutive
+//            output rows of one batch column per lane -> partial / Y stores of 16 B
+//   gather = one global_load_lds_dwordx4 per 32-deep k step and wave: lane (r, kg) names the address of ITS fragment,
+//            the DMA drops the 64 fragments into LDS in lane order, and the A operand is read back with one
+//            conflict-free ds_read_b128.  The gathered entry is still the MFMA fragment; LDS is only the landing zone
+//            that lets NS - 1 = 3 chunks (48 wave-gathers = 3072 lane-gathers per CU) be in flight without registers.
+//   codes  = 16 B per row and 64-deep chunk, DMA'd 2 NS - 1 chunks ahead into a wave-private ring, read back one
+//            iteration before the gather that needs them
+//   X      = Bpad x 64 k chunks into the XOR-swizzled image of xswz() (swizzle applied to the SOURCE address: the DMA
+//            writes lane-linear), shared by the 8 waves
+//   K split over the blocks of one XCD (block -> XCD affinity b % 8, speed only): fp32 partials [ks][b][m] stay in that
+//   XCD's L2 for the finalize kernel, which is mapped the same way.  One barrier per chunk.
+//
+// Per-CU traffic through the L1 fill path for 4096 x 4096, B = 128: 8192 gathered lines (1 MiB) + 128 KiB of X.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <class T>
@@ -262,145 +274,317 @@ __device__ __forceinline__ f32x4 mfma16<BF16>(const u32x4& a, const u32x4& b, co
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-struct Gemm16Params {
-  const uint8_t* codes;
-  const uint8_t* codebook;
-  const uint16_t* X;
-  const uint16_t* scales;
+typedef __attribute__((address_space(3))) const u32x4* glds_u32x4_ptr;
+typedef __attribute__((address_space(3))) const uint16_t* glds_u16_ptr;
+typedef __attribute__((address_space(3))) void* glds_void_ptr;
+typedef __attribute__((address_space(1))) const void* ggbl_void_ptr;
+
+struct GldsParams {
+  const uint8_t* codes;     // [M][in_groups] u16
+  const uint8_t* codebook;  // [65536][G] halfs
+  const uint16_t* X;        // [B][xs]
+  float* partial;           // [ksplit][B][M] fp32 (ksplit > 1)
+  const uint16_t* scales;   // ksplit == 1: the block writes Y itself
   const uint16_t* bias;
   uint16_t* Y;
-  int M, K, B, in_groups;
   long xs, ys;
-  int cb_bytes;
+  int M, B, in_groups;
+  int row_blocks, ksplit;
+  int chunks_base, chunks_rem;  // K slice ks covers chunks_base + (ks < chunks_rem) chunks of 64 k
 };
 
-template <class T, int G, int NBT>  // NBT = 16-column batch tiles (Bpad = 16 * NBT <= 128)
-__global__ __launch_bounds__(256) void gemm_1x16_mfma16_kernel(const Gemm16Params p) {
-  constexpr int BPAD = NBT * 16;
-  constexpr int PIECES = BPAD * 8;             // 16-B pieces of one 64-deep X chunk
-  constexpr int PER_LANE = PIECES / 64;        // = 2 * NBT
-  constexpr int CWN = (64 / G) / 2;            // dwords of codes per row per chunk: 4 (g8) / 2 (g16)
-  __shared__ __attribute__((aligned(16))) u32x4 xl_all[4][PIECES];   // wave-private X chunk images (<= 64 KiB)
+constexpr int GL_NS = 4;       // stages of the W / X ring
+constexpr int GL_NSLOT = 8;    // slots of a wave's code ring (>= GL_NS + 1, power of two)
+constexpr int GL_WAVES = 8;
+constexpr uint32_t GL_W_BYTES = GL_WAVES * 2048u;  // per stage: 2 fragments of 1 KiB per wave
+
+template <int XW>
+struct GldsLds {
+  static constexpr uint32_t X_BYTES = XW * 64u * 128u;        // XW * 64 batch rows x 64 k
+  static constexpr uint32_t STAGE = GL_W_BYTES + X_BYTES;
+  static constexpr uint32_t CODES = GL_NS * STAGE;            // [wave][slot][256 B]
+  static constexpr uint32_t TOTAL = CODES + GL_WAVES * GL_NSLOT * 256u;
+};
+
+constexpr int gl_vmcnt(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }  // vmcnt(n) only
+
+template <class T, int G, int NBT, int XW>  // NBT = 16-column batch tiles computed; XW * 64 = batch rows staged
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_1x16_glds_kernel(const GldsParams p) {
+  using LDS = GldsLds<XW>;
+  constexpr int P = 1 + 2 + XW;  // LDS-DMA operations per wave and issue iteration: codes, 2 fragments, XW pieces of X
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map below starts at 0
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  u32x4* const xl = xl_all[wave];
   const int arow = lane & 15, kg = lane >> 4;
-  const int row0 = blockIdx.x * 16;
-  int my_row = row0 + arow;
-  if (my_row >= p.M) my_row = p.M - 1;  // clamp: computed, never stored
-  const int kq = p.K >> 2;               // this wave's K range
-  const int k_begin = wave * kq;
-  const int nchunks = kq >> 6;
 
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.codebook, 0, p.cb_bytes, 0x00020000);
-  const uint8_t* const code_row = p.codes + (long)my_row * p.in_groups * 2;
+  // block -> (row block, K slice): the K slices of a row block run on one XCD (observed placement: block b on XCD b % 8)
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int rb_hi = slot / p.ksplit;
+  const int row_blk = rb_hi * 8 + xcd, ks = slot - rb_hi * p.ksplit;
+  if (row_blk >= p.row_blocks) return;
+  const int n = p.chunks_base + (ks < p.chunks_rem ? 1 : 0);                                // chunks of this block, >= GL_NS - 1
+  const int chunk0 = ks * p.chunks_base + (ks < p.chunks_rem ? ks : p.chunks_rem);
+  const int row0 = row_blk * 128 + wave * 16;
+
+  // ---- per-lane source addresses ------------------------------------------------------------------------------
+  // codes: g = 8: lanes 0..15 move 16 B (8 codes) of row row0 + lane; g = 16: lanes 0..31 move 4 B (2 codes) each
+  constexpr int CODE_LANES = G == 8 ? 16 : 32;
+  constexpr int CODE_BYTES_PER_CHUNK = G == 8 ? 16 : 8;  // per row
+  const uint8_t* code_src;
+  {
+    int r = row0 + (G == 8 ? lane : (lane >> 1));
+    r = r < p.M ? r : p.M - 1;
+    code_src = p.codes + ((size_t)r * p.in_groups) * 2 + (size_t)chunk0 * CODE_BYTES_PER_CHUNK + (G == 8 ? 0 : (lane & 1) * 4);
+  }
+  // X: piece (wave * XW + x) of a chunk image = 64 slots of 16 B; slot s holds batch row s >> 3, k piece (s & 7) ^ swizzle
+  const uint8_t* x_src[XW];
+#pragma unroll
+  for (int x = 0; x < XW; ++x) {
+    const int s = (wave * XW + x) * 64 + lane;
+    int b = s >> 3;
+    const int c = (s & 7) ^ ((b >> 1) & 7);
+    b = b < p.B ? b : p.B - 1;  // rows past the batch: a valid row, computed and never stored
+    x_src[x] = (const uint8_t*)(p.X + (size_t)b * p.xs + (size_t)chunk0 * 64 + c * 8);
+  }
+  const uint32_t code_ring = LDS::CODES + (uint32_t)wave * (GL_NSLOT * 256u);
+  // this lane's two codes of a chunk inside a ring slot (k step s: g = 8 code 4 s + kg; g = 16 code 2 s + kg / 2)
+  const uint32_t code_off0 = G == 8 ? (uint32_t)arow * 16u + (uint32_t)kg * 2u : (uint32_t)arow * 8u + (uint32_t)(kg >> 1) * 2u;
+  constexpr uint32_t CODE_STEP = G == 8 ? 8u : 4u;  // bytes between the codes of k step 0 and k step 1
+  const uint32_t half_off = G == 8 ? 0u : (uint32_t)(kg & 1) * 16u;
+
+  auto dma_codes = [&](int chunk) {  // chunk may run past the slice: clamped (the slot is written, never used)
+    const int cc = chunk < n ? chunk : n - 1;
+    if (lane < CODE_LANES) {
+      ggbl_void_ptr src = (ggbl_void_ptr)(code_src + (size_t)cc * CODE_BYTES_PER_CHUNK);
+      glds_void_ptr dst = (glds_void_ptr)(size_t)(code_ring + (uint32_t)(chunk & (GL_NSLOT - 1)) * 256u);
+      if constexpr (G == 8) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+    }
+  };
+  auto read_codes = [&](int chunk, uint32_t (&c)[2]) {
+    const uint32_t a = code_ring + (uint32_t)(chunk & (GL_NSLOT - 1)) * 256u + code_off0;
+    c[0] = *(glds_u16_ptr)(size_t)(a);
+    c[1] = *(glds_u16_ptr)(size_t)(a + CODE_STEP);
+  };
+  auto dma_stage = [&](int chunk, int stage, const uint32_t (&c)[2]) {
+    const uint32_t base = (uint32_t)stage * LDS::STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebook + (size_t)c[s] * (G * 2) + half_off),
+                                       (glds_void_ptr)(size_t)(base + (uint32_t)wave * 2048u + (uint32_t)s * 1024u), 16, 0, 0);
+#pragma unroll
+    for (int x = 0; x < XW; ++x)
+      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (size_t)chunk * 128),
+                                       (glds_void_ptr)(size_t)(base + GL_W_BYTES + (uint32_t)(wave * XW + x) * 1024u), 16, 0, 0);
+  };
 
   f32x4 acc[NBT];
 #pragma unroll
   for (int t = 0; t < NBT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto load_codes = [&](int chunk, uint32_t (&cw)[CWN]) {
-    const uint8_t* src = code_row + (long)((k_begin + chunk * 64) / G) * 2;
-    if constexpr (CWN == 4) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(src);
-      cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
-    } else {
-      const u32x2 v = *reinterpret_cast<const u32x2*>(src);
-      cw[0] = v.x; cw[1] = v.y;
-    }
-  };
-  // two 32-deep steps per chunk; lane (arow, kg) needs code 4*step + kg (g8) or code 2*step + kg/2, half kg&1 (g16)
-  auto gather = [&](const uint32_t (&cw)[CWN], u32x4 (&af)[2]) {
+  auto compute = [&](int stage) {
+    const uint32_t base = (uint32_t)stage * LDS::STAGE;
+    // all fragment reads of the chunk are issued before the first MFMA (left alone, hipcc pairs every read with an
+    // lgkmcnt(0) and the wave pays one LDS latency per MFMA)
+    u32x4 a[2], b[2][NBT];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      uint32_t off;
-      if constexpr (G == 8) {
-        const uint32_t dw = (kg & 2) ? cw[2 * st + 1] : cw[2 * st];
-        off = ((dw >> (16 * (kg & 1))) & 0xffffu) * 16u;
-      } else {
-        const uint32_t dw = cw[st];
-        off = ((dw >> (16 * (kg >> 1))) & 0xffffu) * 32u + (uint32_t)(kg & 1) * 16u;
-      }
-      af[st] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-    }
-  };
-  // X chunk: lane takes pieces q = lane + 64*s -> row b = q >> 3, piece c = q & 7 (full 128-B rows: no over-fetch)
-  auto load_x = [&](int chunk, u32x4 (&xr)[PER_LANE]) {
-    const int k0 = k_begin + chunk * 64;
+    for (int s = 0; s < 2; ++s) {
+      a[s] = *(glds_u32x4_ptr)(size_t)(base + (uint32_t)wave * 2048u + (uint32_t)s * 1024u + (uint32_t)lane * 16u);
 #pragma unroll
-    for (int s = 0; s < PER_LANE; ++s) {
-      const int q = lane + 64 * s, b = q >> 3, c = q & 7;
-      xr[s] = b < p.B ? *reinterpret_cast<const u32x4*>(p.X + (long)b * p.xs + k0 + c * 8) : u32x4{0u, 0u, 0u, 0u};
+      for (int t = 0; t < NBT; ++t)
+        b[s][t] = *(glds_u32x4_ptr)(size_t)(base + GL_W_BYTES + (uint32_t)xswz(t * 16 + arow, s * 4 + kg) * 16u);
     }
-  };
-  auto store_x = [&](const u32x4 (&xr)[PER_LANE]) {
+    asm volatile("" ::: "memory");  // keep the reads above the MFMAs (and the next iteration's DMA below them)
 #pragma unroll
-    for (int s = 0; s < PER_LANE; ++s) {
-      const int q = lane + 64 * s;
-      xl[xswz(q >> 3, q & 7)] = xr[s];
-    }
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) acc[t] = mfma16<T>(a[s], b[s][t], acc[t]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + NBT), 0);  // DS reads first ...
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NBT, 0);        // ... then the MFMAs
   };
 
-  uint32_t cw_a[CWN], cw_b[CWN];
-  u32x4 af_a[2], af_b[2];
-  u32x4 xr[PER_LANE];
-  load_x(0, xr);
-  load_codes(0, cw_a);
-  if (nchunks > 1) load_codes(1, cw_b);
-  gather(cw_a, af_a);
-  store_x(xr);
-
-  auto step = [&](int ch, uint32_t (&cw_free)[CWN], const uint32_t (&cw_next)[CWN], const u32x4 (&af_cur)[2], u32x4 (&af_nxt)[2]) {
-    const bool more = ch + 1 < nchunks;
-    if (more) {
-      load_x(ch + 1, xr);
-      gather(cw_next, af_nxt);
-      if (ch + 2 < nchunks) load_codes(ch + 2, cw_free);
-    }
+  // ---- prologue: codes of the first NS chunks (one exposed round trip: the gathers depend on them), then NS - 1
+  // issue iterations.  Issue iteration i: codes of chunk i + 2 NS - 1, stage of chunk q = i + NS - 1, read back the
+  // codes of chunk q + 1 (their DMA is NS iterations old: covered by the wait that opens compute iteration i).
+  uint32_t creg[2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+  for (int j = 0; j < GL_NS; ++j) dma_codes(j);
+  __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
+  read_codes(0, creg);
 #pragma unroll
-      for (int t = 0; t < NBT; ++t) {
-        const u32x4 bfrag = xl[xswz(t * 16 + arow, st * 4 + kg)];
-        acc[t] = mfma16<T>(af_cur[st], bfrag, acc[t]);
-      }
-    }
-    if (more) store_x(xr);  // same-wave LDS ops execute in order: these writes follow the reads above
-  };
-  for (int ch = 0; ch < nchunks; ch += 2) {
-    step(ch, cw_a, cw_b, af_a, af_b);
-    if (ch + 1 < nchunks) step(ch + 1, cw_b, cw_a, af_b, af_a);
+  for (int i = -(GL_NS - 1); i < 0; ++i) {
+    const int q = i + GL_NS - 1;
+    dma_codes(q + GL_NS);
+    dma_stage(q, q, creg);
+    read_codes(q + 1, creg);
   }
+  // ---- main loop: compute chunk i, issue chunk i + NS - 1 -------------------------------------------------------
+  int stage = 0;  // = i % NS
+  int i = 0;
+  for (; i + GL_NS - 1 < n; ++i) {
+    __builtin_amdgcn_s_waitcnt(gl_vmcnt((GL_NS - 2) * P));  // everything this wave issued NS - 1 iterations ago has landed
+    __builtin_amdgcn_s_barrier();                           // ... and everybody else's; the stage of chunk i - 1 is free
+    const int q = i + GL_NS - 1;
+    const int qstage = stage == 0 ? GL_NS - 1 : stage - 1;  // = q % NS
+    dma_codes(q + GL_NS);
+    dma_stage(q, qstage, creg);
+    compute(stage);
+    read_codes(q + 1, creg);
+    stage = stage == GL_NS - 1 ? 0 : stage + 1;
+  }
+  // ---- tail: the last NS - 1 chunks, nothing left to issue --------------------------------------------------------
+  static_assert(GL_NS == 4, "the tail below is written out for three iterations");
+  __builtin_amdgcn_s_waitcnt(gl_vmcnt(2 * P));
+  __builtin_amdgcn_s_barrier();
+  compute(stage);
+  stage = stage == GL_NS - 1 ? 0 : stage + 1;
+  __builtin_amdgcn_s_waitcnt(gl_vmcnt(1 * P));
+  __builtin_amdgcn_s_barrier();
+  compute(stage);
+  stage = stage == GL_NS - 1 ? 0 : stage + 1;
+  __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
+  __builtin_amdgcn_s_barrier();
+  compute(stage);
 
-  // cross-wave K reduction through LDS (re-using the X images), then the fused epilogue
-  __syncthreads();
-  float* const red = reinterpret_cast<float*>(&xl_all[0][0]);  // [4 waves][16 rows][BPAD]
+  // ---- epilogue: lane (arow, kg) holds rows row0 + 4 kg .. + 3 of batch column 16 t + arow --------------------------
+  const int m = row0 + kg * 4;
+  const bool vec = (p.M & 3) == 0;  // 16-B aligned partial rows / 8-B aligned Y rows
+  if (p.ksplit > 1) {
+    float* out = p.partial + (size_t)ks * p.B * p.M;
 #pragma unroll
-  for (int t = 0; t < NBT; ++t)
+    for (int t = 0; t < NBT; ++t) {
+      const int b = t * 16 + arow;
+      if (b < p.B && m < p.M) {
+        float* dst = out + (size_t)b * p.M + m;
+        if (vec) *reinterpret_cast<f32x4*>(dst) = acc[t];
+        else
+          for (int r = 0; r < 4; ++r)
+            if (m + r < p.M) dst[r] = acc[t][r];
+      }
+    }
+  } else {
+    float sc[4], bi[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 16 + kg * 4 + r) * BPAD + t * 16 + arow] = acc[t][r];
-  __syncthreads();
-  for (int q = tid; q < 16 * BPAD; q += 256) {
-    const int b = q >> 4, r = q & 15;   // consecutive threads -> consecutive rows of one batch column (32-B runs of Y)
-    const int row = row0 + r;
-    if (b < p.B && row < p.M) {
-      const float s = red[(0 * 16 + r) * BPAD + b] + red[(1 * 16 + r) * BPAD + b] + red[(2 * 16 + r) * BPAD + b] +
-                      red[(3 * 16 + r) * BPAD + b];
-      const float scale = T::to_float(p.scales[row]);
-      const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-      p.Y[(long)b * p.ys + row] = T::from_float(__builtin_fmaf(s, scale, bias));
+    for (int r = 0; r < 4; ++r) {
+      const int mm = m + r < p.M ? m + r : p.M - 1;
+      sc[r] = T::to_float(p.scales[mm]);
+      bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+      const int b = t * 16 + arow;
+      if (b < p.B && m < p.M) {
+        uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+        uint16_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(acc[t][r], sc[r], bi[r]));
+        if (vec && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        else
+          for (int r = 0; r < 4; ++r)
+            if (m + r < p.M) dst[r] = h[r];
+      }
     }
   }
 }
 
+// Y[b][m] = (sum_ks partial[ks][b][m]) * scales[m] + bias[m]: thread = 4 consecutive m of one batch row, all K slices
+// requested before the first add.  Blocks are mapped like the main kernel's (row block -> XCD row_blk % 8), so the
+// partials are read from the L2 they were written to (speed only).
+struct GldsFinalizeParams {
+  const float* partial;
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* Y;
+  long ys;
+  int M, B, ksplit, row_blocks, bchunks;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gemm_glds_finalize_kernel(const GldsFinalizeParams p) {
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int rb_hi = slot / p.bchunks;
+  const int row_blk = rb_hi * 8 + xcd, bc = slot - rb_hi * p.bchunks;
+  if (row_blk >= p.row_blocks) return;
+  const int m = row_blk * 128 + ((int)threadIdx.x & 31) * 4;
+  const int b = bc * 8 + ((int)threadIdx.x >> 5);
+  if (m >= p.M || b >= p.B) return;
+  const size_t plane = (size_t)p.B * p.M;
+  const float* src = p.partial + (size_t)b * p.M + m;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((p.M & 3) == 0) {
+    int k = 0;
+    for (; k + 8 <= p.ksplit; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(k + j) * plane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += v[j][r];
+    }
+    for (; k < p.ksplit; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)k * plane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] += v[r];
+    }
+  } else {
+    for (int k = 0; k < p.ksplit; ++k)
+      for (int r = 0; r < 4; ++r)
+        if (m + r < p.M) s[r] += src[(size_t)k * plane + r];
+  }
+  uint16_t h[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mm = m + r < p.M ? m + r : p.M - 1;
+    const float sc = T::to_float(p.scales[mm]);
+    const float bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+    h[r] = T::from_float(__builtin_fmaf(s[r], sc, bi));
+  }
+  uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+  if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+  else
+    for (int r = 0; r < 4; ++r)
+      if (m + r < p.M) dst[r] = h[r];
+}
+
+struct GldsPlan {
+  int row_blocks, ksplit, chunks_base, chunks_rem, nbt, xw;
+};
+
+// K split: enough blocks for one round of the chip, K slices of >= 8 chunks (512 k) where K allows, never fewer than
+// NS - 1 chunks (the pipeline's prologue), chunks dealt evenly.
+static bool plan_glds(int B, int M, int K, GldsPlan& g) {
+  const int kchunks = K / BK;
+  if (K % BK != 0 || kchunks < GL_NS - 1 || B < 1 || B > 128) return false;
+  g.row_blocks = (M + 127) / 128;
+  int ksplit = std::max(1, 256 / g.row_blocks);
+  ksplit = std::min(ksplit, std::max(1, kchunks / 8));
+  ksplit = std::min(ksplit, kchunks / (GL_NS - 1));
+  g.ksplit = std::max(1, ksplit);
+  g.chunks_base = kchunks / g.ksplit;
+  g.chunks_rem = kchunks % g.ksplit;
+  const int nbt = (B + 15) / 16;
+  g.nbt = nbt <= 2 ? nbt : (nbt <= 4 ? 4 : (nbt <= 6 ? 6 : 8));
+  g.xw = g.nbt <= 4 ? 1 : 2;
+  return true;
+}
+
 template <class T, int G>
-static int launch_gemm16(const Gemm16Params& p, int bpad, hipStream_t stream) {
-  const int blocks = (p.M + 15) / 16;
-  if (bpad <= 16) hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 1>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (bpad <= 32) hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 2>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (bpad <= 64) hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 4>), dim3(blocks), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((gemm_1x16_mfma16_kernel<T, G, 8>), dim3(blocks), dim3(256), 0, stream, p);
-  return check_hip(hipGetLastError(), "gemm_1x16_mfma16 launch");
+static int launch_glds(const GldsParams& p, const GldsPlan& g, hipStream_t stream) {
+  const int rb8 = (p.row_blocks + 7) / 8;
+  const dim3 grid((unsigned)(8 * rb8 * p.ksplit));
+  auto go = [&](auto kern, size_t lds) -> int {
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    return check_hip(hipGetLastError(), "gemm_1x16_glds launch");
+  };
+  switch (g.nbt) {
+    case 1: return go(gemm_1x16_glds_kernel<T, G, 1, 1>, GldsLds<1>::TOTAL);
+    case 2: return go(gemm_1x16_glds_kernel<T, G, 2, 1>, GldsLds<1>::TOTAL);
+    case 4: return go(gemm_1x16_glds_kernel<T, G, 4, 1>, GldsLds<1>::TOTAL);
+    case 6: return go(gemm_1x16_glds_kernel<T, G, 6, 2>, GldsLds<2>::TOTAL);
+    default: return go(gemm_1x16_glds_kernel<T, G, 8, 2>, GldsLds<2>::TOTAL);
+  }
 }
 
 struct GemmPlan {
@@ -448,8 +632,13 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   if (op == AQLM_HIP_OP_GEMV_1X16_PACKED)  // fp32 partials [16 slices][rows of x][out]
     return (size_t)16 * std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * out_features * sizeof(float);
   if (op != AQLM_HIP_OP_GEMM_1X16_MFMA) return 0;
+  // covers both kernels of the op (the LDS-DMA pipeline and the register-staged one behind the `gemm_variant` knob)
   const GemmPlan g = plan_gemm(batch, out_features, in_features);
-  return (size_t)g.ksplit * out_features * g.Bpad * sizeof(float);
+  size_t need = (size_t)g.ksplit * out_features * g.Bpad * sizeof(float);
+  GldsPlan q;
+  if (plan_glds(std::min(batch, 128), out_features, in_features, q) && q.ksplit > 1)
+    need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
+  return need;
 }
 
 extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, const void* scales, const void* bias,
@@ -484,31 +673,51 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
     return AQLM_HIP_E_INVALID;
   }
   // batch > 128 is processed in slabs of 128 columns (codes re-gathered per slab)
-  const bool splitk_free = (in_features % 256 == 0) && tuning().gemm_splitk_free;  // measured slower: opt-in
+  const bool use_glds = tuning().gemm_variant == 0;
   for (int b0 = 0; b0 < batch; b0 += 128) {
     const int nb = std::min(128, batch - b0);
-    if (splitk_free) {
-      Gemm16Params q{};
-      q.codes = (const uint8_t*)codes;
-      q.codebook = (const uint8_t*)codebook;
-      q.X = (const uint16_t*)X + (long)b0 * xs;
-      q.scales = (const uint16_t*)scales;
-      q.bias = (const uint16_t*)bias;
-      q.Y = (uint16_t*)Y + (long)b0 * ys;
-      q.M = out_features;
-      q.K = in_features;
-      q.B = nb;
-      q.in_groups = in_features / in_group_size;
-      q.xs = xs;
-      q.ys = ys;
-      q.cb_bytes = 65536 * in_group_size * 2;
-      const int bpad = (nb + 15) / 16 * 16;
+    GldsPlan q;
+    if (use_glds && plan_glds(nb, out_features, in_features, q)) {
+      GldsParams gp{};
+      gp.codes = (const uint8_t*)codes;
+      gp.codebook = (const uint8_t*)codebook;
+      gp.X = (const uint16_t*)X + (long)b0 * xs;
+      gp.partial = (float*)workspace;
+      gp.scales = (const uint16_t*)scales;
+      gp.bias = (const uint16_t*)bias;
+      gp.Y = (uint16_t*)Y + (long)b0 * ys;
+      gp.xs = xs;
+      gp.ys = ys;
+      gp.M = out_features;
+      gp.B = nb;
+      gp.in_groups = in_features / in_group_size;
+      gp.row_blocks = q.row_blocks;
+      gp.ksplit = q.ksplit;
+      gp.chunks_base = q.chunks_base;
+      gp.chunks_rem = q.chunks_rem;
       int e;
       if (dtype == AQLM_HIP_F16)
-        e = in_group_size == 8 ? launch_gemm16<F16, 8>(q, bpad, stream) : launch_gemm16<F16, 16>(q, bpad, stream);
+        e = in_group_size == 8 ? launch_glds<F16, 8>(gp, q, stream) : launch_glds<F16, 16>(gp, q, stream);
       else
-        e = in_group_size == 8 ? launch_gemm16<BF16, 8>(q, bpad, stream) : launch_gemm16<BF16, 16>(q, bpad, stream);
+        e = in_group_size == 8 ? launch_glds<BF16, 8>(gp, q, stream) : launch_glds<BF16, 16>(gp, q, stream);
       if (e) return e;
+      if (q.ksplit > 1) {
+        GldsFinalizeParams f{};
+        f.partial = (const float*)workspace;
+        f.scales = (const uint16_t*)scales;
+        f.bias = (const uint16_t*)bias;
+        f.Y = (uint16_t*)Y + (long)b0 * ys;
+        f.ys = ys;
+        f.M = out_features;
+        f.B = nb;
+        f.ksplit = q.ksplit;
+        f.row_blocks = q.row_blocks;
+        f.bchunks = (nb + 7) / 8;
+        const dim3 grid((unsigned)(8 * ((q.row_blocks + 7) / 8) * f.bchunks));
+        if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(gemm_glds_finalize_kernel<F16>, grid, dim3(256), 0, stream, f);
+        else hipLaunchKernelGGL(gemm_glds_finalize_kernel<BF16>, grid, dim3(256), 0, stream, f);
+        if (int e2 = check_hip(hipGetLastError(), "gemm_glds_finalize launch")) return e2;
+      }
       continue;
     }
     const GemmPlan g = plan_gemm(nb, out_features, in_features);

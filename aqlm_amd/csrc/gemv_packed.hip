@@ -49,7 +49,10 @@
 
 namespace aqlm {
 
-constexpr int PK_S_LOG = 4;
+#ifndef AQLM_PK_S_LOG
+#define AQLM_PK_S_LOG 4  // 16 slices of 64 KiB; 5 = 32 slices of 32 KiB (experiment builds: tools/microbench)
+#endif
+constexpr int PK_S_LOG = AQLM_PK_S_LOG;
 constexpr int PK_S = 1 << PK_S_LOG;          // slices
 constexpr int PK_NG = 256 / PK_S;            // row groups (PK_S * PK_NG == 256 workgroups == CUs)
 constexpr int PK_CODE_BITS = 16 - PK_S_LOG;  // bits of a code inside its slice
@@ -61,6 +64,11 @@ constexpr int PK_MAX_GROUPS = 4094;          // j needs 12 bits, in_groups itsel
 constexpr uint32_t PK_MAGIC = 0x36505141u;   // "AQP6"
 constexpr int PK_VERSION = 6;
 constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (x first, slice behind it)
+// accumulator cell of the fused finalize: [arrivals : CNT bits][non-finite contributions : CNT bits][fixed-point sum]
+constexpr int PK_CNT_BITS = PK_S_LOG + 1;                       // counts 0 .. PK_S
+constexpr unsigned long long PK_CNT_MASK = (1ull << PK_CNT_BITS) - 1ull;
+constexpr int PK_VAL_SHIFT = 2 * PK_CNT_BITS;                   // 10 for 16 slices
+constexpr int PK_FIX_BITS = 51 - PK_S_LOG;                      // |slice sum| < 2^e is stored in units of 2^(e - PK_FIX_BITS): PK_S addends stay below 2^51
 
 // x copies (batch-1 kernel): copy c of x starts at 16-B slot c * stride with stride = 4 (mod 16), i.e. its bank-group
 // pattern is rotated by 4 c: an entry can read the copy whose bank group is still free in its service group.
@@ -522,6 +530,14 @@ struct PackedGemvParams {
   const uint16_t* bias;
   uint16_t* y;
   long y_row_stride;
+  // chain prefetch (optional): the layer that runs NEXT on this stream.  NPW extra waves of every workgroup pull the
+  // next layer's stream of the same workgroup index (same XCD under the observed block % 8 placement) and a share of
+  // its codebook slice towards this XCD's L2 while the other waves compute -- the next launch then starts L2-warm.
+  const uint8_t* next_ent;       // entry area of the next layer's packed buffer (nullptr: no prefetch)
+  const uint8_t* next_codebook;
+  uint32_t next_block_bytes;     // bytes of one workgroup's stream in the next layer (NW' * T' KiB)
+  int NPW;                       // prefetch waves in this launch (workgroup = NW + NPW waves)
+  int fill_rotate;               // 1: workgroup g starts its slice fill at piece g * (pieces / row groups)
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;  // [256 workgroups][8] wall-clock stamps (100 MHz), profiling builds only
   int dbg;                    // bit 0: skip the LDS reads + dot products, bit 1: no entry stream (out-of-range loads)
@@ -570,8 +586,12 @@ struct PackedLds {
   __host__ __device__ static uint32_t xmax(int in_groups, int RG) {  // 16-B aligned: read with ds_read_b128
     return (colend(in_groups, RG) + (uint32_t)B * PK_MAX_NW * 64 * 4 + 15u) & ~15u;
   }
-  __host__ __device__ static size_t total(int in_groups, int RG) {
-    return (size_t)xmax(in_groups, RG) + (size_t)B * PK_MAX_NW * 4;  // xmax[B][16 waves] u32: largest |x| seen by each wave (fused finalize)
+  __host__ __device__ static uint32_t dump(int in_groups, int RG) {  // 1 KiB landing zone per prefetch wave (LDS-DMA needs a destination)
+    return (xmax(in_groups, RG) + (uint32_t)B * PK_MAX_NW * 4u + 15u) & ~15u;
+  }
+  __host__ __device__ static size_t total(int in_groups, int RG, int npw = 0) {
+    return npw ? (size_t)dump(in_groups, RG) + (size_t)npw * 1024
+               : (size_t)xmax(in_groups, RG) + (size_t)B * PK_MAX_NW * 4;  // xmax[B][16 waves] u32: largest |x| seen by each wave (fused finalize)
   }
 };
 
@@ -617,16 +637,38 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   u32x2 flagw = {0u, 0u};
   if constexpr (EB == 3)
     flagw = __builtin_amdgcn_raw_buffer_load_b64(rs_ent, (uint32_t)(lane < Tm1 ? lane : Tm1) * 8u, wbase, 0);
+  // Chain prefetch: the last p.NPW waves of the workgroup take no part in the fill or the loop.  They ask for the NEXT
+  // layer's bytes (LDS-DMA into a 1 KiB dump zone each: no registers, nothing to wait for before the fill barrier) and
+  // meet the others at the barriers.
+  const int NWD = NWB - p.NPW;  // waves that fill and compute
+  const bool pfw = wave >= NWD;
+  if (pfw) {
+    const int pw = wave - NWD;
+    const uint32_t dump = LDS::dump(p.in_groups, p.RG) + (uint32_t)pw * 1024u;
+    const uint8_t* nsrc = p.next_ent + (size_t)block * p.next_block_bytes;
+    for (uint32_t off = (uint32_t)pw * 1024u; off < p.next_block_bytes; off += (uint32_t)p.NPW * 1024u)
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)(nsrc + off + lane * 16), (lds_void_ptr)(size_t)dump, 16, 0, AUX_NT);
+    constexpr uint32_t SHARE = PK_SLICE_BYTES / PK_NG;  // the PK_NG workgroups of a slice split its next-layer image
+    const uint8_t* csrc = p.next_codebook + (size_t)slice * PK_SLICE_BYTES + (size_t)group * SHARE;
+    for (uint32_t off = (uint32_t)pw * 1024u; off < SHARE; off += (uint32_t)p.NPW * 1024u)
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)(csrc + off + lane * 16), (lds_void_ptr)(size_t)dump, 16, 0, 0);
+  }
   // (1) LDS-DMA: the 64 KiB slice (shared by the 16 workgroups of the XCD that hold it -> L2 hits) and x
-  {
+  if (!pfw) {
     const uint8_t* src = p.codebook + (size_t)slice * PK_SLICE_BYTES;
-    for (int i = wave; i < (int)(PK_SLICE_BYTES / 1024); i += NWB)
+    // rotated start: the PK_NG workgroups that fill the same slice from the same L2 walk it from different pieces, so at
+    // any moment they ask different L2 channels (and, cold, each pulls a different part from HBM first)
+    constexpr int PIECES = (int)(PK_SLICE_BYTES / 1024);
+    const int rot = p.fill_rotate ? group * (PIECES / PK_NG) : 0;
+    for (int i0 = wave; i0 < PIECES; i0 += NWD) {
+      const int i = (i0 + rot) & (PIECES - 1);
       __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + i * 1024 + lane * 16),
                                        (lds_void_ptr)(size_t)(LDS::SLICE + (uint32_t)i * 1024u), 16, 0, 0);
+    }
     const int nchunk = (p.in_groups + 63) >> 6;  // KiB pieces per row of x
     // B == 1: XC rotated copies of the row (copy c at slot c * xstride); B > 1: one plane per row
     const int ncopy = B == 1 ? p.XC : B;
-    for (int c = wave; c < nchunk * ncopy; c += NWB) {
+    for (int c = wave; c < nchunk * ncopy; c += NWD) {
       const int b = c / nchunk, i = c - b * nchunk;
       const int idx = i * 64 + lane;
       const uint32_t dst = LDS::X + (uint32_t)b * (B == 1 ? xstride16 : XP) + (uint32_t)i * 1024u;
@@ -637,7 +679,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     // the stream's row starts (needed by the epilogue only; as an LDS-DMA they are older than the ring loads, see (5)).
     // Rows of the table are only 4-B aligned -> dword DMA, 256 B per wave-instruction.
     const uint32_t* rs_src = p.rowstart + (size_t)block * RG1;
-    for (int i = wave; i * 64 < RG1; i += NWB) {
+    for (int i = wave; i * 64 < RG1; i += NWD) {
       const int idx = i * 64 + lane;
       if (idx < RG1)
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rs_src + idx), (lds_void_ptr)(size_t)(rowstart_off + (uint32_t)i * 256u), 4, 0, 0);
@@ -658,7 +700,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   };
   ring_t ring[PD];
 #pragma unroll
-  for (int k = 0; k < PD; ++k) ring[k] = fetch(k);
+  for (int k = 0; k < PD; ++k) ring[k] = fetch(pfw ? 0x7fffffff : k);  // prefetch waves: out-of-range requests (zeros, no memory traffic)
   // (3) steps of this wave through the scalar cache (not a VMEM op: it must not sit in the vmcnt queue, see (5))
   // 4-byte entries need neither: the start rows ride in the entries, and every wave range runs all T steps (the tail of a
   // stream is padded with null entries up to T steps -- the workgroup waits for its full ranges anyway)
@@ -681,7 +723,8 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // the parameters of the epilogue (the non-preloaded tail of the kernel arguments) are fetched NOW, under the LDS fill:
   // left to the compiler their s_load sits at the first use, behind the loop, with its whole latency exposed (0.3 us)
   asm volatile("" : : "s"(p.acc), "s"(p.partial), "s"(p.scales), "s"(p.bias), "s"(p.y), "s"(p.y_row_stride), "s"(p.cb_absmax));
-  __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD) lgkmcnt(0)
+  if (!pfw) __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD) lgkmcnt(0)
+  else __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));                          // prefetch waves: lgkmcnt(0) only
   __builtin_amdgcn_s_barrier();
   AQLM_TRACE(2);
 
@@ -901,20 +944,20 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
           int e = 0;
           (void)frexpf(bound, &e);                               // bound < 2^e (e = 0 for bound == 0)
           const bool finite = bound < __builtin_inff() && fabsf(v[b]) <= 2.f * bound;  // false for NaN / Inf anywhere
-          sh[b] = 47 - e;
+          sh[b] = PK_FIX_BITS - e;
           const long long q = finite ? __float2ll_rn(ldexpf(v[b], sh[b])) : 0ll;
-          mine[b] = ((unsigned long long)q << 10) + (finite ? 1ull : 33ull);
+          mine[b] = ((unsigned long long)q << PK_VAL_SHIFT) + (finite ? 1ull : 1ull + (1ull << PK_CNT_BITS));
           old[b] = __hip_atomic_fetch_add(p.acc + (size_t)b * p.M + row, mine[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const float scale = T_::to_float(p.scales[row]);
         const float bias = p.bias ? T_::to_float(p.bias[row]) : 0.f;
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-          if ((old[b] & 31ull) == (unsigned long long)(PK_S - 1)) {
+          if ((old[b] & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
             const unsigned long long cell = old[b] + mine[b];
-            const long long sum = (long long)cell >> 10;
+            const long long sum = (long long)cell >> PK_VAL_SHIFT;
             float sv = (float)ldexp((double)sum, -sh[b]);
-            if ((cell >> 5) & 31ull) sv = __builtin_nanf("");
+            if ((cell >> PK_CNT_BITS) & PK_CNT_MASK) sv = __builtin_nanf("");
             p.y[(size_t)b * p.y_row_stride + row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
             __hip_atomic_store(p.acc + (size_t)b * p.M + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -945,6 +988,9 @@ struct PackedGemvRest {
   uint16_t* y;
   long y_row_stride;
   float cb_absmax;
+  const uint8_t* next_ent;
+  const uint8_t* next_codebook;
+  uint32_t next_block_bytes;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;
   int dbg;
@@ -955,8 +1001,14 @@ template <class T_, int B, int PD, uint32_t XWIN, int EB>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* codebook, const uint16_t* x, const uint32_t* ent,
                                                                 const uint32_t* rowstart, int in_groups, uint32_t geom, int RG,
                                                                 uint32_t ent_bytes, int M, const PackedGemvRest rest) {
-  const int NW = (int)(geom & 0xffu), XC = (int)((geom >> 8) & 0xffu), T = (int)(geom >> 16);
+  // geom: waves 0..7 | x copies 8..11 | prefetch waves 12..14 | rotated fill 15 | steps 16..31
+  const int NW = (int)(geom & 0xffu), XC = (int)((geom >> 8) & 0xfu), NPW = (int)((geom >> 12) & 7u), T = (int)(geom >> 16);
   PackedGemvParams p;
+  p.NPW = NPW;
+  p.fill_rotate = (int)((geom >> 15) & 1u);
+  p.next_ent = rest.next_ent;
+  p.next_codebook = rest.next_codebook;
+  p.next_block_bytes = rest.next_block_bytes;
   p.ent = ent;
   p.winfo = rest.winfo;
   p.rowstart = rowstart;
@@ -981,7 +1033,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* c
   p.trace = rest.trace;
   p.dbg = rest.dbg;
 #endif
-  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, blockIdx.x, NW);
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, blockIdx.x, NW + NPW);
 }
 
 // Several prepacked layers that multiply the same x (q/k/v, gate/up) in one launch of 256 workgroups per layer; the
@@ -1320,9 +1372,16 @@ struct PackedFused {
   float cb_absmax = 0.f;
 };
 
+// the layer that runs next on the stream (chain prefetch); all null = none
+struct PackedNext {
+  const uint8_t* ent = nullptr;
+  const uint8_t* codebook = nullptr;
+  uint32_t block_bytes = 0;
+};
+
 static int packed_launch_main(const PackedLayout& L, const void* packed, const void* codebook, const uint16_t* x, int nb,
                               long x_row_stride, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                              const char* who, const PackedFused& fused = PackedFused{}) {
+                              const char* who, const PackedFused& fused = PackedFused{}, const PackedNext& next = PackedNext{}) {
   const size_t need = fused.y ? 0 : (size_t)PK_S * nb * L.M * sizeof(float);
   if (need && (!workspace || workspace_bytes < need)) {
     set_last_error("%s: workspace of %zu bytes required, got %zu", who, need, workspace_bytes);
@@ -1356,10 +1415,24 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.trace = workspace && workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
   p.dbg = tuning().packed_debug;
 #endif
+  // chain prefetch: up to `packed_prefetch_waves` extra waves per workgroup (default 2) when a next layer is named
+  int npw = 0;
+  if (next.ent && next.codebook && next.block_bytes) {
+    const int want = tuning().packed_prefetch_waves < 0 ? 0 : (tuning().packed_prefetch_waves == 0 ? 2 : tuning().packed_prefetch_waves);
+    npw = std::min(std::min(want, 7), PK_MAX_NW - L.NW);
+  }
+  const uint32_t rotate = tuning().packed_fill_rotate ? 1u : 0u;
   auto launch = [&](auto kern, auto lds_map) -> int {
-    const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG);
-    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG, npw);
+    if (lds > 160 * 1024) { npw = 0; }
+    const size_t lds_final = decltype(lds_map)::total(L.in_groups, L.RG, npw);
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_final)) return e;
     PackedGemvRest rest{};
+    if (npw) {
+      rest.next_ent = next.ent;
+      rest.next_codebook = next.codebook;
+      rest.next_block_bytes = next.block_bytes;
+    }
     rest.winfo = p.winfo;
     rest.partial = p.partial;
     rest.x_row_stride = p.x_row_stride;
@@ -1373,8 +1446,9 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
     rest.trace = p.trace;
     rest.dbg = p.dbg;
 #endif
-    hipLaunchKernelGGL(kern, dim3(256), dim3(L.NW * 64), lds, stream, p.codebook, p.x, p.ent, p.rowstart, p.in_groups,
-                       (uint32_t)p.NW | ((uint32_t)p.XC << 8) | ((uint32_t)p.T << 16), p.RG, p.ent_bytes, p.M, rest);
+    hipLaunchKernelGGL(kern, dim3(256), dim3((L.NW + npw) * 64), lds_final, stream, p.codebook, p.x, p.ent, p.rowstart, p.in_groups,
+                       (uint32_t)p.NW | ((uint32_t)p.XC << 8) | ((uint32_t)npw << 12) | (rotate << 15) | ((uint32_t)p.T << 16), p.RG,
+                       p.ent_bytes, p.M, rest);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
   return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, launch);
@@ -1408,10 +1482,43 @@ static int packed_check_args(const char* who, const aqlm_hip_packed_desc* desc, 
   return 0;
 }
 
+static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+                                 const void* scales, const void* bias, const void* x, void* y, int batch,
+                                 long x_row_stride, long y_row_stride, int dtype, void* workspace,
+                                 size_t workspace_bytes, void* stream_, const PackedNext& next);
+
 extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                          const void* scales, const void* bias, const void* x, void* y, int batch,
                                          long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                          size_t workspace_bytes, void* stream_) {
+  return gemv_1x16_packed_impl(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, workspace,
+                               workspace_bytes, stream_, PackedNext{});
+}
+
+extern "C" int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+                                               const void* scales, const void* bias, const void* x, void* y, int batch,
+                                               long x_row_stride, long y_row_stride, int dtype, void* workspace,
+                                               size_t workspace_bytes, const aqlm_hip_packed_desc* next_desc,
+                                               const void* next_packed, const void* next_codebook, void* stream_) {
+  PackedNext next;
+  PackedLayout LN;
+  if (next_desc && next_packed && next_codebook) {
+    if (!desc_layout(next_desc, LN) || !aligned16(next_packed) || !aligned16(next_codebook)) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_chain: invalid descriptor / misaligned buffer of the next layer");
+      return AQLM_HIP_E_INVALID;
+    }
+    next.ent = (const uint8_t*)next_packed + LN.off_ent;
+    next.codebook = (const uint8_t*)next_codebook;
+    next.block_bytes = (uint32_t)(LN.ent_bytes / LN.nst);
+  }
+  return gemv_1x16_packed_impl(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, workspace,
+                               workspace_bytes, stream_, next);
+}
+
+static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+                                 const void* scales, const void* bias, const void* x, void* y, int batch,
+                                 long x_row_stride, long y_row_stride, int dtype, void* workspace,
+                                 size_t workspace_bytes, void* stream_, const PackedNext& next) {
   hipStream_t stream = (hipStream_t)stream_;
   PackedLayout L;
   int max_b = 0;
@@ -1430,7 +1537,8 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void*
       fz.y = (uint16_t*)y + (size_t)b0 * y_row_stride;
       fz.y_row_stride = y_row_stride;
       if (int e = packed_launch_main(L, packed, codebook, (const uint16_t*)x + (size_t)b0 * x_row_stride, nb, x_row_stride, dtype,
-                                     workspace, workspace_bytes, stream, "aqlm_hip_gemv_1x16_packed", fz))
+                                     workspace, workspace_bytes, stream, "aqlm_hip_gemv_1x16_packed", fz,
+                                     b0 + nb >= batch ? next : PackedNext{}))
         return e;
       continue;
     }

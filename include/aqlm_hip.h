@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 3
+#define AQLM_HIP_ABI_VERSION 4
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -216,6 +216,20 @@ int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, co
                               const void* scales, const void* bias, const void* x, void* y, int batch,
                               long x_row_stride, long y_row_stride, int dtype, void* workspace, size_t workspace_bytes,
                               void* stream);
+
+/*
+ * aqlm_hip_gemv_1x16_packed that also names the prepacked layer which runs NEXT on the same stream (chain prefetch; no
+ * reference counterpart -- the reference launches each layer cold, cuda_kernel.cpp:148-182): a few extra waves of every
+ * workgroup request the next layer's entry stream and codebook so that they sit in the GPU's L2 / Infinity Cache when the
+ * next launch starts (a batch-1 matvec is bound by the latency of its cold start, not by HBM bandwidth, and HBM idles
+ * most of the kernel).  A hint: results are identical to aqlm_hip_gemv_1x16_packed; next_* may be NULL (then it IS that
+ * call).  The next layer's buffers are only read.
+ */
+int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+                                    const void* scales, const void* bias, const void* x, void* y, int batch,
+                                    long x_row_stride, long y_row_stride, int dtype, void* workspace,
+                                    size_t workspace_bytes, const aqlm_hip_packed_desc* next_desc,
+                                    const void* next_packed, const void* next_codebook, void* stream);
 
 /*
  * aqlm_hip_gemv_1x16_packed for up to AQLM_HIP_MAX_SEGMENTS prepacked layers that share x, in one launch (+ one

@@ -269,22 +269,50 @@ def test_matmat_dequant_mfma(hk, g, fin, fout, B, dt):
         check_close(y2, y64, dtype, f"mfma slabs g{g} {fin}->{fout} B{B}")
 
 
-def test_matmat_dequant_mfma_splitk_free_variant(hk):
-    """The experimental split-K-free 16x16x32 kernel (tuning knob) must agree with the oracle too."""
+def test_matmat_dequant_mfma_register_staged_variant(hk):
+    """The round-1 register-staged split-K kernel stays reachable (tuning knob `gemm_variant` = 1, A/B runs): it must
+    agree with the oracle too, and with the default LDS-DMA pipeline to fp32 round-off."""
     from aqlm_amd import _native
 
-    _native.set_tuning("gemm_splitk_free", 1)
-    try:
-        for g, fin, fout, B, dt in [(8, 4096, 1000, 100, "float16"), (16, 1024, 256, 20, "bfloat16"), (8, 512, 48, 128, "float16")]:
-            dtype = tdtype(dt)
-            L = orc.make_layer(5150 + B, fin, fout, 1, 16, g, batch=B, bias=True,
-                               float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
-            T = to_dev(L, dtype)
-            y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
-            y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-            check_close(y, y64, dtype, f"mfma16 g{g} {fin}->{fout} B{B}")
-    finally:
-        _native.set_tuning("gemm_splitk_free", 0)
+    for g, fin, fout, B, dt in [(8, 4096, 1000, 100, "float16"), (16, 1024, 256, 20, "bfloat16"), (8, 512, 48, 128, "float16")]:
+        dtype = tdtype(dt)
+        L = orc.make_layer(5150 + B, fin, fout, 1, 16, g, batch=B, bias=True,
+                           float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+        T = to_dev(L, dtype)
+        y0 = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+        _native.set_tuning("gemm_variant", 1)
+        try:
+            y1 = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+        finally:
+            _native.set_tuning("gemm_variant", 0)
+        y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y0, y64, dtype, f"mfma lds-dma g{g} {fin}->{fout} B{B}")
+        check_close(y1, y64, dtype, f"mfma register-staged g{g} {fin}->{fout} B{B}")
+
+
+@pytest.mark.parametrize("g,fin,fout,B,dt", [
+    (8, 192, 16, 1, "float16"),          # the shortest K the pipeline takes (3 chunks), one row tile, one column
+    (8, 256, 129, 17, "float16"),        # 4 chunks: prologue + one main iteration + tail; ragged row block
+    (8, 4096, 130, 33, "bfloat16"),      # out % 4 != 0: scalar partial / Y stores, K split
+    (16, 2048, 2048, 64, "float16"),     # g = 16: half-entry fragments, 4-byte code DMA
+    (8, 14336, 4096, 128, "float16"),    # uneven K slices (224 chunks over 8 blocks = 28 each), full tile
+    (8, 5120, 13824, 96, "float16"),     # more row blocks than one round of the chip; 6 batch tiles
+    (8, 2048, 28672, 48, "float16"),     # no K split: the block writes Y itself
+])
+def test_matmat_dequant_mfma_pipeline_shapes(hk, g, fin, fout, B, dt):
+    """Edge cases of the LDS-DMA pipeline (gemm_1x16_glds_kernel): shortest K, ragged rows / batch, unaligned out,
+    both group sizes, uneven K slices, direct epilogue."""
+    dtype = tdtype(dt)
+    L = orc.make_layer(9000 + B + fout, fin, fout, 1, 16, g, batch=B, bias=True,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+    if fin * fout <= 1 << 24:
+        y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    else:  # large layers: W from the C restatement (fp32, exact sums of fp16 entries times an fp16 scale), product in fp64
+        W = c_oracle.dequant_weight(L["codebooks"], L["codes"], L["scales"], 16)
+        y64 = L["x"].astype(np.float64) @ W.T.astype(np.float64) + L["bias"].astype(np.float64)
+    check_close(y, y64, dtype, f"mfma pipeline g{g} {fin}->{fout} B{B}")
 
 
 @pytest.mark.parametrize("K,g", [(2, 8), (1, 8), (8, 32)])

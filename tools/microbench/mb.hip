@@ -366,7 +366,11 @@ static size_t algo_bytes(int in, int out, const Scheme& s, int batch) {
   return n;
 }
 
-static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st) {
+static bool g_chain = false;  // packed 1x16: name the next layer of the graph (chain prefetch)
+static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int batch, hipStream_t st, const Layer* next = nullptr) {
+  if (s.nbits == 16 && s.packed && g_chain && next)
+    return aqlm_hip_gemv_1x16_packed_chain(&L.desc, L.packed, L.cb, L.scales, nullptr, L.x, L.y, batch, in, out, AQLM_HIP_F16, g_ws, g_ws_bytes,
+                                           &next->desc, next->packed, next->cb, st);
   if (s.lut && g_lut_fused)  // g_ws is zero-filled before every variant and left zero by every fused call
     return aqlm_hip_gemv_8x8_lut_fused(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.lut)
@@ -382,12 +386,12 @@ static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int ba
 static double time_graph(const Scheme& s, const std::vector<Layer>& layers, int in, int out, int batch, int reps) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
-  for (const auto& L : layers)
-    if (int rc = launch_layer(s, L, in, out, batch, st)) { fprintf(stderr, "launch failed rc=%d: %s\n", rc, aqlm_hip_last_error()); exit(3); }
+  for (size_t i = 0; i < layers.size(); ++i)
+    if (int rc = launch_layer(s, layers[i], in, out, batch, st, &layers[(i + 1) % layers.size()])) { fprintf(stderr, "launch failed rc=%d: %s\n", rc, aqlm_hip_last_error()); exit(3); }
   CK(hipStreamSynchronize(st));
   hipGraph_t g; hipGraphExec_t ge;
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
-  for (const auto& L : layers) launch_layer(s, L, in, out, batch, st);
+  for (size_t i = 0; i < layers.size(); ++i) launch_layer(s, layers[i], in, out, batch, st, &layers[(i + 1) % layers.size()]);
   CK(hipStreamEndCapture(st, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   CK(hipGraphLaunch(ge, st));
@@ -447,7 +451,7 @@ static void free_layers(std::vector<Layer>& v) {
   for (auto& L : v) { hipFree(L.codes); hipFree(L.cb); hipFree(L.scales); hipFree(L.x); hipFree(L.y); if (L.packed) hipFree(L.packed); }
 }
 
-struct Scheme; static void check_packed(const Scheme& s, const Layer& L, int in, int out);
+struct Scheme; static void check_packed(const Scheme& s, const Layer& L, int in, int out, const Layer* next = nullptr);
 static void bench_gemv(int argc, char** argv) {
   g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
   CK(hipMalloc(&g_ws, g_ws_bytes));
@@ -511,7 +515,13 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"arrange=0", "packed_arrange", 0}});
       }
 
-    } else if (c.s.packed) {
+    } else if (c.s.packed) {  // quick: the round-3 switches
+      variants.push_back({{"rotate=0", "packed_fill_rotate", 0}});
+      variants.push_back({{"chain prefetch (2 waves)", "mb_chain", 2}});
+      variants.push_back({{"chain prefetch (1 wave)", "mb_chain", 1}});
+      variants.push_back({{"chain prefetch (4 waves)", "mb_chain", 4}});
+      variants.push_back({{"chain + rotate=0", "mb_chain", 2}, {"", "packed_fill_rotate", 0}});
+      variants.push_back({{"default again", "packed_fill_rotate", 1}});
     } else if (c.s.lut) {
       variants.push_back({{"two-kernel finalize", "mb_lut_two_kernel", 1}});
     } else if (c.s.nbits == 8 && c.s.g == 8) {
@@ -544,10 +554,12 @@ static void bench_gemv(int argc, char** argv) {
       }
       g_lut_fused = true;
       for (const auto& kv : var) {
-        if (!strcmp(kv.key, "mb_lut_two_kernel")) g_lut_fused = false; else aqlm_hip_set_tuning(kv.key, kv.val);
+        if (!strcmp(kv.key, "mb_lut_two_kernel")) g_lut_fused = false;
+        else if (!strcmp(kv.key, "mb_chain")) { g_chain = true; aqlm_hip_set_tuning("packed_prefetch_waves", kv.val); }
+        else aqlm_hip_set_tuning(kv.key, kv.val);
         vn += kv.name;
       }
-      if (c.s.packed && !var.empty() && !strcmp(var[0].key, "packed_fused_finalize")) check_packed(c.s, layers[0], c.in, c.out);
+      if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_fused_finalize") || !strcmp(var[0].key, "mb_chain") || !strcmp(var[0].key, "packed_fill_rotate"))) check_packed(c.s, layers[0], c.in, c.out, &layers[1]);
       if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange") || !strcmp(var[0].key, "packed_entry_bytes") || !strcmp(var[0].key, "packed_xcopies"))) {  // a format parameter: repack
         const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
         for (auto& L : layers) {
@@ -568,7 +580,10 @@ static void bench_gemv(int argc, char** argv) {
                ab / cold * 1e-3 / 80.0);
         fflush(stdout);
       }
-      for (const auto& kv : var) if (strcmp(kv.key, "mb_lut_two_kernel")) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange") || !strcmp(kv.key, "packed_fused_finalize")) ? 1 : 0);
+      for (const auto& kv : var) {
+        if (!strcmp(kv.key, "mb_chain")) { g_chain = false; aqlm_hip_set_tuning("packed_prefetch_waves", 0); continue; }
+        if (strcmp(kv.key, "mb_lut_two_kernel")) aqlm_hip_set_tuning(kv.key, (!strcmp(kv.key, "kx8_replicas") || !strcmp(kv.key, "packed_arrange") || !strcmp(kv.key, "packed_fused_finalize") || !strcmp(kv.key, "packed_fill_rotate")) ? 1 : 0);
+      }
     }
     free_layers(layers);
   }
@@ -582,15 +597,18 @@ static void bench_trace(int in, int out) {
   const size_t ab1 = algo_bytes(in, out, s, 1);
   int n = (int)((600u << 20) / ab1) + 1;
   auto layers = make_layers(s, in, out, 8, n);
-  const size_t need = (size_t)16 * out * 4;
+  const size_t need = layers[0].desc.codebook_absmax > 0.f ? 0 : (size_t)16 * out * 4;  // fused finalize: no partials ahead of the stamps
   unsigned long long* tr = (unsigned long long*)((char*)g_ws + need);
   const int NWMAX = 16;
   std::vector<unsigned long long> h(256 * NWMAX * 8);
   const int NW = layers[0].desc.waves;
   const char* names[7] = {"entry", "loads issued", "LDS filled (barrier)", "-", "loop done", "2nd barrier", "end"};
-  const int dbgs[6] = {0, 0, 1, 2, 2 | 4, 2 | 8};  // runs: warm-up, full, no compute, no stream, no stream + no dots, no stream + no LDS reads
-  for (int rep = 0; rep < 6; ++rep) {
+  const int NRUN = 8;
+  const int dbgs[NRUN] = {0, 0, 0, 0, 0, 1, 2, 2 | 4};  // runs: warm-up, full x 4 (rotated fill on / off alternating), no compute, no stream, no stream + no dots
+  const int rots[NRUN] = {1, 1, 0, 1, 0, 1, 1, 1};
+  for (int rep = 0; rep < NRUN; ++rep) {
     aqlm_hip_set_tuning("packed_debug", dbgs[rep]);
+    aqlm_hip_set_tuning("packed_fill_rotate", rots[rep]);
     for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
     CK(hipMemset(tr, 0, h.size() * 8));
     CK(hipDeviceSynchronize());
@@ -599,8 +617,8 @@ static void bench_trace(int in, int out) {
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) t0 = std::min(t0, h[(b * NWMAX + w) * 8]);
-    printf("# packed %d->%d cold, run %d [debug %d: 0 full, 1 no LDS reads / dots, 2 no entry stream, +4 no dots, +8 no LDS reads] (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
-           in, out, rep, dbgs[rep], NW, layers[0].desc.steps, 256 * NW);
+    printf("# packed %d->%d cold, run %d [debug %d: 0 full, 1 no LDS reads / dots, 2 no entry stream, +4 no dots, +8 no LDS reads; rotated fill %d] (waves %d, steps %d): time since the first wave's entry, us (min / mean / max over %d waves)\n",
+           in, out, rep, dbgs[rep], rots[rep], NW, layers[0].desc.steps, 256 * NW);
     for (int i = 0; i < 7; ++i) {
       if (i == 3) continue;
       double mn = 1e9, mx = 0, sum = 0;
@@ -636,7 +654,7 @@ static void bench_trace(int in, int out) {
 }
 
 // packed kernel vs the direct kernel on the same layer (quick on-device sanity check; the real parity tests are in tests/)
-static void check_packed(const Scheme& s, const Layer& L, int in, int out) {
+static void check_packed(const Scheme& s, const Layer& L, int in, int out, const Layer* next) {
   for (int batch : {1, 4, 8}) {
     std::vector<uint16_t> y0((size_t)batch * out), y1((size_t)batch * out);
     CK(hipMemset(L.y, 0xff, y0.size() * 2));
@@ -644,7 +662,7 @@ static void check_packed(const Scheme& s, const Layer& L, int in, int out) {
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(y0.data(), L.y, y0.size() * 2, hipMemcpyDeviceToHost));
     CK(hipMemset(L.y, 0xff, y0.size() * 2));
-    rc |= launch_layer(s, L, in, out, batch, nullptr);
+    rc |= launch_layer(s, L, in, out, batch, nullptr, next);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(y1.data(), L.y, y1.size() * 2, hipMemcpyDeviceToHost));
     auto h2f = [](uint16_t h) { _Float16 f; memcpy(&f, &h, 2); return (double)(float)f; };
@@ -692,12 +710,12 @@ static void bench_gemm(bool nosync) {
       int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
       if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
     });
-    // split-K-free kernel: same entry point behind the tuning knob; cross-check Y against the split-K result first
+    // round-1 register-staged split-K kernel: same entry point behind the tuning knob; cross-check Y against the default first
     std::vector<uint16_t> y0((size_t)B * out), y1((size_t)B * out);
     aqlm_hip_gemm_1x16_mfma(layers[0].codes, layers[0].cb, layers[0].scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(y0.data(), Y, y0.size() * 2, hipMemcpyDeviceToHost));
-    aqlm_hip_set_tuning("gemm_splitk_free", 1);
+    aqlm_hip_set_tuning("gemm_variant", 1);
     CK(hipMemset(Y, 0xff, y1.size() * 2));
     aqlm_hip_gemm_1x16_mfma(layers[0].codes, layers[0].cb, layers[0].scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, nullptr);
     CK(hipDeviceSynchronize());
@@ -706,20 +724,20 @@ static void bench_gemm(bool nosync) {
       auto h2f = [](uint16_t h) { _Float16 f; memcpy(&f, &h, 2); return (float)f; };
       double num = 0, den = 0; size_t same = 0;
       for (size_t i = 0; i < y0.size(); ++i) { num += fabs(h2f(y0[i]) - h2f(y1[i])); den += fabs(h2f(y0[i])); same += y0[i] == y1[i]; }
-      printf("# split-K-free vs split-K: mean-rel diff %.3e, %zu of %zu bit-identical\n", num / den, same, y0.size());
+      printf("# LDS-DMA pipeline vs register-staged kernel: mean-rel diff %.3e, %zu of %zu bit-identical%s\n", num / den, same, y0.size(), num / den < 1e-3 ? "" : "   <-- MISMATCH");
     }
     const double free_us = time_it([&](const Layer& L, hipStream_t st) {
       int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
       if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
     });
-    aqlm_hip_set_tuning("gemm_splitk_free", 0);
+    aqlm_hip_set_tuning("gemm_variant", 0);
     fprintf(stderr, "B=%d dequant\n", B);
     const double deq = time_it([&](const Layer& L, hipStream_t st) {
       aqlm_hip_dequant_1x16(L.codes, L.cb, L.scales, W, out, in, 8, AQLM_HIP_F16, st);
     });
     const double flop = 2.0 * B * in * out;
-    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (split-K)", B, fused, flop / fused * 1e-6);
-    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (split-K-free)", B, free_us, flop / free_us * 1e-6);
+    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (LDS-DMA)", B, fused, flop / fused * 1e-6);
+    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (round 1)", B, free_us, flop / free_us * 1e-6);
     printf("%-28s %5d %10.2f %10s   (reference pipeline = this + a %d x %d x %d library GEMM)\n", "dequant_1x16 alone", B, deq, "-", B, out, in);
     hipFree(X); hipFree(Y); hipFree(W); hipFree(ws);
     free_layers(layers);
