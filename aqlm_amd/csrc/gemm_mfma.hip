@@ -291,27 +291,39 @@ struct GldsParams {
   int M, B, in_groups;
   int row_blocks, ksplit;
   int chunks_base, chunks_rem;  // K slice ks covers chunks_base + (ks < chunks_rem) chunks of 64 k
+  int store_nt;                 // partial stores with the non-temporal hint (tuning knob, A/B runs)
+  int dbg;                      // knock-out switches for timing experiments (results are wrong): 1 no MFMA, 2 no fragment reads, 4 no stores, 8 no X DMA, 16 gathers from one line
 };
 
 constexpr int GL_NS = 4;       // stages of the W / X ring
 constexpr int GL_NSLOT = 8;    // slots of a wave's code ring (>= GL_NS + 1, power of two)
-constexpr int GL_WAVES = 8;
+constexpr int GL_WAVES = 8;      // consumer waves (16 output rows each)
+constexpr int GL_PRODUCERS = 4;  // DMA waves
 constexpr uint32_t GL_W_BYTES = GL_WAVES * 2048u;  // per stage: 2 fragments of 1 KiB per wave
 
 template <int XW>
 struct GldsLds {
   static constexpr uint32_t X_BYTES = XW * 64u * 128u;        // XW * 64 batch rows x 64 k
-  static constexpr uint32_t STAGE = GL_W_BYTES + X_BYTES;
-  static constexpr uint32_t CODES = GL_NS * STAGE;            // [wave][slot][256 B]
-  static constexpr uint32_t TOTAL = CODES + GL_WAVES * GL_NSLOT * 256u;
+  static constexpr uint32_t W_BYTES = GL_W_BYTES;             // per stage: 2 fragments of 1 KiB per consumer wave
+  static constexpr uint32_t STAGE = W_BYTES + X_BYTES;
+  static constexpr uint32_t CODES = GL_NS * STAGE;            // [producer][slot][512 B]
+  static constexpr uint32_t TOTAL = CODES + GL_PRODUCERS * GL_NSLOT * 512u;
 };
 
 constexpr int gl_vmcnt(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }  // vmcnt(n) only
 
+// Roles.  Measured with every wave doing both jobs (round 3, profiles/r03_mb_gemm_symmetric.log): a chunk took
+// TA time + compute time -- a wave that is issuing LDS-DMA sits in the issue stage while the texture addresser works
+// through the 64 scattered lines of each gather (its queue is a few instructions deep), and the addresser idles while the
+// waves compute.  So the block is split: 8 consumer waves (16 rows each) only read fragments and run MFMAs, 4 producer
+// waves (one per SIMD) only issue DMA -- codes, gathers, X -- and are parked in the issue stage almost all the time,
+// which keeps the addresser fed.  One s_barrier per chunk joins them: the producers arrive when the chunk's DMA has
+// landed (counted vmcnt), the consumers when they are done with the previous chunk (whose stage is refilled next).
 template <class T, int G, int NBT, int XW>  // NBT = 16-column batch tiles computed; XW * 64 = batch rows staged
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_1x16_glds_kernel(const GldsParams p) {
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_1x16_glds_kernel(const GldsParams p) {
   using LDS = GldsLds<XW>;
-  constexpr int P = 1 + 2 + XW;  // LDS-DMA operations per wave and issue iteration: codes, 2 fragments, XW pieces of X
+  constexpr int P = 1 + 4 + 2 * XW;  // LDS-DMA operations per producer wave and chunk: codes, 4 fragments, 2 XW pieces of X
+  static_assert((GL_NS - 2) * P < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map below starts at 0
   const int tid = threadIdx.x, lane = tid & 63;
@@ -325,163 +337,201 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (row_blk >= p.row_blocks) return;
   const int n = p.chunks_base + (ks < p.chunks_rem ? 1 : 0);                                // chunks of this block, >= GL_NS - 1
   const int chunk0 = ks * p.chunks_base + (ks < p.chunks_rem ? ks : p.chunks_rem);
-  const int row0 = row_blk * 128 + wave * 16;
 
-  // ---- per-lane source addresses ------------------------------------------------------------------------------
-  // codes: g = 8: lanes 0..15 move 16 B (8 codes) of row row0 + lane; g = 16: lanes 0..31 move 4 B (2 codes) each
-  constexpr int CODE_LANES = G == 8 ? 16 : 32;
-  constexpr int CODE_BYTES_PER_CHUNK = G == 8 ? 16 : 8;  // per row
-  const uint8_t* code_src;
-  {
-    int r = row0 + (G == 8 ? lane : (lane >> 1));
-    r = r < p.M ? r : p.M - 1;
-    code_src = p.codes + ((size_t)r * p.in_groups) * 2 + (size_t)chunk0 * CODE_BYTES_PER_CHUNK + (G == 8 ? 0 : (lane & 1) * 4);
-  }
-  // X: piece (wave * XW + x) of a chunk image = 64 slots of 16 B; slot s holds batch row s >> 3, k piece (s & 7) ^ swizzle
-  const uint8_t* x_src[XW];
-#pragma unroll
-  for (int x = 0; x < XW; ++x) {
-    const int s = (wave * XW + x) * 64 + lane;
-    int b = s >> 3;
-    const int c = (s & 7) ^ ((b >> 1) & 7);
-    b = b < p.B ? b : p.B - 1;  // rows past the batch: a valid row, computed and never stored
-    x_src[x] = (const uint8_t*)(p.X + (size_t)b * p.xs + (size_t)chunk0 * 64 + c * 8);
-  }
-  const uint32_t code_ring = LDS::CODES + (uint32_t)wave * (GL_NSLOT * 256u);
-  // this lane's two codes of a chunk inside a ring slot (k step s: g = 8 code 4 s + kg; g = 16 code 2 s + kg / 2)
-  const uint32_t code_off0 = G == 8 ? (uint32_t)arow * 16u + (uint32_t)kg * 2u : (uint32_t)arow * 8u + (uint32_t)(kg >> 1) * 2u;
-  constexpr uint32_t CODE_STEP = G == 8 ? 8u : 4u;  // bytes between the codes of k step 0 and k step 1
-  const uint32_t half_off = G == 8 ? 0u : (uint32_t)(kg & 1) * 16u;
-
-  auto dma_codes = [&](int chunk) {  // chunk may run past the slice: clamped (the slot is written, never used)
-    const int cc = chunk < n ? chunk : n - 1;
-    if (lane < CODE_LANES) {
-      ggbl_void_ptr src = (ggbl_void_ptr)(code_src + (size_t)cc * CODE_BYTES_PER_CHUNK);
-      glds_void_ptr dst = (glds_void_ptr)(size_t)(code_ring + (uint32_t)(chunk & (GL_NSLOT - 1)) * 256u);
-      if constexpr (G == 8) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-      else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+  if (wave >= GL_WAVES) {
+    // ============================================ producer ============================================================
+    const int pw = wave - GL_WAVES;                 // serves consumer waves 2 pw and 2 pw + 1: 32 rows
+    if (!(p.dbg & 32)) __builtin_amdgcn_s_setprio(3);  // the address arithmetic of the DMA wave goes ahead of the consumers' issue slots
+    const int prow0 = row_blk * 128 + pw * 32;
+    // codes: g = 8: lanes 0..31 move 16 B (8 codes) of row prow0 + lane; g = 16: all lanes move 4 B (2 codes), row lane / 2
+    constexpr int CODE_LANES = G == 8 ? 32 : 64;
+    constexpr int CODE_BYTES_PER_CHUNK = G == 8 ? 16 : 8;  // per row
+    const uint8_t* code_src;
+    {
+      int r = prow0 + (G == 8 ? lane : (lane >> 1));
+      r = r < p.M ? r : p.M - 1;
+      code_src = p.codes + ((size_t)r * p.in_groups) * 2 + (size_t)chunk0 * CODE_BYTES_PER_CHUNK + (G == 8 ? 0 : (lane & 1) * 4);
     }
-  };
-  auto read_codes = [&](int chunk, uint32_t (&c)[2]) {
-    const uint32_t a = code_ring + (uint32_t)(chunk & (GL_NSLOT - 1)) * 256u + code_off0;
-    c[0] = *(glds_u16_ptr)(size_t)(a);
-    c[1] = *(glds_u16_ptr)(size_t)(a + CODE_STEP);
-  };
-  auto dma_stage = [&](int chunk, int stage, const uint32_t (&c)[2]) {
-    const uint32_t base = (uint32_t)stage * LDS::STAGE;
+    // X: piece (pw * 2 XW + x) of a chunk image = 64 slots of 16 B; slot s holds batch row s >> 3, k piece (s & 7) ^ swizzle
+    const uint8_t* x_src[2 * XW];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebook + (size_t)c[s] * (G * 2) + half_off),
-                                       (glds_void_ptr)(size_t)(base + (uint32_t)wave * 2048u + (uint32_t)s * 1024u), 16, 0, 0);
-#pragma unroll
-    for (int x = 0; x < XW; ++x)
-      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (size_t)chunk * 128),
-                                       (glds_void_ptr)(size_t)(base + GL_W_BYTES + (uint32_t)(wave * XW + x) * 1024u), 16, 0, 0);
-  };
+    for (int x = 0; x < 2 * XW; ++x) {
+      const int s = (pw * 2 * XW + x) * 64 + lane;
+      int b = s >> 3;
+      const int c = (s & 7) ^ ((b >> 1) & 7);
+      b = b < p.B ? b : p.B - 1;  // rows past the batch: a valid row, computed and never stored
+      x_src[x] = (const uint8_t*)(p.X + (size_t)b * p.xs + (size_t)chunk0 * 64 + c * 8);
+    }
+    const uint32_t code_ring = LDS::CODES + (uint32_t)pw * (GL_NSLOT * 512u);
+    // this lane's codes of a chunk inside a ring slot: consumer wave cw, k step s -> row 16 cw + arow; g = 8: code 4 s + kg,
+    // g = 16: code 2 s + kg / 2 (and the lane takes the 16-B half kg & 1 of the 32-B entry)
+    constexpr uint32_t ROW_BYTES = G == 8 ? 16u : 8u;
+    constexpr uint32_t CODE_STEP = G == 8 ? 8u : 4u;  // bytes between the codes of k step 0 and k step 1
+    const uint32_t code_off0 = (uint32_t)arow * ROW_BYTES + (G == 8 ? (uint32_t)kg * 2u : (uint32_t)(kg >> 1) * 2u);
+    const uint32_t half_off = G == 8 ? 0u : (uint32_t)(kg & 1) * 16u;
 
-  f32x4 acc[NBT];
+    auto dma_codes = [&](int chunk) {  // chunk may run past the slice: clamped (the slot is written, never used)
+      const int cc = chunk < n ? chunk : n - 1;
+      if (lane < CODE_LANES) {
+        ggbl_void_ptr src = (ggbl_void_ptr)(code_src + (size_t)cc * CODE_BYTES_PER_CHUNK);
+        glds_void_ptr dst = (glds_void_ptr)(size_t)(code_ring + (uint32_t)(chunk & (GL_NSLOT - 1)) * 512u);
+        if constexpr (G == 8) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+      }
+    };
+    auto read_codes = [&](int chunk, uint32_t (&c)[4]) {
+      const uint32_t a = code_ring + (uint32_t)(chunk & (GL_NSLOT - 1)) * 512u + code_off0;
 #pragma unroll
-  for (int t = 0; t < NBT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](int stage) {
+      for (int cw = 0; cw < 2; ++cw)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) c[cw * 2 + s] = *(glds_u16_ptr)(size_t)(a + (uint32_t)cw * (16u * ROW_BYTES) + (uint32_t)s * CODE_STEP);
+    };
+    auto dma_stage = [&](int chunk, int stage, const uint32_t (&c)[4]) {
+      const uint32_t base = (uint32_t)stage * LDS::STAGE;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)  // fragment f = (consumer wave 2 pw + f / 2, k step f % 2)
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebook + (size_t)((p.dbg & 16) ? (c[f] & 7u) : c[f]) * (G * 2) + half_off),
+                                         (glds_void_ptr)(size_t)(base + (uint32_t)(2 * pw) * 2048u + (uint32_t)f * 1024u), 16, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 2 * XW; ++x)
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (size_t)((p.dbg & 8) ? 0 : chunk) * 128),
+                                         (glds_void_ptr)(size_t)(base + LDS::W_BYTES + (uint32_t)(pw * 2 * XW + x) * 1024u), 16, 0, 0);
+    };
+    // prologue: codes of the first NS chunks (one exposed round trip: the gathers depend on them), then NS - 1 issue
+    // iterations.  Issue iteration i: codes of chunk i + 2 NS - 1, stage of chunk q = i + NS - 1, read back the codes of
+    // chunk q + 1 (their DMA is NS iterations old: covered by the wait that opens iteration i).
+    uint32_t creg[4];
+#pragma unroll
+    for (int j = 0; j < GL_NS; ++j) dma_codes(j);
+    __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
+    read_codes(0, creg);
+#pragma unroll
+    for (int i = -(GL_NS - 1); i < 0; ++i) {
+      const int q = i + GL_NS - 1;
+      dma_codes(q + GL_NS);
+      dma_stage(q, q, creg);
+      read_codes(q + 1, creg);
+    }
+    int stage = 0;  // = i % NS
+    int i = 0;
+    for (; i + GL_NS - 1 < n; ++i) {
+      __builtin_amdgcn_s_waitcnt(gl_vmcnt((GL_NS - 2) * P));  // what this wave issued NS - 1 iterations ago has landed
+      __builtin_amdgcn_s_barrier();                           // chunk i is complete; the consumers are done with chunk i - 1
+      const int q = i + GL_NS - 1;
+      const int qstage = stage == 0 ? GL_NS - 1 : stage - 1;  // = q % NS
+      dma_codes(q + GL_NS);
+      dma_stage(q, qstage, creg);
+      read_codes(q + 1, creg);
+      stage = stage == GL_NS - 1 ? 0 : stage + 1;
+    }
+    static_assert(GL_NS == 4, "the tail below is written out for three iterations");
+    __builtin_amdgcn_s_waitcnt(gl_vmcnt(2 * P));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(gl_vmcnt(1 * P));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // ============================================== consumer ==============================================================
+  // register blocking: a wave owns RT row tiles x CT batch tiles (2 x NBT / 2 from two batch tiles on): per k step
+  // RT + CT fragment reads feed RT * CT MFMAs -- the consumers' ds_reads share the LDS port with the landing DMA
+  constexpr int RT = NBT >= 2 ? 2 : 1, CT = NBT / RT;
+  static_assert(RT * CT == NBT, "batch tiles split evenly");
+  const int rp = wave % (GL_WAVES / RT), bh = wave / (GL_WAVES / RT);  // row-tile group, batch-tile group
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int stage = 0;
+  for (int c = 0; c < n; ++c) {
+    __builtin_amdgcn_s_barrier();
     const uint32_t base = (uint32_t)stage * LDS::STAGE;
     // all fragment reads of the chunk are issued before the first MFMA (left alone, hipcc pairs every read with an
     // lgkmcnt(0) and the wave pays one LDS latency per MFMA)
-    u32x4 a[2], b[2][NBT];
+    if (p.dbg & 2) continue;
+    u32x4 a[2][RT], b[2][CT];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      a[s] = *(glds_u32x4_ptr)(size_t)(base + (uint32_t)wave * 2048u + (uint32_t)s * 1024u + (uint32_t)lane * 16u);
 #pragma unroll
-      for (int t = 0; t < NBT; ++t)
-        b[s][t] = *(glds_u32x4_ptr)(size_t)(base + GL_W_BYTES + (uint32_t)xswz(t * 16 + arow, s * 4 + kg) * 16u);
+      for (int j = 0; j < RT; ++j)
+        a[s][j] = *(glds_u32x4_ptr)(size_t)(base + (uint32_t)(rp * RT + j) * 2048u + (uint32_t)s * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+        b[s][t] = *(glds_u32x4_ptr)(size_t)(base + LDS::W_BYTES + (uint32_t)xswz((bh * CT + t) * 16 + arow, s * 4 + kg) * 16u);
     }
-    asm volatile("" ::: "memory");  // keep the reads above the MFMAs (and the next iteration's DMA below them)
+    if (p.dbg & 1) {  // reads kept alive, no matrix work
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int t = 0; t < NBT; ++t) acc[t] = mfma16<T>(a[s], b[s][t], acc[t]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + NBT), 0);  // DS reads first ...
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NBT, 0);        // ... then the MFMAs
-  };
-
-  // ---- prologue: codes of the first NS chunks (one exposed round trip: the gathers depend on them), then NS - 1
-  // issue iterations.  Issue iteration i: codes of chunk i + 2 NS - 1, stage of chunk q = i + NS - 1, read back the
-  // codes of chunk q + 1 (their DMA is NS iterations old: covered by the wait that opens compute iteration i).
-  uint32_t creg[2];
+        for (int j = 0; j < RT; ++j)
 #pragma unroll
-  for (int j = 0; j < GL_NS; ++j) dma_codes(j);
-  __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
-  read_codes(0, creg);
+          for (int t = 0; t < CT; ++t) acc[j][t][0] += __uint_as_float((a[s][j].x ^ b[s][t].y) & 0x007fffffu);
+    } else {
 #pragma unroll
-  for (int i = -(GL_NS - 1); i < 0; ++i) {
-    const int q = i + GL_NS - 1;
-    dma_codes(q + GL_NS);
-    dma_stage(q, q, creg);
-    read_codes(q + 1, creg);
-  }
-  // ---- main loop: compute chunk i, issue chunk i + NS - 1 -------------------------------------------------------
-  int stage = 0;  // = i % NS
-  int i = 0;
-  for (; i + GL_NS - 1 < n; ++i) {
-    __builtin_amdgcn_s_waitcnt(gl_vmcnt((GL_NS - 2) * P));  // everything this wave issued NS - 1 iterations ago has landed
-    __builtin_amdgcn_s_barrier();                           // ... and everybody else's; the stage of chunk i - 1 is free
-    const int q = i + GL_NS - 1;
-    const int qstage = stage == 0 ? GL_NS - 1 : stage - 1;  // = q % NS
-    dma_codes(q + GL_NS);
-    dma_stage(q, qstage, creg);
-    compute(stage);
-    read_codes(q + 1, creg);
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[j][t] = mfma16<T>(a[s][j], b[s][t], acc[j][t]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RT + CT), 0);  // DS reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NBT, 0);        // ... then the MFMAs
+    }
     stage = stage == GL_NS - 1 ? 0 : stage + 1;
   }
-  // ---- tail: the last NS - 1 chunks, nothing left to issue --------------------------------------------------------
-  static_assert(GL_NS == 4, "the tail below is written out for three iterations");
-  __builtin_amdgcn_s_waitcnt(gl_vmcnt(2 * P));
-  __builtin_amdgcn_s_barrier();
-  compute(stage);
-  stage = stage == GL_NS - 1 ? 0 : stage + 1;
-  __builtin_amdgcn_s_waitcnt(gl_vmcnt(1 * P));
-  __builtin_amdgcn_s_barrier();
-  compute(stage);
-  stage = stage == GL_NS - 1 ? 0 : stage + 1;
-  __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
-  __builtin_amdgcn_s_barrier();
-  compute(stage);
 
-  // ---- epilogue: lane (arow, kg) holds rows row0 + 4 kg .. + 3 of batch column 16 t + arow --------------------------
-  const int m = row0 + kg * 4;
+  // ---- epilogue: lane (arow, kg) holds rows 4 kg .. 4 kg + 3 of row tile rp RT + j, batch column 16 (bh CT + t) + arow ------
+  if (p.dbg & 4) {  // no stores (one lane keeps the accumulators alive)
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) v += acc[j][t][0] + acc[j][t][1] + acc[j][t][2] + acc[j][t][3];
+    if (v == 1.2345e-30f) p.partial[0] = v;
+    return;
+  }
   const bool vec = (p.M & 3) == 0;  // 16-B aligned partial rows / 8-B aligned Y rows
-  if (p.ksplit > 1) {
-    float* out = p.partial + (size_t)ks * p.B * p.M;
 #pragma unroll
-    for (int t = 0; t < NBT; ++t) {
-      const int b = t * 16 + arow;
-      if (b < p.B && m < p.M) {
-        float* dst = out + (size_t)b * p.M + m;
-        if (vec) *reinterpret_cast<f32x4*>(dst) = acc[t];
-        else
-          for (int r = 0; r < 4; ++r)
-            if (m + r < p.M) dst[r] = acc[t][r];
+  for (int j = 0; j < RT; ++j) {
+    const int m = row_blk * 128 + (rp * RT + j) * 16 + kg * 4;
+    if (p.ksplit > 1) {
+      float* out = p.partial + (size_t)ks * p.B * p.M;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int b = (bh * CT + t) * 16 + arow;
+        if (b < p.B && m < p.M) {
+          float* dst = out + (size_t)b * p.M + m;
+          if (vec) {
+            if (p.store_nt) __builtin_nontemporal_store(acc[j][t], reinterpret_cast<f32x4*>(dst));
+            else *reinterpret_cast<f32x4*>(dst) = acc[j][t];
+          } else
+            for (int r = 0; r < 4; ++r)
+              if (m + r < p.M) dst[r] = acc[j][t][r];
+        }
       }
-    }
-  } else {
-    float sc[4], bi[4];
+    } else {
+      float sc[4], bi[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int mm = m + r < p.M ? m + r : p.M - 1;
-      sc[r] = T::to_float(p.scales[mm]);
-      bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m + r < p.M ? m + r : p.M - 1;
+        sc[r] = T::to_float(p.scales[mm]);
+        bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+      }
 #pragma unroll
-    for (int t = 0; t < NBT; ++t) {
-      const int b = t * 16 + arow;
-      if (b < p.B && m < p.M) {
-        uint16_t* dst = p.Y + (size_t)b * p.ys + m;
-        uint16_t h[4];
+      for (int t = 0; t < CT; ++t) {
+        const int b = (bh * CT + t) * 16 + arow;
+        if (b < p.B && m < p.M) {
+          uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+          uint16_t h[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(acc[t][r], sc[r], bi[r]));
-        if (vec && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
-        else
-          for (int r = 0; r < 4; ++r)
-            if (m + r < p.M) dst[r] = h[r];
+          for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(acc[j][t][r], sc[r], bi[r]));
+          if (vec && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+          else
+            for (int r = 0; r < 4; ++r)
+              if (m + r < p.M) dst[r] = h[r];
+        }
       }
     }
   }
@@ -496,7 +546,7 @@ struct GldsFinalizeParams {
   const uint16_t* bias;
   uint16_t* Y;
   long ys;
-  int M, B, ksplit, row_blocks, bchunks;
+  int M, B, ksplit, row_blocks, bchunks, rb_rows;  // rb_rows: rows of a row block (128 or 64), 32 threads x 4 rows cover 128
 };
 
 template <class T>
@@ -505,12 +555,21 @@ __global__ __launch_bounds__(256) void gemm_glds_finalize_kernel(const GldsFinal
   const int rb_hi = slot / p.bchunks;
   const int row_blk = rb_hi * 8 + xcd, bc = slot - rb_hi * p.bchunks;
   if (row_blk >= p.row_blocks) return;
+  // a block covers 128 consecutive rows: one row block of the main kernel, or two of its 64-row blocks (same XCD pairing
+  // is not attempted for those: speed only)
   const int m = row_blk * 128 + ((int)threadIdx.x & 31) * 4;
   const int b = bc * 8 + ((int)threadIdx.x >> 5);
   if (m >= p.M || b >= p.B) return;
   const size_t plane = (size_t)p.B * p.M;
   const float* src = p.partial + (size_t)b * p.M + m;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float sc[4], bi[4];  // requested before the partials: one exposed round trip instead of two
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mm = m + r < p.M ? m + r : p.M - 1;
+    sc[r] = T::to_float(p.scales[mm]);
+    bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+  }
   if ((p.M & 3) == 0) {
     int k = 0;
     for (; k + 8 <= p.ksplit; k += 8) {
@@ -534,12 +593,7 @@ __global__ __launch_bounds__(256) void gemm_glds_finalize_kernel(const GldsFinal
   }
   uint16_t h[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int mm = m + r < p.M ? m + r : p.M - 1;
-    const float sc = T::to_float(p.scales[mm]);
-    const float bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
-    h[r] = T::from_float(__builtin_fmaf(s[r], sc, bi));
-  }
+  for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(s[r], sc[r], bi[r]));
   uint16_t* dst = p.Y + (size_t)b * p.ys + m;
   if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
   else
@@ -548,14 +602,15 @@ __global__ __launch_bounds__(256) void gemm_glds_finalize_kernel(const GldsFinal
 }
 
 struct GldsPlan {
-  int row_blocks, ksplit, chunks_base, chunks_rem, nbt, xw;
+  int row_blocks, ksplit, chunks_base, chunks_rem, nbt, xw, wk;
 };
 
 // K split: enough blocks for one round of the chip, K slices of >= 8 chunks (512 k) where K allows, never fewer than
 // NS - 1 chunks (the pipeline's prologue), chunks dealt evenly.
-static bool plan_glds(int B, int M, int K, GldsPlan& g) {
+static bool plan_glds(int B, int M, int K, GldsPlan& g, int wk = 0) {
   const int kchunks = K / BK;
   if (K % BK != 0 || kchunks < GL_NS - 1 || B < 1 || B > 128) return false;
+  g.wk = 1;
   g.row_blocks = (M + 127) / 128;
   int ksplit = std::max(1, 256 / g.row_blocks);
   ksplit = std::min(ksplit, std::max(1, kchunks / 8));
@@ -571,11 +626,11 @@ static bool plan_glds(int B, int M, int K, GldsPlan& g) {
 
 template <class T, int G>
 static int launch_glds(const GldsParams& p, const GldsPlan& g, hipStream_t stream) {
-  const int rb8 = (p.row_blocks + 7) / 8;
-  const dim3 grid((unsigned)(8 * rb8 * p.ksplit));
+  const int rb8 = ((p.M + 127) / 128 + 7) / 8;  // 128-row groups per XCD
+  const dim3 grid((unsigned)(8 * rb8 * g.wk * p.ksplit));
   auto go = [&](auto kern, size_t lds) -> int {
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3((GL_WAVES + GL_PRODUCERS) * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemm_1x16_glds launch");
   };
   switch (g.nbt) {
@@ -636,8 +691,9 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   const GemmPlan g = plan_gemm(batch, out_features, in_features);
   size_t need = (size_t)g.ksplit * out_features * g.Bpad * sizeof(float);
   GldsPlan q;
-  if (plan_glds(std::min(batch, 128), out_features, in_features, q) && q.ksplit > 1)
-    need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
+  for (int wk = 1; wk <= 2; ++wk)  // whichever block shape the tuning picks at call time
+    if (plan_glds(std::min(batch, 128), out_features, in_features, q, wk) && q.ksplit > 1)
+      need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
   return need;
 }
 
@@ -695,6 +751,8 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
       gp.ksplit = q.ksplit;
       gp.chunks_base = q.chunks_base;
       gp.chunks_rem = q.chunks_rem;
+      gp.store_nt = tuning().gemm_store_nt;
+      gp.dbg = tuning().gemm_debug;
       int e;
       if (dtype == AQLM_HIP_F16)
         e = in_group_size == 8 ? launch_glds<F16, 8>(gp, q, stream) : launch_glds<F16, 16>(gp, q, stream);
@@ -711,9 +769,10 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
         f.M = out_features;
         f.B = nb;
         f.ksplit = q.ksplit;
-        f.row_blocks = q.row_blocks;
+        f.row_blocks = (out_features + 127) / 128;
         f.bchunks = (nb + 7) / 8;
-        const dim3 grid((unsigned)(8 * ((q.row_blocks + 7) / 8) * f.bchunks));
+        f.rb_rows = 128 / q.wk;
+        const dim3 grid((unsigned)(8 * ((f.row_blocks + 7) / 8) * f.bchunks));
         if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(gemm_glds_finalize_kernel<F16>, grid, dim3(256), 0, stream, f);
         else hipLaunchKernelGGL(gemm_glds_finalize_kernel<BF16>, grid, dim3(256), 0, stream, f);
         if (int e2 = check_hip(hipGetLastError(), "gemm_glds_finalize launch")) return e2;

@@ -306,13 +306,20 @@ def test_matmat_dequant_mfma_pipeline_shapes(hk, g, fin, fout, B, dt):
     L = orc.make_layer(9000 + B + fout, fin, fout, 1, 16, g, batch=B, bias=True,
                        float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
     T = to_dev(L, dtype)
-    y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
     if fin * fout <= 1 << 24:
         y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
     else:  # large layers: W from the C restatement (fp32, exact sums of fp16 entries times an fp16 scale), product in fp64
         W = c_oracle.dequant_weight(L["codebooks"], L["codes"], L["scales"], 16)
         y64 = L["x"].astype(np.float64) @ W.T.astype(np.float64) + L["bias"].astype(np.float64)
-    check_close(y, y64, dtype, f"mfma pipeline g{g} {fin}->{fout} B{B}")
+    from aqlm_amd import _native
+
+    for wk in (0, 1, 2):  # block shape: by batch size (default), 128 rows, 64 rows with the k steps on two waves
+        _native.set_tuning("gemm_wk", wk)
+        try:
+            y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+        finally:
+            _native.set_tuning("gemm_wk", 0)
+        check_close(y, y64, dtype, f"mfma pipeline g{g} {fin}->{fout} B{B} wk{wk}")
 
 
 @pytest.mark.parametrize("K,g", [(2, 8), (1, 8), (8, 32)])

@@ -609,9 +609,11 @@ static void bench_trace(int in, int out) {
   for (int rep = 0; rep < NRUN; ++rep) {
     aqlm_hip_set_tuning("packed_debug", dbgs[rep]);
     aqlm_hip_set_tuning("packed_fill_rotate", rots[rep]);
-    for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);  // evict layer 0 from every cache
+    // steady state: the traced launch follows n - 1 launches of other layers back to back (they evict layer 0 from every
+    // cache, keep the clocks up and the instruction cache warm; every launch stamps the same buffer, the last one stays)
     CK(hipMemset(tr, 0, h.size() * 8));
     CK(hipDeviceSynchronize());
+    for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);
     launch_layer(s, layers[0], in, out, 1, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
@@ -706,10 +708,23 @@ static void bench_gemm(bool nosync) {
       return ms * 1e3 / (5.0 * layers.size());
     };
     fprintf(stderr, "B=%d wsb=%zu fused\n", B, wsb);
-    const double fused = time_it([&](const Layer& L, hipStream_t st) {
-      int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
-      if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
-    });
+    auto run_fused = [&]() {
+      return time_it([&](const Layer& L, hipStream_t st) {
+        int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
+        if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
+      });
+    };
+    const double fused = run_fused();
+    if (getenv("MB_GEMM_SWEEP")) {  // knock-out runs of the LDS-DMA pipeline (timing only: the results are wrong)
+      const struct { int dbg; const char* what; } ko[] = {{1, "no MFMA"}, {3, "no MFMA, no fragment reads"}, {4, "no stores"}, {8, "no X stream"}, {16, "gathers from one line"},
+                                                         {7, "no MFMA / reads / stores"}, {15, "DMA of the gathers only"}, {31, "nothing but the skeleton"}, {32, "full, producers without priority"}, {0, "full again"}, {32, "full, producers without priority"}, {0, "full again"}};
+      for (const auto& k : ko) {
+        aqlm_hip_set_tuning("gemm_debug", k.dbg);
+        const double t = run_fused();
+        printf("%-28s %5d %10.2f %10s   knock-out %2d: %s\n", "gemm_1x16_mfma (LDS-DMA)", B, t, "-", k.dbg, k.what);
+      }
+      aqlm_hip_set_tuning("gemm_debug", 0);
+    }
     // round-1 register-staged split-K kernel: same entry point behind the tuning knob; cross-check Y against the default first
     std::vector<uint16_t> y0((size_t)B * out), y1((size_t)B * out);
     aqlm_hip_gemm_1x16_mfma(layers[0].codes, layers[0].cb, layers[0].scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, nullptr);
