@@ -54,7 +54,14 @@ namespace aqlm {
 #endif
 constexpr int PK_S_LOG = AQLM_PK_S_LOG;
 constexpr int PK_S = 1 << PK_S_LOG;          // slices
-constexpr int PK_NG = 256 / PK_S;            // row groups (PK_S * PK_NG == 256 workgroups == CUs)
+#ifndef AQLM_PK_NG_LOG
+#define AQLM_PK_NG_LOG (8 - AQLM_PK_S_LOG)  // row groups: by default PK_S * PK_NG == 256 workgroups == CUs
+#endif
+constexpr int PK_NG = 1 << AQLM_PK_NG_LOG;   // row groups
+constexpr int PK_NST = PK_NG * PK_S;         // streams == workgroups of a layer
+#ifndef AQLM_PK_XFIRST
+#define AQLM_PK_XFIRST 1  // batch-1 LDS map: 1 = x first (a 64 KiB window, x copies possible), 0 = slice first (LDS = slice + x: several workgroups per CU)
+#endif
 constexpr int PK_CODE_BITS = 16 - PK_S_LOG;  // bits of a code inside its slice
 constexpr int PK_SLICE_ENTRIES = 1 << PK_CODE_BITS;
 constexpr uint32_t PK_SLICE_BYTES = PK_SLICE_ENTRIES * 16;
@@ -134,7 +141,7 @@ static int choose_waves(uint32_t max_lane_steps) {
   // kernel's tail code and leaves late requests behind (measured, profiles/r02_mb_wave_counts.log: 4096x4096 with
   // 6 waves x 6 steps 6.09 us, 7 x 5 6.23 us, 5 x 7 6.22 us; 8192->1024 with 6 x 3 = 7 x 3 5.23 us, 5 x 4 5.55 us)
   int best = 8, best_cost = 1 << 30;
-  for (int nw = 8; nw >= 4; --nw) {
+  for (int nw = 8; nw >= (PK_NST > 256 ? 2 : 4); --nw) {  // many small workgroups per CU: fewer waves each
     const int t = (q + nw - 1) / nw;
     const int cost = (nw * t - q) * 8 + (8 - nw) + ((t >= 3 && t % 3 != 0) ? 12 : 0);
     if (cost < best_cost) { best_cost = cost; best = nw; }
@@ -573,7 +580,7 @@ __device__ __forceinline__ void lds_store_f32(uint32_t byte_addr, float v) {
 //   column accumulated after its last row end: the head of a row that continues in the next column)
 template <int B, uint32_t XWIN>
 struct PackedLds {
-  static constexpr bool XFIRST = (B == 1);
+  static constexpr bool XFIRST = (B == 1) && AQLM_PK_XFIRST;
   static constexpr uint32_t SLICE = XFIRST ? XWIN : 0u;
   static constexpr uint32_t X = XFIRST ? 0u : PK_SLICE_BYTES;
   __host__ __device__ static uint32_t plane(int in_groups) { return (uint32_t)(in_groups + 1) * 16u; }
@@ -605,8 +612,9 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   const int NT = NWB << 6;  // NWB = waves in the workgroup (>= p.NW); passed in: blockDim lives in the hidden kernel arguments
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef AQLM_PACKED_TRACE
-  unsigned long long tr[7];
+  unsigned long long tr[8];
   tr[0] = wall_clock64();
+  const unsigned long long cyc0 = __builtin_readcyclecounter();  // s_memtime: shader clock
 #define AQLM_TRACE(i) tr[i] = wall_clock64()
 #else
 #define AQLM_TRACE(i)
@@ -969,6 +977,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   AQLM_TRACE(6);
   if (p.trace && lane == 0) {
     unsigned long long* o = p.trace + ((size_t)block * PK_MAX_NW + wave) * 8;
+    tr[3] = __builtin_readcyclecounter() - cyc0;  // shader cycles from entry to end (slot 3 is not a time stamp)
     for (int i = 0; i < 7; ++i) o[i] = tr[i];
   }
 #endif
@@ -1064,7 +1073,7 @@ struct PackedMultiParams {
 
 template <class T_, int B, int PD, uint32_t XWIN, int EB>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const PackedMultiParams mp) {
-  const int sidx = (int)blockIdx.x >> 8;
+  const int sidx = (int)blockIdx.x / PK_NST;
   PackedGemvParams p{};
   p.x = mp.x;
   p.x_row_stride = mp.x_row_stride;
@@ -1091,7 +1100,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_multi_kernel(const Pack
       p.cb_absmax = mp.seg[k].cb_absmax;
     }
   }
-  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, (int)blockIdx.x & 255, (int)blockDim.x >> 6);
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, (int)blockIdx.x % PK_NST, (int)blockDim.x >> 6);
 }
 
 struct PackedFinalizeParams {
@@ -1281,7 +1290,7 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   // rotated copies of x: 1 by default -- with the row pools the x reads are already spread well, and up to 4 copies
   // measured within +-1 % (profiles/r02_mb_packed_variants.log); the knob keeps the mechanism testable
   int XC = 1;
-  if (arrange && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
+  if (AQLM_PK_XFIRST && arrange && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
   // 32-bit entries by default (1-3 % faster: two operations instead of four to form an entry's addresses); 24-bit entries
   // (-23 % bytes; wave ranges of at most 32 steps) are the compact choice for inference-only deployments
   const int EB = (tuning().packed_entry_bytes == 3 && T <= 32) ? 3 : 4;
@@ -1412,7 +1421,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.XC = L.XC;
   p.ent_bytes = (uint32_t)L.ent_bytes;
 #ifdef AQLM_PACKED_TRACE
-  p.trace = workspace && workspace_bytes >= need + (size_t)256 * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
+  p.trace = workspace && workspace_bytes >= need + (size_t)PK_NST * PK_MAX_NW * 8 * 8 ? (unsigned long long*)((uint8_t*)workspace + need) : nullptr;
   p.dbg = tuning().packed_debug;
 #endif
   // chain prefetch: up to `packed_prefetch_waves` extra waves per workgroup (default 2) when a next layer is named
@@ -1446,7 +1455,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
     rest.trace = p.trace;
     rest.dbg = p.dbg;
 #endif
-    hipLaunchKernelGGL(kern, dim3(256), dim3((L.NW + npw) * 64), lds_final, stream, p.codebook, p.x, p.ent, p.rowstart, p.in_groups,
+    hipLaunchKernelGGL(kern, dim3(PK_NST), dim3((L.NW + npw) * 64), lds_final, stream, p.codebook, p.x, p.ent, p.rowstart, p.in_groups,
                        (uint32_t)p.NW | ((uint32_t)p.XC << 8) | ((uint32_t)npw << 12) | (rotate << 15) | ((uint32_t)p.T << 16), p.RG,
                        p.ent_bytes, p.M, rest);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
@@ -1675,7 +1684,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
   auto launch = [&](auto kern, auto lds_map) -> int {
     const size_t lds = decltype(lds_map)::total(mp.in_groups, max_rg);
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(256 * num_segments), dim3(nw * 64), lds, stream, mp);
+    hipLaunchKernelGGL(kern, dim3(PK_NST * num_segments), dim3(nw * 64), lds, stream, mp);
     return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
   };
   if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, eb, launch)) return e;

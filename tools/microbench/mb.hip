@@ -516,11 +516,15 @@ static void bench_gemv(int argc, char** argv) {
       }
 
     } else if (c.s.packed) {  // quick: the round-3 switches
-      variants.push_back({{"rotate=0", "packed_fill_rotate", 0}});
-      variants.push_back({{"chain prefetch (2 waves)", "mb_chain", 2}});
-      variants.push_back({{"chain prefetch (1 wave)", "mb_chain", 1}});
-      variants.push_back({{"chain prefetch (4 waves)", "mb_chain", 4}});
-      variants.push_back({{"chain + rotate=0", "mb_chain", 2}, {"", "packed_fill_rotate", 0}});
+      if (getenv("MB_CHAIN")) {
+        variants.push_back({{"rotate=0", "packed_fill_rotate", 0}});
+        variants.push_back({{"chain prefetch (2 waves)", "mb_chain", 2}});
+        variants.push_back({{"chain prefetch (1 wave)", "mb_chain", 1}});
+        variants.push_back({{"chain + rotate=0", "mb_chain", 2}, {"", "packed_fill_rotate", 0}});
+      }
+      variants.push_back({{"prefetch=8", "packed_prefetch", 8}});
+      variants.push_back({{"prefetch=4", "packed_prefetch", 4}});
+      variants.push_back({{"prefetch=8", "packed_prefetch", 8}});
       variants.push_back({{"default again", "packed_fill_rotate", 1}});
     } else if (c.s.lut) {
       variants.push_back({{"two-kernel finalize", "mb_lut_two_kernel", 1}});
@@ -606,6 +610,7 @@ static void bench_trace(int in, int out) {
   const int NRUN = 8;
   const int dbgs[NRUN] = {0, 0, 0, 0, 0, 1, 2, 2 | 4};  // runs: warm-up, full x 4 (rotated fill on / off alternating), no compute, no stream, no stream + no dots
   const int rots[NRUN] = {1, 1, 0, 1, 0, 1, 1, 1};
+  if (const char* pf = getenv("MB_PREFETCH")) aqlm_hip_set_tuning("packed_prefetch", atoi(pf));
   for (int rep = 0; rep < NRUN; ++rep) {
     aqlm_hip_set_tuning("packed_debug", dbgs[rep]);
     aqlm_hip_set_tuning("packed_fill_rotate", rots[rep]);
@@ -629,6 +634,14 @@ static void bench_trace(int in, int out) {
         mn = std::min(mn, v); mx = std::max(mx, v); sum += v;
       }
       printf("  %-22s %7.2f %7.2f %7.2f\n", names[i], mn, sum / (256 * NW), mx);
+    }
+    {  // effective shader clock: s_memtime cycles / wall time between a wave's entry and its end
+      double sum = 0; int cnt = 0;
+      for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) {
+        const double us = (double)(h[(b * NWMAX + w) * 8 + 6] - h[(b * NWMAX + w) * 8 + 0]) * 0.01;
+        if (us > 0) { sum += (double)h[(b * NWMAX + w) * 8 + 3] / us; ++cnt; }
+      }
+      printf("  shader clock (s_memtime cycles per microsecond of a wave's life, mean): %.0f MHz\n", cnt ? sum / cnt : 0.0);
     }
     {  // who finishes late?  "loop done" by XCD (block % 8) and by wave index
       printf("  loop done by block %% 8:");
