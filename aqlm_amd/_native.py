@@ -79,6 +79,7 @@ SIGNATURES = {
     "aqlm_hip_gemv_1x16": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_1x16_packed_multi": (_ci, [_segp, _descpp, _ci, _vp, _ci, _ci, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_1x16_packed_multi_cells": (_ci, [_segp, _descpp, _ci, _vp, _ci, _ci, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_kx8_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_prepack_1x16_bytes": (_sz, [_ci, _ci, _ci]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "aqlm_hip_packed_desc_read": (_ci, [_vp, _sz, _descp]),
     "aqlm_hip_unpack_1x16": (_ci, [_descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_1x16_packed_cells": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_1x16_packed_chain": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed_partials": (_ci, [_descp, _vp, _vp, _vp, _ci, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_xgmi_state_bytes": (_sz, [_ci]),

@@ -1379,6 +1379,7 @@ struct PackedFused {
   void* y = nullptr;
   long y_row_stride = 0;
   float cb_absmax = 0.f;
+  void* cells = nullptr;  // caller-owned accumulator cells [rows][M] u64, zero at rest (one set per stream); null: the cells inside the packed buffer
 };
 
 // the layer that runs next on the stream (chain prefetch); all null = none
@@ -1405,7 +1406,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.x = x;
   p.partial = (float*)workspace;
   if (fused.y) {
-    p.acc = (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
+    p.acc = fused.cells ? (unsigned long long*)fused.cells : (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
     p.cb_absmax = fused.cb_absmax;
     p.scales = (const uint16_t*)fused.scales;
     p.bias = (const uint16_t*)fused.bias;
@@ -1494,7 +1495,26 @@ static int packed_check_args(const char* who, const aqlm_hip_packed_desc* desc, 
 static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                  const void* scales, const void* bias, const void* x, void* y, int batch,
                                  long x_row_stride, long y_row_stride, int dtype, void* workspace,
-                                 size_t workspace_bytes, void* stream_, const PackedNext& next);
+                                 size_t workspace_bytes, void* stream_, const PackedNext& next, void* cells = nullptr,
+                                 size_t cells_bytes = 0);
+
+extern "C" int aqlm_hip_gemv_1x16_packed_cells(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+                                               const void* scales, const void* bias, const void* x, void* y, int batch,
+                                               long x_row_stride, long y_row_stride, int dtype, void* cells,
+                                               size_t cells_bytes, void* stream_) {
+  if (!cells || !desc || !(desc->codebook_absmax > 0.f) || cells_bytes < (size_t)std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * desc->out_features * 8 ||
+      (reinterpret_cast<uintptr_t>(cells) & 7u)) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_cells: needs a descriptor with the codebook range and %zu bytes of 8-B aligned, "
+                   "zero-filled cells", desc ? (size_t)std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * desc->out_features * 8 : (size_t)0);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (!tuning().packed_fused_finalize) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_cells: the fused finalize is switched off (tuning knob packed_fused_finalize)");
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  return gemv_1x16_packed_impl(desc, const_cast<void*>(packed), codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype,
+                               nullptr, 0, stream_, PackedNext{}, cells, cells_bytes);
+}
 
 extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                          const void* scales, const void* bias, const void* x, void* y, int batch,
@@ -1527,7 +1547,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc,
 static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                  const void* scales, const void* bias, const void* x, void* y, int batch,
                                  long x_row_stride, long y_row_stride, int dtype, void* workspace,
-                                 size_t workspace_bytes, void* stream_, const PackedNext& next) {
+                                 size_t workspace_bytes, void* stream_, const PackedNext& next, void* cells, size_t cells_bytes) {
   hipStream_t stream = (hipStream_t)stream_;
   PackedLayout L;
   int max_b = 0;
@@ -1545,6 +1565,7 @@ static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed,
       fz.bias = bias;
       fz.y = (uint16_t*)y + (size_t)b0 * y_row_stride;
       fz.y_row_stride = y_row_stride;
+      fz.cells = cells;  // launches of one call are stream-ordered: they share the cells
       if (int e = packed_launch_main(L, packed, codebook, (const uint16_t*)x + (size_t)b0 * x_row_stride, nb, x_row_stride, dtype,
                                      workspace, workspace_bytes, stream, "aqlm_hip_gemv_1x16_packed", fz,
                                      b0 + nb >= batch ? next : PackedNext{}))
@@ -1589,10 +1610,35 @@ extern "C" int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* de
                             (hipStream_t)stream_, "aqlm_hip_gemv_1x16_packed_partials");
 }
 
+static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+                                       int num_segments, const void* x, int in_features, int batch, long x_row_stride,
+                                       int dtype, void* workspace, size_t workspace_bytes, void* cells, size_t cells_bytes,
+                                       void* stream_);
+
 extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
                                                int num_segments, const void* x, int in_features, int batch,
                                                long x_row_stride, int dtype, void* workspace, size_t workspace_bytes,
                                                void* stream_) {
+  return gemv_1x16_packed_multi_impl(segments, descs, num_segments, x, in_features, batch, x_row_stride, dtype, workspace,
+                                     workspace_bytes, nullptr, 0, stream_);
+}
+
+extern "C" int aqlm_hip_gemv_1x16_packed_multi_cells(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+                                                     int num_segments, const void* x, int in_features, int batch,
+                                                     long x_row_stride, int dtype, void* cells, size_t cells_bytes,
+                                                     void* stream_) {
+  if (!cells || (reinterpret_cast<uintptr_t>(cells) & 7u) || !tuning().packed_fused_finalize) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_multi_cells: needs 8-B aligned, zero-filled cells and the fused finalize switched on");
+    return AQLM_HIP_E_INVALID;
+  }
+  return gemv_1x16_packed_multi_impl(segments, descs, num_segments, x, in_features, batch, x_row_stride, dtype, nullptr, 0,
+                                     cells, cells_bytes, stream_);
+}
+
+static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+                                       int num_segments, const void* x, int in_features, int batch, long x_row_stride,
+                                       int dtype, void* workspace, size_t workspace_bytes, void* cells, size_t cells_bytes,
+                                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!segments || !descs || num_segments < 1 || num_segments > AQLM_HIP_MAX_SEGMENTS || !x) {
     set_last_error("aqlm_hip_gemv_1x16_packed_multi: 1..%d segments, their descriptors and a non-null x required (got %d)",
@@ -1618,6 +1664,19 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
   int fblocks = 0, max_rg = 0, nw = 0, pd = 4, eb = 0;
   bool fused = true;  // every segment must know its codebook range
   for (int k = 0; k < num_segments; ++k) fused = fused && descs[k] && packed_fused(descs[k]);
+  size_t cells_need = 0;
+  if (cells) {  // caller-owned accumulator cells: [segment][batch][M] u64
+    if (!fused) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi_cells: every descriptor must carry the codebook range");
+      return AQLM_HIP_E_INVALID;
+    }
+    for (int k = 0; k < num_segments; ++k) cells_need += (size_t)batch * segments[k].out_features * 8;
+    if (cells_bytes < cells_need) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi_cells: %zu bytes of cells required, got %zu", cells_need, cells_bytes);
+      return AQLM_HIP_E_INVALID;
+    }
+  }
+  size_t cells_off = 0;
   for (int k = 0; k < num_segments; ++k) {
     const aqlm_hip_segment& sg = segments[k];
     if (!sg.codes || !sg.codebook || !sg.scales || !sg.y) {
@@ -1639,7 +1698,8 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
     ps.codebook = (const uint8_t*)sg.codebook;
     ps.partial = fused ? nullptr : (float*)((uint8_t*)workspace + need);
     if (fused) {
-      ps.acc = (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
+      ps.acc = cells ? (unsigned long long*)((uint8_t*)cells + cells_off) : (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
+      cells_off += (size_t)batch * sg.out_features * 8;
       ps.scales = (const uint16_t*)sg.scales;
       ps.bias = (const uint16_t*)sg.bias;
       ps.y = (uint16_t*)sg.y;

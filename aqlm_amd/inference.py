@@ -73,6 +73,7 @@ class QuantizedLinear(nn.Module):
         self._cpu_codes_alt = None  # host modules with 8-bit codebooks: codes permuted for the LUT kernel (derived)
         self._prepack_deferred = False
         self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
+        self._fast = None  # compiled fast lane of the decode call (aqlm_amd/_front.py); derived, rebuilt with the kernel choice
 
     def extra_repr(self) -> str:
         return (f"in_features={self.in_features}, out_features={self.out_features}, scheme="
@@ -82,6 +83,13 @@ class QuantizedLinear(nn.Module):
         group = self._shared_input_group
         if group is not None and group.applicable(input):
             return group.forward(self, input)  # one launch for all projections of this input (fusion.py)
+        fast = self._fast
+        if fast is not None and not torch.compiler.is_compiling():
+            out = fast(input)  # None: not a call for the fast lane (rows, dtype, grad, a parameter changed) -> below
+            if out is not None:
+                return out
+            if not fast.is_current():
+                self.gemv_op = None  # a parameter was rebound / written in place: resolve everything again
         if self.gemv_op is None or (not torch.compiler.is_compiling() and self._derived_state_is_stale()):
             self.prepare_matmul_op(input)
         packed = self._packed_codes
@@ -131,6 +139,7 @@ class QuantizedLinear(nn.Module):
         self._codes_shape = tuple(self.codes.shape)
         self.codes = nn.Parameter(torch.empty((0,), dtype=self.codes.dtype, device=self.codes.device), requires_grad=False)
         self._codes_dropped = True
+        self._build_fast_lane()
         return True
 
     def restore_canonical_codes(self) -> None:
@@ -139,6 +148,7 @@ class QuantizedLinear(nn.Module):
             self._codes_dropped = False
             self.codes = nn.Parameter(codes, requires_grad=False)
             self._packed_fingerprint = self._codes_fingerprint()
+            self._build_fast_lane()
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
@@ -149,6 +159,7 @@ class QuantizedLinear(nn.Module):
         if self._codes_dropped and prefix + "codes" in state_dict:  # new codes arrive: give them a parameter to land in
             self._codes_dropped = False
             self._packed_codes = None
+            self._fast = None
             self.codes = nn.Parameter(torch.empty(self._codes_shape, dtype=self.codes.dtype, device=self.codes.device),
                                       requires_grad=False)
             self.gemv_op = None
@@ -160,6 +171,7 @@ class QuantizedLinear(nn.Module):
         self.restore_canonical_codes()  # the derived buffer does not survive a conversion; the codes must
         out = super()._apply(fn, *args, **kwargs)
         self.gemv_op = self.gemm_op = self.use_gemv_rule = None
+        self._fast = None
         self._packed_codes = None
         self._cpu_codes_alt = None
         self._prepack_deferred = False
@@ -171,6 +183,7 @@ class QuantizedLinear(nn.Module):
         "TODO: fix this thing"); here the permuted copy is a derived buffer and ``codes`` keeps the checkpoint layout."""
         from .inference_kernels.kernel_selector import cpu_kernel_takes_permuted_codes
 
+        self._fast = None
         self._cpu_codes_alt = None
         if cpu_kernel_takes_permuted_codes(self.codebooks):
             from .inference_kernels.cpu_kernel import permute_codes_for_lut
@@ -189,6 +202,7 @@ class QuantizedLinear(nn.Module):
         # load-time re-layout of the codes for the decode kernel (the reference does the analogous thing for its CPU
         # kernel here, inference.py:78-83 -- but in place; we keep `codes` untouched and add a derived buffer)
         if self._codes_dropped:
+            self._build_fast_lane()
             return  # the packed buffer IS the weights now
         self._packed_codes = None
         self._prepack_deferred = False
@@ -204,6 +218,43 @@ class QuantizedLinear(nn.Module):
 
             self._packed_codes = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
             self._packed_fingerprint = self._codes_fingerprint()
+        self._build_fast_lane()
+
+    def _build_fast_lane(self) -> None:
+        """The compiled fast lane of decode calls (<= GEMV_MAX_ROWS rows, no grad): flatten / allocate / launch without the
+        interpreter.  Same kernels and same results as the ops the selector returned; it watches the parameters and hands
+        any call it does not recognise back to the Python path (aqlm_amd/csrc_front/front.cpp)."""
+        self._fast = None
+        from . import _front
+
+        if (not _front.available() or not self.codebooks.is_cuda or self.out_group_size != 1
+                or self.codebooks.dtype not in (torch.float16, torch.bfloat16) or self.scales.dtype != self.codebooks.dtype
+                or (self.bias is not None and self.bias.dtype != self.codebooks.dtype)
+                or not (self.codebooks.is_contiguous() and self.scales.is_contiguous())):
+            return
+        from .inference_kernels import hip_kernel
+
+        packed = self._packed_codes
+        scheme = (self.num_codebooks, self.nbits_per_codebook, self.in_group_size)
+        if packed is not None:
+            if not (hip_kernel.FUSED_FINALIZE and packed.desc.codebook_absmax > 0.0 and packed.range_is_current(self.codebooks)):
+                return  # two-kernel finalize (needs a workspace): Python path
+            kind, buf, desc = _front.KIND_PACKED_1X16, packed.buf, bytes(packed.desc)
+        elif self._codes_dropped or not (self.codes.is_cuda and self.codes.is_contiguous()):
+            return
+        elif scheme in ((1, 16, 8), (1, 16, 16)):
+            if hip_kernel.RAW_OP_PREPACK and self.out_features * (self.in_features // 8) >= hip_kernel.RAW_OP_PREPACK_MIN_CODES:
+                return  # the raw op would pack this layer on its own (PREPACK_MIN_CODES was raised): leave it to the op
+            kind, buf, desc = _front.KIND_GEMV_1X16, None, ""
+        elif scheme in ((2, 8, 8), (1, 8, 8)):
+            kind, buf, desc = _front.KIND_GEMV_KX8, None, ""
+        else:
+            return
+        try:
+            self._fast = _front.ext.FastLinear(self._parameters, kind, buf, desc, self.in_features, self.out_features,
+                                               self.num_codebooks, self.in_group_size, not self._codes_dropped, GEMV_MAX_ROWS)
+        except RuntimeError:
+            self._fast = None
 
 
 def _get_autograd_matmul_op(forward_pass_kernel, backward_pass_kernel):

@@ -73,6 +73,15 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _version(t: torch.Tensor) -> int:
+    """The tensor's version counter; inference tensors (created under ``torch.inference_mode()``) carry none and cannot
+    be written in place outside inference mode, so a constant stands in."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 # ------------------------------------------------------------------------------------------------------
 # gemv ops (decode; the hot path)
 # ------------------------------------------------------------------------------------------------------
@@ -139,10 +148,10 @@ class PackedCodes:
         absmax = float(codebooks.detach().abs().max().float().item())
         self.desc.codebook_absmax = absmax if absmax == absmax and absmax != float("inf") else 0.0
         self._ints = self.desc.as_ints()
-        self._range_of = (codebooks.data_ptr(), codebooks._version)
+        self._range_of = (codebooks.data_ptr(), _version(codebooks))
 
     def range_is_current(self, codebooks: torch.Tensor) -> bool:
-        return self._range_of == (codebooks.data_ptr(), codebooks._version)
+        return self._range_of == (codebooks.data_ptr(), _version(codebooks))
 
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
@@ -217,6 +226,30 @@ def _workspace(device: torch.device, nbytes: int, stream: Optional[int] = None) 
     return ws
 
 
+# Accumulator cells of the single-kernel finalize, one zero-at-rest set per (device, stream): the prepacked buffers are then
+# only read, so one layer may run on several streams at once (weight sharing, overlapped graphs) -- the reference's
+# launcher is stateless in the same way (cuda_kernel.cu:505-509).  Launches on one stream are ordered, so all layers of a
+# stream share the set.  Sized once and never freed or resized (a hipGraph may have captured the pointer); calls that
+# need more, and captures on a stream that has no set yet, use the cells inside the layer's packed buffer (one stream at
+# a time per layer, include/aqlm_hip.h).
+PACKED_CELLS_BYTES = _native.MAX_GEMV_BATCH * 131072 * 8
+_PACKED_CELLS = {}
+
+
+def _packed_cells(device: torch.device, stream: int, nbytes: int):
+    if nbytes > PACKED_CELLS_BYTES:
+        return None
+    key = (device.index, stream)
+    cells = _PACKED_CELLS.get(key)
+    if cells is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        with torch.cuda.device(device):
+            cells = torch.zeros((PACKED_CELLS_BYTES // 8,), dtype=torch.int64, device=device)
+        _PACKED_CELLS[key] = cells
+    return cells
+
+
 FUSED_FINALIZE = True  # mirror of the library knob `packed_fused_finalize` (set both through set_fused_finalize)
 
 
@@ -267,18 +300,26 @@ def code1x16_matmat_packed(input, packed: PackedCodes, codebooks, scales, bias=N
     nb_max = min(B, _native.MAX_GEMV_BATCH)
     stream = _stream_ptr(input.device)
     _refresh_range(packed, codebooks)
-    if FUSED_FINALIZE and packed.desc.codebook_absmax > 0.0:   # single kernel: the accumulator cells live in the packed buffer
+    cells = None
+    if FUSED_FINALIZE and packed.desc.codebook_absmax > 0.0:   # single kernel: fixed-point cells, per stream where possible
         ws_ptr, ws_len = None, 0
+        cells = _packed_cells(input.device, stream, nb_max * out_features * 8)
     else:                                   # two kernels: fp32 slice partials in a workspace
         ws = _workspace(input.device, 16 * nb_max * out_features * 4, stream)
         ws_ptr, ws_len = ws.data_ptr(), ws.numel() * 4
     with _device_guard(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
             nb = min(_native.MAX_GEMV_BATCH, B - b0)
-            rc = _lib.aqlm_hip_gemv_1x16_packed(ctypes.byref(packed.desc), packed.data_ptr(), codebooks.data_ptr(),
-                                                scales.data_ptr(), _ptr(bias), x.data_ptr() + b0 * x.stride(0) * 2,
-                                                y.data_ptr() + b0 * out_features * 2, nb, x.stride(0), out_features, dt,
-                                                ws_ptr, ws_len, stream)
+            if cells is not None:
+                rc = _lib.aqlm_hip_gemv_1x16_packed_cells(ctypes.byref(packed.desc), packed.data_ptr(), codebooks.data_ptr(),
+                                                          scales.data_ptr(), _ptr(bias), x.data_ptr() + b0 * x.stride(0) * 2,
+                                                          y.data_ptr() + b0 * out_features * 2, nb, x.stride(0), out_features,
+                                                          dt, cells.data_ptr(), cells.numel() * 8, stream)
+            else:
+                rc = _lib.aqlm_hip_gemv_1x16_packed(ctypes.byref(packed.desc), packed.data_ptr(), codebooks.data_ptr(),
+                                                    scales.data_ptr(), _ptr(bias), x.data_ptr() + b0 * x.stride(0) * 2,
+                                                    y.data_ptr() + b0 * out_features * 2, nb, x.stride(0), out_features, dt,
+                                                    ws_ptr, ws_len, stream)
             if rc:
                 _native.check(rc, "aqlm gemv_1x16_packed")
     return y.reshape(input.shape[:-1] + (out_features,))
@@ -350,6 +391,7 @@ def code1x16_matmat_multi(input, codes, codebooks, scales, bias):
 # call): a capture whose stream has not run the op before takes the two-kernel form.
 USE_8X8_LUT_FUSED = True
 _LUT_CELLS = {}
+_LUT_CELLS_RETIRED = []
 
 
 def _lut_cells(device: torch.device, stream: int, rows: int) -> Optional[torch.Tensor]:
@@ -360,7 +402,9 @@ def _lut_cells(device: torch.device, stream: int, rows: int) -> Optional[torch.T
     if cells is None or cells.numel() < rows:
         if torch.cuda.is_current_stream_capturing():
             return None
-        cells = torch.zeros((max(rows, 1 << 16),), dtype=torch.int64, device=device)
+        if cells is not None:
+            _LUT_CELLS_RETIRED.append(cells)  # a hipGraph may have captured its address: never freed
+        cells = torch.zeros((max(rows, 1 << 17),), dtype=torch.int64, device=device)
         _LUT_CELLS[key] = cells
     return cells
 
@@ -450,14 +494,20 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
         segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), of, of
         descs[k] = ctypes.pointer(packed[k].desc)
     stream = _stream_ptr(input.device)
+    cells = None
     if FUSED_FINALIZE and all(pk.desc.codebook_absmax > 0.0 for pk in packed):  # single kernel, no workspace
         ws_ptr, ws_len = None, 0
+        cells = _packed_cells(input.device, stream, B * total * 8)
     else:
         ws = _workspace(input.device, 16 * B * total * 4, stream)
         ws_ptr, ws_len = ws.data_ptr(), ws.numel() * 4
     with _device_guard(input.device):
-        rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, descs, n, x.data_ptr(), packed[0].in_features, B, x.stride(0), dt,
-                                                  ws_ptr, ws_len, stream)
+        if cells is not None:
+            rc = _lib.aqlm_hip_gemv_1x16_packed_multi_cells(segs, descs, n, x.data_ptr(), packed[0].in_features, B, x.stride(0),
+                                                            dt, cells.data_ptr(), cells.numel() * 8, stream)
+        else:
+            rc = _lib.aqlm_hip_gemv_1x16_packed_multi(segs, descs, n, x.data_ptr(), packed[0].in_features, B, x.stride(0), dt,
+                                                      ws_ptr, ws_len, stream)
     if rc == _native.E_UNSUPPORTED and B > 1:
         # the rows do not fit one LDS image next to the codebook slice (very wide inputs): per-layer launches split the
         # rows themselves; same kernels, same bits
@@ -484,7 +534,7 @@ _RAW_STATS = {"bytes": 0, "packs_without_hit": 0, "hits": 0, "packs": 0}
 
 
 def _raw_fingerprint(codes):
-    return (codes.data_ptr(), codes._version, tuple(codes.shape), tuple(codes.stride()), codes.dtype, codes.device)
+    return (codes.data_ptr(), _version(codes), tuple(codes.shape), tuple(codes.stride()), codes.dtype, codes.device)
 
 
 def _raw_drop(key):
@@ -826,7 +876,7 @@ for _name, _impl in (("code1x16_matmat_multi", code1x16_matmat_multi), ("codekx8
 # (the descriptor travels as a list of ints; eager calls skip the dispatcher and use code1x16_matmat_packed directly)
 def _packed_op(input, packed, codebooks, scales, bias, desc):
     pk = PackedCodes(packed, _native.PackedDesc.from_ints(desc))
-    pk._range_of = (codebooks.data_ptr(), codebooks._version)  # the caller's descriptor is taken at its word (0 = unknown)
+    pk._range_of = (codebooks.data_ptr(), _version(codebooks))  # the caller's descriptor is taken at its word (0 = unknown)
     return code1x16_matmat_packed(input, pk, codebooks, scales, bias)
 
 

@@ -80,6 +80,31 @@ class ShardedQuantizedLinear(nn.Module):
         self._kernel = kernel
         self._packed = None      # prepacked codes of this shard (derived; built at first use on the GPU)
         self._packed_tried = False
+        self._packed_fingerprint = None  # identity / storage / version of `codes` at pack time (as QuantizedLinear does)
+        self._selector_kernel = None
+
+    def _codes_fingerprint(self):
+        c = self.codes
+        try:
+            v = c._version
+        except RuntimeError:  # inference tensors carry no version counter
+            v = 0
+        return (id(c), c.data_ptr() if c.numel() else 0, tuple(c.shape), v)
+
+    def _drop_derived_if_stale(self) -> None:
+        """The prepacked buffer (and the one-shot all-reduce state sized for it) is derived from ``codes``: after
+        ``load_state_dict`` / an in-place write / a rebind it is rebuilt at this call instead of being multiplied with."""
+        if self._packed_tried and self._packed_fingerprint != self._codes_fingerprint():
+            self._packed, self._packed_tried, self._packed_fingerprint = None, False, None
+            self._xgmi_ok = None  # the collective decision depends on every shard being packed: agree again
+
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()`` / ``.cuda()`` / ``.half()`` replace the parameters: everything derived from them goes."""
+        out = super()._apply(fn, *args, **kwargs)
+        self._packed, self._packed_tried, self._packed_fingerprint = None, False, None
+        self._xgmi, self._xgmi_ok = None, None
+        self._selector_kernel = None
+        return out
 
     @classmethod
     def from_full(cls, codes, codebooks, scales, bias, *, mode: str = "in", group=None, gather_output: bool = True,
@@ -105,15 +130,18 @@ class ShardedQuantizedLinear(nn.Module):
                    gather_output=gather_output, kernel=kernel, reduce_dtype=reduce_dtype)
 
     def _k(self):
-        if self._kernel is None:
-            self._kernel = get_forward_pass_kernel(self.codebooks, False)
-        return self._kernel
+        if self._kernel is not None:  # injected (tests): used as is
+            return self._kernel
+        if self._selector_kernel is None:  # depends on the codebooks' device / dtype: dropped by _apply
+            self._selector_kernel = get_forward_pass_kernel(self.codebooks, False)
+        return self._selector_kernel
 
     def _shard_matvec(self, x, bias):
         """The shard's ``(W_shard x) * scales (+ bias)``: prepacked kernel for big 1x16 g8 shards on the GPU (same rule as
         ``QuantizedLinear``), else the selector's kernel / the injected one."""
         from . import inference
 
+        self._drop_derived_if_stale()
         if (self._kernel is None and not self._packed_tried and self.codes.is_cuda and inference.PREPACK_MIN_CODES
                 and tuple(self.codebooks.shape[:3]) == (1, 65536, 1) and self.codebooks.shape[3] == 8
                 and self.codes.shape[0] * self.codes.shape[1] >= inference.PREPACK_MIN_CODES
@@ -122,6 +150,7 @@ class ShardedQuantizedLinear(nn.Module):
 
             self._packed_tried = True
             self._packed = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
+            self._packed_fingerprint = self._codes_fingerprint()
         if (self._packed is not None and x.dtype == self.codebooks.dtype
                 and x.numel() // x.shape[-1] <= inference.GEMV_MAX_ROWS):
             from .inference_kernels import hip_kernel
@@ -135,9 +164,11 @@ class ShardedQuantizedLinear(nn.Module):
         from .inference_kernels import hip_kernel
         from .xgmi import OneShotAllReduce
 
+        self._drop_derived_if_stale()
         if self._xgmi_ok is None:  # first use: collective decision + state exchange
             if not self._packed_tried and self.codes.is_cuda and self.codes.shape[1] > 0:
                 self._packed_tried = True
+                self._packed_fingerprint = self._codes_fingerprint()
                 if (tuple(self.codebooks.shape[:3]) == (1, 65536, 1) and self.codebooks.shape[3] == 8
                         and self.codes.shape[0] * self.codes.shape[1] >= inference.PREPACK_MIN_CODES):
                     self._packed = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)

@@ -218,6 +218,19 @@ int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, co
                               void* stream);
 
 /*
+ * Re-entrant form of the single-kernel finalize: the accumulator cells are the CALLER's -- `cells` = at least
+ * batch * out_features * 8 bytes, 8-B aligned, zero-filled once; every call leaves them zero.  The packed buffer is only
+ * read, so the same layer may run on several streams / from several host threads at once, like the reference's stateless
+ * launcher (cuda_kernel.cu:505-509); give every stream its own cells (launches on one stream are ordered, so all layers
+ * of a stream can share one set).  Requires desc->codebook_absmax > 0.  Same results, bit for bit, as
+ * aqlm_hip_gemv_1x16_packed.
+ */
+int aqlm_hip_gemv_1x16_packed_cells(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+                                    const void* scales, const void* bias, const void* x, void* y, int batch,
+                                    long x_row_stride, long y_row_stride, int dtype, void* cells, size_t cells_bytes,
+                                    void* stream);
+
+/*
  * aqlm_hip_gemv_1x16_packed that also names the prepacked layer which runs NEXT on the same stream (chain prefetch; no
  * reference counterpart -- the reference launches each layer cold, cuda_kernel.cpp:148-182): a few extra waves of every
  * workgroup request the next layer's entry stream and codebook so that they sit in the GPU's L2 / Infinity Cache when the
@@ -242,6 +255,12 @@ int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc, void* pack
 int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
                                     int num_segments, const void* x, int in_features, int batch, long x_row_stride,
                                     int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* aqlm_hip_gemv_1x16_packed_multi with caller-owned accumulator cells (see aqlm_hip_gemv_1x16_packed_cells): `cells` holds
+ * the segments' cells back to back, batch * out_features_s * 8 bytes each, zero-filled once and left zero. */
+int aqlm_hip_gemv_1x16_packed_multi_cells(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+                                          int num_segments, const void* x, int in_features, int batch, long x_row_stride,
+                                          int dtype, void* cells, size_t cells_bytes, void* stream);
 
 /*
  * Row-parallel ("in"-split) layers over several MI355X: the finalize of the prepacked matvec fused with a ONE-SHOT

@@ -3,6 +3,7 @@ two native libraries next to the Python sources before they are collected as pac
 
   aqlm_amd/libaqlm_hip.so   hipcc --offload-arch=gfx950 (aqlm_amd/csrc/Makefile; hipcc cross-compiles without a GPU)
   aqlm_amd/libaqlm_cpu.so   g++ -fopenmp            (aqlm_amd/csrc_cpu/Makefile)
+  aqlm_amd/_aqlm_front.so   g++ + libtorch + pybind11 (aqlm_amd/csrc_front/Makefile; host glue of the decode call)
 
 The reference ships pure Python and JIT-compiles its CUDA source at first use (inference_lib/setup.cfg:1-53,
 cuda_kernel.py:7-11); ahead-of-time libraries are what this package loads, so they are built here.  Set AQLM_SKIP_HIP_BUILD=1 to package the CPU library only (hosts without ROCm)."""
@@ -20,6 +21,7 @@ def build_native():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc_cpu")])
     if os.environ.get("AQLM_SKIP_HIP_BUILD") != "1":
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc"), "-j", jobs])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc_front")])  # compiled host glue (needs torch)
 
 
 class BuildPyWithNative(build_py):
@@ -38,6 +40,6 @@ setup(
     install_requires=["torch>=2.2.0"],
     extras_require={"hf": ["transformers>=4.38.0", "accelerate>=0.27.0"], "dev": ["pytest", "numpy"]},
     packages=["aqlm", "aqlm_amd", "aqlm_amd.inference_kernels"],
-    package_data={"aqlm_amd": ["libaqlm_hip.so", "libaqlm_cpu.so"]},
+    package_data={"aqlm_amd": ["libaqlm_hip.so", "libaqlm_cpu.so", "_aqlm_front.so"]},
     cmdclass={"build_py": BuildPyWithNative},
 )

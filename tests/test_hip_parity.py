@@ -1464,3 +1464,124 @@ def test_xgmi_fused_finalize_two_ranks_on_one_gpu(hk):
     for rank, ok, timed_out, err, _ in res:
         assert ok and not timed_out and err < 1e-3, (rank, ok, timed_out, err)
     assert res[0][4] == res[1][4]   # bit-identical replicas of y
+
+
+# ------------------------------------------------------------------ round 3: compiled fast lane, re-entrancy, inference mode
+def _big_packed_module(seed=31, fin=4096, fout=1536, dt=torch.float16, batch=4):
+    L = orc.make_layer(seed, fin, fout, 1, 16, 8, batch=batch, bias=True,
+                       float_dtype=np.float16 if dt == torch.float16 else "bfloat16")
+    m, T = _module_from(L, 1, 16, 8, fin, fout, dt)
+    return L, m, T
+
+
+@pytest.mark.parametrize("K,nbits,g,fin,fout", [(1, 16, 8, 4096, 1536), (1, 16, 8, 1024, 96), (1, 16, 16, 1024, 96),
+                                                (2, 8, 8, 1024, 200), (1, 8, 8, 512, 64)])
+def test_fast_lane_equals_python_path(hk, K, nbits, g, fin, fout):
+    """The compiled fast lane of QuantizedLinear (aqlm_amd/csrc_front/front.cpp) launches the same kernels as the Python
+    ops: bit-identical outputs; calls it does not serve (rows, dtype, grad) fall through to the Python path; a parameter
+    that is rebound or written in place is noticed."""
+    from aqlm_amd import _front
+
+    if not _front.available():
+        pytest.skip("aqlm_amd/_aqlm_front.so not built")
+    L = orc.make_layer(123, fin, fout, K, nbits, g, batch=6, bias=True)
+    m, T = _module_from(L, K, nbits, g, fin, fout, torch.float16)
+    with torch.no_grad():
+        y = m(T["x"])                       # first call: prepare_matmul_op, builds the lane
+        assert m._fast is not None, "no fast lane was built for a tuned scheme"
+        y_fast = m(T["x"])
+        lane, m._fast = m._fast, None
+        y_py = m(T["x"])                    # the Python path alone
+        m._fast = lane
+        assert torch.equal(y, y_fast) and torch.equal(y_fast, y_py)
+        y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y_fast.float().cpu().numpy(), y64, torch.float16, f"fast lane {K}x{nbits}g{g}")
+        # shapes are kept; 3-d inputs; one row
+        assert m(T["x"].reshape(2, 3, fin)).shape == (2, 3, fout)
+        assert torch.equal(m(T["x"][1:2])[0], y[1])
+        # not the lane's calls
+        assert lane(torch.cat([T["x"], T["x"][:1]])) is None                     # 7 rows: the gemm rule of the module
+        assert lane(T["x"].float()) is None                                       # another dtype
+    xg = T["x"].clone().requires_grad_(True)
+    assert lane(xg) is None                                                       # needs grad: autograd op of the Python path
+    m(xg).sum().backward()
+    assert xg.grad is not None
+    # an in-place update of the codebooks and a rebound codes parameter are noticed; results follow the new values
+    with torch.no_grad():
+        m.codebooks.mul_(2.0)
+        y2 = m(T["x"])
+        check_close(y2.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L["codes"], 2.0 * L["codebooks"].astype(np.float32), L["scales"], L["bias"]),
+                    torch.float16, "after a codebook update")
+        assert m._fast is not None and m._fast.is_current()
+        L2 = orc.make_layer(124, fin, fout, K, nbits, g, batch=6, bias=True)
+        m.codes = torch.nn.Parameter(torch.from_numpy(L2["codes"]).to(DEV), requires_grad=False)
+        y3 = m(T["x"])
+        check_close(y3.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L2["codes"], 2.0 * L["codebooks"].astype(np.float32), L["scales"], L["bias"]),
+                    torch.float16, "after rebinding codes")
+        assert m._fast is not None and m._fast.is_current()
+
+
+def test_packed_layer_runs_on_two_streams_at_once(hk):
+    """Re-entrancy of the single-kernel finalize (reference launcher: stateless on the caller's stream,
+    cuda_kernel.cu:505-509): one prepacked module -- i.e. one packed buffer -- driven from two streams concurrently, through
+    the module (fast lane), the Python op and a shared-input launch.  Every result equals the single-stream result bit for
+    bit (the accumulator cells are per stream, the packed buffer is only read)."""
+    L, m, T = _big_packed_module(batch=6)
+    xs = [torch.roll(T["x"], k, dims=0) * (1.0 + 0.25 * k) for k in range(8)]
+    with torch.no_grad():
+        ref = [m(x) for x in xs]
+        assert m._packed_codes is not None
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        out = {}
+        for rep in range(30):               # interleaved issue: both streams have many launches of the same layer in flight
+            for k, x in enumerate(xs):
+                s = s1 if (k + rep) % 2 == 0 else s2
+                with torch.cuda.stream(s):
+                    out[(rep, k)] = m(x)
+                    out[(rep, k, "op")] = hk.code1x16_matmat_packed(x, m._packed_codes, m.codebooks, m.scales, m.bias)
+                    out[(rep, k, "multi")] = hk.code1x16_matmat_packed_multi(x, [m._packed_codes], [m.codebooks], [m.scales], [m.bias])[0]
+        torch.cuda.synchronize()
+        for key, y in out.items():
+            assert torch.equal(y, ref[key[1]]), f"stream-concurrent launch {key} differs from the single-stream result"
+        # the cells inside the packed buffer were not used and the per-stream cells are back to zero
+        for cells in hk._PACKED_CELLS.values():
+            assert int(cells.abs().max()) == 0
+
+
+def test_packed_layer_under_inference_mode(hk):
+    """Parameters created under ``torch.inference_mode()`` carry no version counter: the prepacked path, the
+    raw op's prepack cache and the fast lane must not ask for one."""
+    with torch.inference_mode():
+        L, m, T = _big_packed_module(seed=77, fout=1024)
+        y = m(T["x"])
+        assert m._packed_codes is not None
+        y2 = m(T["x"])
+        y_op = torch.ops.aqlm.code1x16_matmat(T["x"], m.codes, m.codebooks, m.scales, m.bias)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y.float().cpu().numpy(), y64, torch.float16, "inference-mode module")
+    assert torch.equal(y, y2)
+    check_close(y_op.float().cpu().numpy(), y64, torch.float16, "inference-mode raw op")
+
+
+def test_sharded_layer_repacks_when_its_codes_change(hk):
+    """ShardedQuantizedLinear kept multiplying with a stale prepacked buffer after its codes were replaced."""
+    from aqlm_amd.sharded import ShardedQuantizedLinear
+
+    fin, fout = 4096, 1024
+    La = orc.make_layer(5, fin, fout, 1, 16, 8, batch=2, bias=True)
+    Lb = orc.make_layer(6, fin, fout, 1, 16, 8, batch=2, bias=True)
+    Ta, Tb = to_dev(La, torch.float16), to_dev(Lb, torch.float16)
+    sh = ShardedQuantizedLinear.from_full(Ta["codes"].clone(), Ta["codebooks"], Ta["scales"], Ta["bias"], mode="in")
+    with torch.no_grad():
+        ya = sh(Ta["x"])
+        assert sh._packed is not None
+        sh.codes.copy_(Tb["codes"])                       # load_state_dict / in-place write
+        yb = sh(Ta["x"])
+        sh.codes = torch.nn.Parameter(Ta["codes"].clone(), requires_grad=False)   # rebind
+        ya2 = sh(Ta["x"])
+    ref_a = orc.dequantize_gemm(La["x"], La["codes"], La["codebooks"], La["scales"], La["bias"])
+    ref_b = orc.dequantize_gemm(La["x"], Lb["codes"], La["codebooks"], La["scales"], La["bias"])
+    check_close(ya.float().cpu().numpy(), ref_a, torch.float16, "sharded, first codes")
+    check_close(yb.float().cpu().numpy(), ref_b, torch.float16, "sharded, after an in-place write of the codes")
+    assert torch.equal(ya, ya2)
