@@ -66,6 +66,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "packed_entry_bytes")) return &t.packed_entry_bytes;
   if (!strcmp(key, "packed_debug")) return &t.packed_debug;
   if (!strcmp(key, "packed_fill_rotate")) return &t.packed_fill_rotate;
+  if (!strcmp(key, "packed_pipe")) return &t.packed_pipe;
   if (!strcmp(key, "packed_prefetch_waves")) return &t.packed_prefetch_waves;
   return nullptr;
 }

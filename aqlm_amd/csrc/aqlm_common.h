@@ -162,6 +162,7 @@ struct Tuning {
   int packed_entry_bytes = 0;    // prepack: 0 / 4 = 32-bit entries; 3 = 24-bit entries (wave ranges of <= 32 steps)
   int packed_debug = 0;          // profiling builds (-DAQLM_PACKED_TRACE) only: 1 = no LDS reads / dots, 2 = no entry stream
   int packed_prefetch = 0;       // packed 1x16 kernel: steps of the entry stream in flight per wave (4 / 8); 0 = heuristic
+  int packed_pipe = 1;           // shared-input launches of batch 1: 1 = one workgroup per CU walks the segments with double-buffered slices
   int packed_fill_rotate = 1;    // packed 1x16 kernel: 1 = the workgroups that share a codebook slice start their LDS fill at different pieces
   int packed_prefetch_waves = 0; // chain prefetch: extra waves per workgroup that pull the next layer towards L2 (0 = 2, -1 = off)
 };

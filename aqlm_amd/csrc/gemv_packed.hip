@@ -1165,6 +1165,289 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const Pac
   packed_finalize_row<T_>(p, ((int)blockIdx.x - begin) * 256 + threadIdx.x);
 }
 
+
+// ---------------------------------------------------------------------------------------------- pipelined shared-input launch
+// q/k/v (gate/up) of a decoder layer in ONE launch of 256 workgroups, each walking its (row group, slice) stream of every
+// segment in turn with the codebook slices double-buffered: while the compute waves run the loop of segment k, two DMA
+// waves pull the slice of segment k + 1 into the other buffer, so only the first fill of the launch is exposed (the
+// plain multi kernel above starts a fresh workgroup per segment: fill and loop of a CU never overlap).  Batch 1, 4-byte
+// entries, one x copy, single-kernel finalize; everything else takes the plain multi kernel.
+//   LDS: x window | slice buffer 0 | slice buffer 1 | rowstart x 2 | rowval | colend | xmax.  The two slice buffers are
+//   65536 bytes apart: an entry's codebook address is (word & 0xfff0) | (k & 1) << 16 -- one v_and_or_b32, as many
+//   operations per entry as the single-layer kernel -- plus the constant offset of buffer 0 in the ds_read.
+//   Waves: NWC compute waves (max over the segments' wave counts) + 2 DMA waves.  The compute waves' VMEM queue holds ring
+//   fetches and the returning atomics only (hipcc counts those); the DMA waves hold LDS-DMA only (waited with vmcnt(0)).
+//   Barriers per segment: M_k (loop k done -> epilogue k may read rowval / colend) and F_k (epilogue k done AND slice
+//   k + 1 landed).
+constexpr uint32_t PP_XWIN = 16640;                                 // x window: (in_groups + 1) * 16 <= PP_XWIN
+constexpr uint32_t PP_BUF0 = PP_XWIN;
+constexpr uint32_t PP_BOOK = PP_XWIN + 2u * PK_SLICE_BYTES;         // bookkeeping area
+constexpr int PP_DMA_WAVES = 2;
+
+struct PipeLds {
+  uint32_t rs0, rs_bytes, rowval, colend, xmax, total;  // row starts of buffer b at rs0 + b * rs_bytes
+};
+__host__ __device__ static inline PipeLds pipe_lds(int max_rg) {
+  PipeLds l;
+  l.rs_bytes = ((uint32_t)(max_rg + 1) * 4u + 1023u) & ~1023u;
+  l.rs0 = PP_BOOK;
+  l.rowval = l.rs0 + 2u * l.rs_bytes;
+  l.colend = l.rowval + (((uint32_t)(max_rg + 1) * 4u + 15u) & ~15u);
+  l.xmax = l.colend + (uint32_t)PK_MAX_NW * 64u * 4u;
+  l.total = l.xmax + (uint32_t)PK_MAX_NW * 4u;
+  return l;
+}
+
+struct PipeParams {
+  const uint16_t* x;
+  int in_groups, nseg, max_rg, nwc;  // nwc: compute waves of the workgroup
+  PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
+};
+
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_vgpr, uint32_t base) {
+  uint32_t d;  // one scalar operand per VOP3 instruction (constant bus): the mask travels in a VGPR
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(w), "v"(mask_vgpr), "s"(base));
+  return d;
+}
+
+template <class T_>
+__global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeParams mp) {
+  constexpr int PD = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NWC = mp.nwc;
+  const bool dma_wave = wave >= NWC;
+  const int dw = wave - NWC;  // 0 / 1 for the DMA waves
+  const int block = (int)blockIdx.x;
+  const int slice = block & (PK_S - 1), group = block >> PK_S_LOG;
+  const PipeLds L = pipe_lds(mp.max_rg);
+  const int NTC = NWC << 6;  // compute threads
+
+  // scalar select of a segment's parameters (no dynamic indexing of the kernel-argument struct)
+  auto segment = [&](int k) -> PackedSegment {
+    PackedSegment s = mp.seg[0];
+#pragma unroll
+    for (int q = 1; q < AQLM_HIP_MAX_SEGMENTS; ++q)
+      if (k == q) s = mp.seg[q];
+    return s;
+  };
+  auto dma_slice = [&](const PackedSegment& s, int buf, int first, int stride) {  // pieces first, first + stride, ... of the slice
+    const uint8_t* src = s.codebook + (size_t)slice * PK_SLICE_BYTES;
+    constexpr int PIECES = (int)(PK_SLICE_BYTES / 1024);
+    const int rot = group * (PIECES / PK_NG);
+    for (int i0 = first; i0 < PIECES; i0 += stride) {
+      const int i = (i0 + rot) & (PIECES - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + i * 1024 + lane * 16),
+                                       (lds_void_ptr)(size_t)(PP_BUF0 + (uint32_t)buf * PK_SLICE_BYTES + (uint32_t)i * 1024u), 16, 0, 0);
+    }
+  };
+  auto dma_rowstart = [&](const PackedSegment& s, int buf, int first, int stride) {
+    const int RG1 = s.RG + 1;
+    const uint32_t* rs_src = s.rowstart + (size_t)block * RG1;
+    for (int i = first; i * 64 < RG1; i += stride) {
+      const int idx = i * 64 + lane;
+      if (idx < RG1)
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rs_src + idx), (lds_void_ptr)(size_t)(L.rs0 + (uint32_t)buf * L.rs_bytes + (uint32_t)i * 256u), 4, 0, 0);
+    }
+  };
+
+  // ---- prologue: every wave helps with the first fill (slice 0, x, row starts 0), as in the single-layer kernel ---------
+  PackedSegment s0 = segment(0);
+  const int NWB = NWC + PP_DMA_WAVES;
+  dma_slice(s0, 0, wave, NWB);
+  {
+    const int nchunk = (mp.in_groups + 63) >> 6;
+    for (int c = wave; c < nchunk; c += NWB) {
+      const int idx = c * 64 + lane;
+      if (idx < mp.in_groups)
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(mp.x + (size_t)idx * 8), (lds_void_ptr)(size_t)((uint32_t)c * 1024u), 16, 0, 0);
+    }
+  }
+  dma_rowstart(s0, 0, wave, NWB);
+  if (tid == 0) *reinterpret_cast<u32x4*>(smem_raw + (uint32_t)mp.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};  // the null entries' x
+  if (tid < PK_MAX_NW) *reinterpret_cast<uint32_t*>(smem_raw + L.xmax + (uint32_t)tid * 4u) = 0u;
+
+  uint32_t mask = 0xfff0u;
+  asm volatile("" : "+v"(mask));  // SDWA operand in a VGPR
+
+  if (dma_wave) {
+    // ============================================ DMA waves ================================================================
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));  // vmcnt(0) lgkmcnt(0): my share of the first fill has landed
+    __builtin_amdgcn_s_barrier();                          // B0
+    for (int k = 0; k < mp.nseg; ++k) {
+      if (k + 1 < mp.nseg) {
+        const PackedSegment sn = segment(k + 1);
+        dma_slice(sn, (k + 1) & 1, dw, PP_DMA_WAVES);
+        dma_rowstart(sn, (k + 1) & 1, dw, PP_DMA_WAVES);
+      }
+      __builtin_amdgcn_s_barrier();                        // M_k
+      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));
+      __builtin_amdgcn_s_barrier();                        // F_k: slice k + 1 is in LDS
+    }
+    return;
+  }
+
+  // ============================================== compute waves =============================================================
+  __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)s0.ent, 0, s0.ent_bytes, 0x00020000);
+  auto fetch_from = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t wbase, int Tm1, int t) -> u32x4 {
+    const uint32_t vo = t <= Tm1 ? (uint32_t)lane * 16u : 0xfffffff0u;  // past the range: zeros, no memory traffic
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, wbase + (uint32_t)t * 1024u, AUX_NT);
+  };
+  u32x4 ring[PD];
+  {
+    const int wv = wave < s0.NW ? wave : s0.NW - 1;
+    const uint32_t wbase = (uint32_t)(((size_t)block * s0.NW + wv) * s0.T) * 1024u;
+#pragma unroll
+    for (int j = 0; j < PD; ++j) ring[j] = fetch_from(rs_ent, wbase, wave < s0.NW ? s0.T - 1 : -1, j);
+  }
+  __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD): the fill, not the ring
+  __builtin_amdgcn_s_barrier();                            // B0
+
+  for (int k = 0; k < mp.nseg; ++k) {
+    const PackedSegment s = segment(k);
+    const int RG1 = s.RG + 1;
+    int nrows = s.M - group * s.RG;
+    nrows = nrows < 0 ? 0 : (nrows < s.RG ? nrows : s.RG);
+    const int steps = wave < s.NW ? s.T : 0;
+    const uint32_t bufsel = (uint32_t)(k & 1) << 16;
+    const uint32_t wbase = (uint32_t)(((size_t)block * s.NW + (wave < s.NW ? wave : s.NW - 1)) * s.T) * 1024u;
+    const int Tm1 = steps > 0 ? s.T - 1 : -1;
+    // the first steps of the NEXT segment's entry stream are requested now: by the time the epilogue below waits for its
+    // atomics they have long landed (VMEM returns in order), and loop k + 1 starts on data that is already here
+    u32x4 ring_next[PD];
+    __amdgpu_buffer_rsrc_t rs_next = rs_ent;
+    if (k + 1 < mp.nseg) {
+      const PackedSegment sn = segment(k + 1);
+      rs_next = __builtin_amdgcn_make_buffer_rsrc((void*)sn.ent, 0, sn.ent_bytes, 0x00020000);
+      const int wv = wave < sn.NW ? wave : sn.NW - 1;
+      const uint32_t wb = (uint32_t)(((size_t)block * sn.NW + wv) * sn.T) * 1024u;
+#pragma unroll
+      for (int j = 0; j < PD; ++j) ring_next[j] = fetch_from(rs_next, wb, wave < sn.NW ? sn.T - 1 : -1, j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) ring_next[j] = u32x4{0u, 0u, 0u, 0u};
+    }
+    float acc = 0.f;
+    uint32_t row_addr = 0;
+    auto step = [&](const u32x4& e) {
+      const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+      uint32_t a_cb[4], a_x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a_cb[j] = and_or(w[j], mask, bufsel);
+        a_x[j] = half_and<1>(w[j], mask);
+      }
+      u32x4 ev[4], xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ev[j] = *(lds_u32x4_ptr)(size_t)(a_cb[j] + PP_BUF0);
+        xv[j] = *(lds_u32x4_ptr)(size_t)(a_x[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = dot8<T_>(ev[j], xv[j], acc);
+      if (e.x & 1u) {  // a row ends here: unique writer
+        lds_store_f32(row_addr, acc);
+        acc = 0.f;
+        row_addr += 4u;
+      }
+    };
+    if (steps > 0) {
+      row_addr = L.rowval + pk_get_start_row(ring[0].x, ring[0].y, ring[0].z, ring[0].w) * 4u;
+      int t = 0;
+      for (; t + PD <= steps; t += PD) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+          step(ring[j]);
+          ring[j] = fetch_from(rs_ent, wbase, Tm1, t + PD + j);
+        }
+      }
+      const int rem = steps - t;
+#pragma unroll
+      for (int j = 0; j < PD - 1; ++j)
+        if (j < rem) step(ring[j]);
+    }
+    if (k == 0) {  // largest |x| (every segment multiplies the same x): per-wave maxima, once
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      us2 m = {0, 0};
+      for (int idx = tid; idx < mp.in_groups; idx += NTC) {
+        const u32x4 v = *(lds_u32x4_ptr)(size_t)((uint32_t)idx * 16u);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = __builtin_elementwise_max(m, __builtin_bit_cast(us2, w4[j] & 0x7fff7fffu));
+      }
+      const uint32_t mm = wave_max_u32(m.x > m.y ? (uint32_t)m.x : (uint32_t)m.y);
+      if (lane == 0) *reinterpret_cast<uint32_t*>(smem_raw + L.xmax + (uint32_t)wave * 4u) = mm;
+    }
+    if (wave < s.NW) lds_store_f32(L.colend + (uint32_t)(wave * 64 + lane) * 4u, acc);
+    rs_ent = rs_next;
+#pragma unroll
+    for (int j = 0; j < PD; ++j) ring[j] = ring_next[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");  // the asm LDS stores are invisible to the compiler's counters
+    __builtin_amdgcn_s_barrier();                          // M_k
+    // ---- epilogue of segment k (compute waves): row sums -> fixed-point cell -> last arrival writes y ---------------------
+    {
+      const uint32_t* rs = reinterpret_cast<const uint32_t*>(smem_raw + L.rs0 + (uint32_t)(k & 1) * L.rs_bytes);
+      const float* rowval = reinterpret_cast<const float*>(smem_raw + L.rowval);
+      const float* colend = reinterpret_cast<const float*>(smem_raw + L.colend);
+      const uint32_t T = (uint32_t)s.T;
+      const int row_begin = group * s.RG;
+      for (int r = tid; r < nrows; r += NTC) {
+        const uint32_t q0 = rs[r], q1 = rs[r + 1];
+        const uint32_t c0 = q0 / T, c1 = (q1 - 1u) / T;
+        float v = rowval[r];
+        for (uint32_t c = c0; c < c1; ++c) v += colend[c];
+        uint32_t xm = 0u;
+        {
+          u32x4 sl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sl[q] = *(lds_u32x4_ptr)(size_t)(L.xmax + (uint32_t)(q * 4) * 4u);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t a = sl[q].x > sl[q].y ? sl[q].x : sl[q].y, c = sl[q].z > sl[q].w ? sl[q].z : sl[q].w;
+            const uint32_t d = a > c ? a : c;
+            xm = d > xm ? d : xm;
+          }
+        }
+        const float bound = (float)mp.in_groups * 8.f * s.cb_absmax * T_::to_float((uint16_t)xm);
+        int e = 0;
+        (void)frexpf(bound, &e);
+        const bool finite = bound < __builtin_inff() && fabsf(v) <= 2.f * bound;
+        const int sh = PK_FIX_BITS - e;
+        const long long qv = finite ? __float2ll_rn(ldexpf(v, sh)) : 0ll;
+        const unsigned long long mine = ((unsigned long long)qv << PK_VAL_SHIFT) + (finite ? 1ull : 1ull + (1ull << PK_CNT_BITS));
+        const int row = row_begin + r;
+        const unsigned long long old = __hip_atomic_fetch_add(s.acc + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
+          const unsigned long long cell = old + mine;
+          const long long sum = (long long)cell >> PK_VAL_SHIFT;
+          float sv = (float)ldexp((double)sum, -sh);
+          if ((cell >> PK_CNT_BITS) & PK_CNT_MASK) sv = __builtin_nanf("");
+          const float scale = T_::to_float(s.scales[row]);
+          const float bias = s.bias ? T_::to_float(s.bias[row]) : 0.f;
+          s.y[row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
+          __hip_atomic_store(s.acc + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    __builtin_amdgcn_s_barrier();                          // F_k
+  }
+}
+
+static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max_rg, int& nwc) {
+  max_rg = 0;
+  nwc = 0;
+  for (int k = 0; k < n; ++k) {
+    if (Ls[k].EB != 4 || Ls[k].XC != 1) return false;
+    max_rg = std::max(max_rg, Ls[k].RG);
+    nwc = std::max(nwc, Ls[k].NW);
+  }
+  if (PK_S_LOG != 4 || n < 2 || nwc + PP_DMA_WAVES > PK_MAX_NW || (uint32_t)(in_groups + 1) * 16u > PP_XWIN) return false;
+  return pipe_lds(max_rg).total <= 160u * 1024u;
+}
+
 // ---------------------------------------------------------------------------------------------- host launch helpers
 static int pick_pd(const PackedLayout& L) {
   const int t = tuning().packed_prefetch;
@@ -1740,6 +2023,28 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
   if (packed_max_batch(mp.in_groups, max_rg) < batch) {
     set_last_error("aqlm_hip_gemv_1x16_packed_multi: %d rows of %d features do not fit the LDS image", batch, in_features);
     return AQLM_HIP_E_UNSUPPORTED;
+  }
+  // batch 1 with the single-kernel finalize: one workgroup per CU walks all segments, slices double-buffered (pipe kernel)
+  if (fused && batch == 1 && tuning().packed_pipe) {
+    PackedLayout Ls[AQLM_HIP_MAX_SEGMENTS];
+    for (int k = 0; k < num_segments; ++k) desc_layout(descs[k], Ls[k]);
+    int prg = 0, nwc = 0;
+    if (pipe_eligible(Ls, num_segments, mp.in_groups, prg, nwc)) {
+      PipeParams pp{};
+      pp.x = mp.x;
+      pp.in_groups = mp.in_groups;
+      pp.nseg = num_segments;
+      pp.max_rg = prg;
+      pp.nwc = nwc;
+      for (int k = 0; k < num_segments; ++k) pp.seg[k] = mp.seg[k];
+      const size_t lds = pipe_lds(prg).total;
+      auto go = [&](auto kern) -> int {
+        if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+        hipLaunchKernelGGL(kern, dim3(PK_NST), dim3((nwc + PP_DMA_WAVES) * 64), lds, stream, pp);
+        return check_hip(hipGetLastError(), "gemv_1x16_packed_pipe launch");
+      };
+      return dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16>) : go(gemv_1x16_packed_pipe_kernel<BF16>);
+    }
   }
   auto launch = [&](auto kern, auto lds_map) -> int {
     const size_t lds = decltype(lds_map)::total(mp.in_groups, max_rg);

@@ -1585,3 +1585,51 @@ def test_sharded_layer_repacks_when_its_codes_change(hk):
     check_close(ya.float().cpu().numpy(), ref_a, torch.float16, "sharded, first codes")
     check_close(yb.float().cpu().numpy(), ref_b, torch.float16, "sharded, after an in-place write of the codes")
     assert torch.equal(ya, ya2)
+
+
+@pytest.mark.parametrize("outs,fin,dt", [
+    ((4096, 1024, 1024), 4096, "float16"),      # Llama-3-8B q / k / v: different wave and step counts per segment
+    ((14336, 14336), 4096, "float16"),          # gate / up: 16 waves each, 896-row groups
+    ((1024, 1024, 1024, 1024), 4096, "bfloat16"),
+    ((4096, 4096, 4096), 4096, "float16"),
+    ((1536, 2048), 8192, "float16"),            # 8192-wide input: x fills the window to 16400 of 16640 bytes
+])
+def test_pipelined_shared_input_launch(hk, outs, fin, dt):
+    """The pipelined shared-input kernel (one workgroup per CU walks the segments, codebook slices double-buffered, two DMA
+    waves; gemv_1x16_packed_pipe_kernel): bit-identical to the per-segment kernel of the plain multi launch and to separate
+    single-layer launches, repeatable (cells zero at rest), within tolerance of the oracle."""
+    from aqlm_amd import _native
+
+    dtype = tdtype(dt)
+    Ls = [orc.make_layer(900 + i, fin, o, 1, 16, 8, batch=1, bias=(i % 2 == 0),
+                         float_dtype=np.float16 if dt == "float16" else "bfloat16") for i, o in enumerate(outs)]
+    Ts = [to_dev(L, dtype) for L in Ls]
+    x = Ts[0]["x"]
+    packed = [hk.prepack_1x16(T["codes"], 8, codebooks=T["codebooks"]) for T in Ts]
+    assert all(p is not None for p in packed)
+    args = (x, packed, [T["codebooks"] for T in Ts], [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    singles = [hk.code1x16_matmat_packed(x, p, T["codebooks"], T["scales"], T["bias"]) for p, T in zip(packed, Ts)]
+    _native.set_tuning("packed_pipe", 0)
+    try:
+        plain = hk.code1x16_matmat_packed_multi(*args)
+    finally:
+        _native.set_tuning("packed_pipe", 1)
+    for rep in range(5):
+        piped = hk.code1x16_matmat_packed_multi(*args)
+        for k in range(len(outs)):
+            assert torch.equal(piped[k], plain[k]) and torch.equal(piped[k], singles[k]), f"segment {k}, repeat {rep}"
+    for k, L in enumerate(Ls):
+        y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(piped[k].float().cpu().numpy(), y64, dtype, f"pipelined segment {k}")
+    # inside a hipGraph (the decode loop's form): replay equals eager
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        hk.code1x16_matmat_packed_multi(*args)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            captured = hk.code1x16_matmat_packed_multi(*args)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    for k in range(len(outs)):
+        assert torch.equal(captured[k], singles[k])

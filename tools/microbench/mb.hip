@@ -772,6 +772,98 @@ static void bench_gemm(bool nosync) {
   }
 }
 
+// ---------------------------------------------------------------- shared-input launches (q/k/v, gate/up) through the C ABI
+static void bench_multi() {
+  g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
+  CK(hipMalloc(&g_ws, g_ws_bytes));
+  CK(hipMemset(g_ws, 0, g_ws_bytes));
+  const Scheme s{"1x16g8P", 1, 16, 8, false, true};
+  struct Group { const char* name; int in; std::vector<int> outs; };
+  const std::vector<Group> groups = {{"3 x 4096->4096", 4096, {4096, 4096, 4096}}, {"Llama-3-8B q/k/v", 4096, {4096, 1024, 1024}},
+                                     {"Llama-3-8B gate/up", 4096, {14336, 14336}}, {"Llama-2-7B gate/up", 4096, {11008, 11008}},
+                                     {"Llama-3-70B q/k/v", 8192, {8192, 1024, 1024}}};
+  printf("%-22s %-34s %9s %9s\n", "group", "variant", "cold_us", "coldGB/s");
+  for (const auto& gr : groups) {
+    const int nseg = (int)gr.outs.size();
+    size_t ab = 0;
+    for (int o : gr.outs) ab += algo_bytes(gr.in, o, s, 1);
+    int n = (int)((600u << 20) / ab) + 1;
+    if (n > 48) n = 48;
+    std::vector<std::vector<Layer>> segs(nseg);
+    for (int k = 0; k < nseg; ++k) segs[k] = make_layers(s, gr.in, gr.outs[k], 1, n);
+    auto time_it = [&](bool one_launch) {
+      hipStream_t st; CK(hipStreamCreate(&st));
+      auto run = [&]() {
+        for (int i = 0; i < n; ++i) {
+          if (one_launch) {
+            aqlm_hip_segment sg[4]; const aqlm_hip_packed_desc* ds[4];
+            for (int k = 0; k < nseg; ++k) {
+              const Layer& L = segs[k][i];
+              sg[k] = aqlm_hip_segment{L.packed, L.cb, L.scales, nullptr, L.y, gr.outs[k], gr.outs[k], 0};
+              ds[k] = &L.desc;
+            }
+            int rc = aqlm_hip_gemv_1x16_packed_multi(sg, ds, nseg, segs[0][i].x, gr.in, 1, gr.in, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
+            if (rc) { fprintf(stderr, "multi rc=%d %s\n", rc, aqlm_hip_last_error()); exit(6); }
+          } else {
+            for (int k = 0; k < nseg; ++k) {
+              const Layer& L = segs[k][i];
+              aqlm_hip_gemv_1x16_packed(&L.desc, L.packed, L.cb, L.scales, nullptr, segs[0][i].x, L.y, 1, gr.in, gr.outs[k], AQLM_HIP_F16, g_ws, g_ws_bytes, st);
+            }
+          }
+        }
+      };
+      run();
+      CK(hipStreamSynchronize(st));
+      hipGraph_t g; hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      run();
+      CK(hipStreamEndCapture(st, &g));
+      CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+      Timer t; t.start(st);
+      for (int r = 0; r < 4; ++r) CK(hipGraphLaunch(ge, st));
+      const float ms = t.stop_ms(st);
+      CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(st));
+      return ms * 1e3 / (4.0 * n);
+    };
+    const double sep = time_it(false);
+    printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "separate launches", sep, ab / sep * 1e-3);
+    for (int rep = 0; rep < 2; ++rep) {
+      aqlm_hip_set_tuning("packed_pipe", 0);
+      const double plain = time_it(true);
+      printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "one launch, workgroup per segment", plain, ab / plain * 1e-3);
+      aqlm_hip_set_tuning("packed_pipe", 1);
+      const double pipe = time_it(true);
+      printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "one launch, pipelined segments", pipe, ab / pipe * 1e-3);
+    }
+    // outputs of the pipelined launch vs separate launches (layer set 0)
+    {
+      std::vector<std::vector<uint16_t>> ref(nseg);
+      for (int k = 0; k < nseg; ++k) {
+        const Layer& L = segs[k][0];
+        CK(hipMemset(L.y, 0xff, (size_t)gr.outs[k] * 2));
+        aqlm_hip_gemv_1x16_packed(&L.desc, L.packed, L.cb, L.scales, nullptr, segs[0][0].x, L.y, 1, gr.in, gr.outs[k], AQLM_HIP_F16, g_ws, g_ws_bytes, nullptr);
+        CK(hipDeviceSynchronize());
+        ref[k].resize(gr.outs[k]);
+        CK(hipMemcpy(ref[k].data(), L.y, (size_t)gr.outs[k] * 2, hipMemcpyDeviceToHost));
+        CK(hipMemset(L.y, 0xff, (size_t)gr.outs[k] * 2));
+      }
+      aqlm_hip_segment sg[4]; const aqlm_hip_packed_desc* ds[4];
+      for (int k = 0; k < nseg; ++k) { const Layer& L = segs[k][0]; sg[k] = aqlm_hip_segment{L.packed, L.cb, L.scales, nullptr, L.y, gr.outs[k], gr.outs[k], 0}; ds[k] = &L.desc; }
+      int rc = aqlm_hip_gemv_1x16_packed_multi(sg, ds, nseg, segs[0][0].x, gr.in, 1, gr.in, AQLM_HIP_F16, g_ws, g_ws_bytes, nullptr);
+      CK(hipDeviceSynchronize());
+      size_t bad = 0, tot = 0;
+      for (int k = 0; k < nseg; ++k) {
+        std::vector<uint16_t> y(gr.outs[k]);
+        CK(hipMemcpy(y.data(), segs[k][0].y, (size_t)gr.outs[k] * 2, hipMemcpyDeviceToHost));
+        for (int i = 0; i < gr.outs[k]; ++i) { bad += y[i] != ref[k][i]; ++tot; }
+      }
+      printf("# %s: pipelined vs separate launches rc=%d: %zu of %zu outputs differ%s\n", gr.name, rc, bad, tot, bad ? "   <-- MISMATCH" : "");
+    }
+    for (auto& v : segs) free_layers(v);
+  }
+}
+
 int main(int argc, char** argv) {
   const char* what = argc > 1 ? argv[1] : "all";
   if (const char* tune = getenv("MB_TUNE")) {  // MB_TUNE="packed_entry_bytes=3,packed_xcopies=4": library tuning knobs for the whole run
@@ -798,6 +890,7 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "rates") || !strcmp(what, "all")) bench_rates();
   if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
+  if (!strcmp(what, "multi")) bench_multi();
   if (!strcmp(what, "trace")) {
     g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
     CK(hipMalloc(&g_ws, g_ws_bytes));
