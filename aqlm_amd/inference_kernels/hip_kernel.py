@@ -527,7 +527,7 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
 # being captured (the pack synchronises); outputs equal the direct kernel's up to fp32 summation order.
 RAW_OP_PREPACK = True                 # set False to keep the raw op on the direct kernel
 RAW_OP_PREPACK_MIN_CODES = 500_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
-RAW_OP_PREPACK_MAX_BYTES = 16 << 30
+RAW_OP_PREPACK_MAX_BYTES = 4 << 30  # of packed buffers held for callers of the raw op (modules keep their own)
 RAW_OP_PREPACK_MAX_MISSES = 8
 _RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None)
 _RAW_STATS = {"bytes": 0, "packs_without_hit": 0, "hits": 0, "packs": 0}

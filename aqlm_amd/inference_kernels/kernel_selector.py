@@ -47,7 +47,7 @@ def _torch_backward(grad_output, codes, codebooks, scales, bias):
     return torch.matmul(grad_output, W.to(grad_output.dtype))
 
 
-def _cpu_forward_kernel(codebooks: torch.Tensor):
+def _cpu_forward_kernel(codebooks: torch.Tensor, optimize_for_training: bool = False):
     """Host tensors (reference kernel_selector.py:95-102).  NOTE the contract of the 8-bit route: like the reference's
     numba kernel it takes ``codes`` permuted to [in_groups, out, K] uint8 -- ``QuantizedLinear.prepare_matmul_op`` keeps
     that copy next to the canonical codes."""
@@ -56,7 +56,10 @@ def _cpu_forward_kernel(codebooks: torch.Tensor):
     num_codebooks, codebook_size, out_group_size, in_group_size = codebooks.shape
     if out_group_size == 1 and codebook_size == 256:
         return cpu_kernel.cpu_gemm_lut
-    if out_group_size == 1 and num_codebooks == 1 and in_group_size in (8, 16) and codebook_size in (4096, 65536):
+    if (not optimize_for_training and out_group_size == 1 and num_codebooks == 1 and in_group_size in (8, 16)
+            and codebook_size in (4096, 65536)):
+        # decode only: the direct kernel re-gathers the codebook vector per (row, batch column); for many rows the
+        # reference's dequantize + GEMM is the faster host path (64 rows: 0.24 s vs 0.43 s at 4096 x 4096, 8 threads)
         return cpu_kernel.cpu_gemv_1xn
     return _torch_forward
 
@@ -79,7 +82,7 @@ def get_forward_pass_kernel(
 ) -> Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]], torch.Tensor]:
     """reference kernel_selector.py:21-102."""
     if codebooks.device.type == "cpu":
-        return _cpu_forward_kernel(codebooks)
+        return _cpu_forward_kernel(codebooks, optimize_for_training)
     _require_gpu(codebooks)
     from . import hip_kernel  # noqa: F401  (registers torch.ops.aqlm.*; raises if libaqlm_hip.so is missing)
 

@@ -52,6 +52,7 @@ class Layer:
 
     def __init__(self, fin, fout, K, nbits, g, seed, device, batch=1):
         gen = torch.Generator(device=device).manual_seed(seed)
+        self.seed = seed
         self.fin, self.fout, self.K, self.nbits, self.g = fin, fout, K, nbits, g
         cdt = torch.int16 if nbits > 8 else torch.int8
         lo, hi = (-(2 ** (nbits - 1)), 2 ** (nbits - 1))
@@ -267,11 +268,35 @@ def cpu_baseline(sample_seconds=24.0):
                                              "GBps_algorithmic_median": b / st["median"] * 1e-9, "iters": n}
     except Exception as e:  # noqa: BLE001 - a reported extra, never fatal for the GPU benchmark
         native = {"error": f"{type(e).__name__}: {e}"}
+    # what the reference itself EXECUTES on CPU for 1x16 (kernel_selector.py:99-102): the pure-torch dequantize_gemm
+    # (dequantization.py:9-21 + utils.py:43-70: embedding_bag gather, reshape, F.linear).  /root/reference does not exist
+    # on the GPU box, so this is aqlm_amd's module of the same name and semantics (checked against the reference's
+    # outputs by tests/golden); fp32, batch 1, 4096 x 4096, one thread and all cores, a handful of calls each.
+    ref_torch = {}
+    try:
+        from aqlm_amd.inference_kernels.dequantization import dequantize_gemm
+
+        L = orc.make_layer(2, 4096, 4096, 1, 16, 8, batch=1, bias=False, float_dtype=np.float32, edge_codes=False)
+        xt = torch.from_numpy(np.ascontiguousarray(L["x"][:1]))
+        cbt = torch.from_numpy(np.ascontiguousarray(L["codebooks"]))
+        sct = torch.from_numpy(np.ascontiguousarray(L["scales"]))
+        codes_t = torch.from_numpy(np.ascontiguousarray(orc.pack_int_data(L["codes"], 16)))
+        b = algorithmic_bytes(4096, 4096)
+        keep = torch.get_num_threads()
+        for label, nt in (("1_thread", 1), (f"{threads}_threads", threads)):
+            torch.set_num_threads(nt)
+            st, n = _time_calls(lambda: dequantize_gemm(xt, codes_t, cbt, sct, None), 2.5, 20, 2)
+            ref_torch[f"1x16g8_4096x4096_{label}"] = {"ms_median": st["median"] * 1e3, "ms_min": st["min"] * 1e3,
+                                                      "GBps_algorithmic_median": b / st["median"] * 1e-9, "iters": n}
+        torch.set_num_threads(keep)
+    except Exception as e:  # noqa: BLE001
+        ref_torch = {"error": f"{type(e).__name__}: {e}"}
     return {
         "value": total_bytes / total_time * 1e-9,
         "unit": "GB/s",
         "cores": threads,
         "kind": "port",
+        "reference_torch_path": ref_torch,
         "native_cpu_path": native,
         "sample": f"oracle C dequant-gemv (what the reference runs on CPU for 1x16), fp32, one 4096->4096 + one 4096->11008 "
                   f"layer, <= 1000 calls or {budget:.0f} s each on {threads} OpenMP threads; `protocol`: the reference "
@@ -308,13 +333,50 @@ def large_batch_detail(dev, reps):
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e3 / n
 
-    fused = timeit(lambda l: hk.code1x16_matmat_dequant(x, l.codes, l.codebooks, l.scales, None))
+    def timegraph(fn, xin):
+        """The same rotation captured in one hipGraph (what a served prefill / speculative step looks like): kernel time
+        without the interpreter.  The eager figures next to it are host-bound below ~20 us per call."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for l in layers[:3]:
+                fn(l, xin)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for l in layers:
+                    fn(l, xin)
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = max(3, reps // 2)
+            e0.record(s)
+            for _ in range(n):
+                g.replay()
+            e1.record(s)
+            e1.synchronize()
+        del g
+        return e0.elapsed_time(e1) * 1e3 / (n * len(layers))
+
+    fused_eager = timeit(lambda l: hk.code1x16_matmat_dequant(x, l.codes, l.codebooks, l.scales, None))
     ref_like = timeit(lambda l: F.linear(x, hk.code1x16_dequant(l.codes, l.codebooks, l.scales)))
     W = hk.code1x16_dequant(layers[0].codes, layers[0].codebooks, layers[0].scales)
-    dense = timeit(lambda l: F.linear(x, W))
+    Ws = [W] + [W.clone() for _ in range(7)]  # 8 x 32 MiB: the dense rotation does not sit in L2 either
+    dense_eager = timeit(lambda l: F.linear(x, W))
+    fused = timegraph(lambda l, xin: hk.code1x16_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), x)
+    dense = timegraph(lambda l, xin: F.linear(xin, Ws[l.seed % 8]), x)
+    ref_graph = timegraph(lambda l, xin: F.linear(xin, hk.code1x16_dequant(l.codes, l.codebooks, l.scales)), x)
     flop = 2.0 * B * fin * fout
-    out = {"fused_mfma_us": fused, "fused_TFLOPs": flop / fused * 1e-6, "dequant_plus_gemm_us": ref_like,
-           "dense_fp16_gemm_us": dense, "note": "eager launches incl. python overhead; same x, 24 rotating layers"}
+    out = {"fused_mfma_us": fused, "fused_TFLOPs": flop / fused * 1e-6, "dequant_plus_gemm_us": ref_graph,
+           "dense_fp16_gemm_us": dense, "fused_mfma_eager_us": fused_eager, "dequant_plus_gemm_eager_us": ref_like,
+           "dense_fp16_gemm_eager_us": dense_eager,
+           "note": "hipGraph replay of 24 rotating layers (kernel time, launch gaps included); *_eager_us: the same calls "
+                   "issued one by one from python (host-bound)"}
+    by_rows = {}
+    for rows in (16, 32, 64):
+        xr = torch.randn((rows, fin), device=dev, dtype=torch.float16)
+        by_rows[f"rows{rows}"] = {"fused_mfma_us": timegraph(lambda l, xin: hk.code1x16_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), xr),
+                                  "dense_fp16_gemm_us": timegraph(lambda l, xin: F.linear(xin, Ws[l.seed % 8]), xr)}
+    out["graph_by_rows"] = by_rows
     # why the op switches to dequant + library GEMM above FUSED_MFMA_MAX_ROWS: the fused kernel re-gathers per 128-row slab
     old = hk.FUSED_MFMA_MAX_ROWS
     try:

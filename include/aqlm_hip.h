@@ -8,7 +8,8 @@
  * a reference maintainer would add.
  *
  * Conventions (all entry points):
- *   - raw device pointers, caller-owned, never retained; inputs are never written;
+ *   - raw device pointers, caller-owned, never retained; inputs are never written (one documented exception: the
+ *     accumulator cells inside a prepacked buffer, see aqlm_hip_gemv_1x16_packed; the *_cells entries avoid it);
  *   - stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the null stream), asynchronous,
  *     no allocation, no synchronisation -> hipGraph-capturable and re-entrant;
  *   - tensors use the reference's checkpoint layout unchanged:
