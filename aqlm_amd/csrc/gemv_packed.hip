@@ -613,6 +613,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef AQLM_PACKED_TRACE
   unsigned long long tr[8];
+  uint32_t tr_wait = 0, tr_work = 0;
   tr[0] = wall_clock64();
   const unsigned long long cyc0 = __builtin_readcyclecounter();  // s_memtime: shader clock
 #define AQLM_TRACE(i) tr[i] = wall_clock64()
@@ -863,7 +864,19 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     for (; t + PD <= steps; t += PD) {
 #pragma unroll
       for (int k = 0; k < PD; ++k) {  // single back-edge, static ring slots: no in-flight register is ever copied
+#ifdef AQLM_PACKED_TRACE
+        // profiling build: split a step into "waiting for its entries" and "LDS reads + dot products" (shader cycles)
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(((PD - 1) & 15) | (7 << 4) | (15 << 8));
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        step(ring[k]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+        tr_wait += (uint32_t)(c1 - c0);
+        tr_work += (uint32_t)(c2 - c1);
+#else
         step(ring[k]);                 // the slot's words are dead once their addresses are formed ...
+#endif
         ring[k] = fetch(t + PD + k);   // ... so the refill lands in the same registers (no copy at the back-edge)
       }
     }
@@ -978,7 +991,8 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   if (p.trace && lane == 0) {
     unsigned long long* o = p.trace + ((size_t)block * PK_MAX_NW + wave) * 8;
     tr[3] = __builtin_readcyclecounter() - cyc0;  // shader cycles from entry to end (slot 3 is not a time stamp)
-    for (int i = 0; i < 7; ++i) o[i] = tr[i];
+    tr[7] = ((unsigned long long)tr_wait << 32) | tr_work;  // steps of the main loop: cycles waiting for entries | cycles in LDS reads + dots
+    for (int i = 0; i < 8; ++i) o[i] = tr[i];
   }
 #endif
 }

@@ -525,6 +525,7 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
 # (data_ptr, _version, shape), bounded in bytes.  A caller that passes a fresh view object on every call never hits: after
 # RAW_OP_PREPACK_MAX_MISSES packs without a single hit the cache switches itself off.  Nothing is packed while a hipGraph is
 # being captured (the pack synchronises); outputs equal the direct kernel's up to fp32 summation order.
+MATMAT_GEMM_MIN_ROWS = 7              # rows (batch x sequence) from which aqlm::code1x16_matmat runs the MFMA kernel (= the module's gemv rule + 1)
 RAW_OP_PREPACK = True                 # set False to keep the raw op on the direct kernel
 RAW_OP_PREPACK_MIN_CODES = 500_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
 RAW_OP_PREPACK_MAX_BYTES = 4 << 30  # of packed buffers held for callers of the raw op (modules keep their own)
@@ -593,6 +594,13 @@ def code1x16_matmat(input, codes, codebooks, scales, bias=None):
     """aqlm::code1x16_matmat (cuda_kernel.py:13-22, cuda_kernel.cpp:148-182)."""
     if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536:
         raise NotImplementedError(f"code1x16_matmat needs codebooks [1, 65536, 1, g], got {tuple(codebooks.shape)}")
+    rows = input.numel() // input.shape[-1] if input.shape[-1] else 0
+    if rows >= MATMAT_GEMM_MIN_ROWS and input.shape[-1] % 64 == 0 and input.dtype == codebooks.dtype and codebooks.shape[2] == 1:
+        # the matvec kernels pay one more LDS gather + 4 dot products per code and input row (prepacked 4096->11008:
+        # 9 / 18 / 35 us for 1 / 4 / 8 rows); from 7 rows on the MFMA kernel (~16 / 28 us for up to 16 rows at
+        # 4096->4096 / 4096->11008, one gather per code whatever the batch) is the faster way through the same op.  The
+        # reference relaunches its matvec once per row here (cuda_kernel.cpp:165-175).
+        return code1x16_matmat_dequant(input, codes, codebooks, scales, bias)
     packed = _raw_packed_for(codes, codebooks, input)
     if packed is not None and scales.dtype == input.dtype and input.device == codes.device:
         return code1x16_matmat_packed(input, packed, codebooks, scales, bias)

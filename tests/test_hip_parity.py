@@ -623,9 +623,11 @@ def test_raw_op_packs_large_layers_transparently(hk, monkeypatch):
     check_close(y_a.float().cpu().numpy(), y64, torch.float16, "raw op, packed through the cache")
     y_direct = hk._gemv(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "1x16")
     check_close(y_a.float().cpu().numpy(), y_direct.float().cpu().numpy().astype(np.float64), torch.float16, "cache vs direct")
-    # more rows than one launch takes, a bf16 input on an fp16 layer: the direct path's behaviour, unchanged
+    # 7 rows and more go to the MFMA kernel (same op, other summation order); a bf16 input on an fp16 layer raises
     x9 = T["x"][:1].expand(9, fin).contiguous()
-    assert torch.equal(hk.code1x16_matmat(x9, T["codes"], T["codebooks"], T["scales"], T["bias"])[0], y_direct[0])
+    y9 = hk.code1x16_matmat(x9, T["codes"], T["codebooks"], T["scales"], T["bias"])
+    check_close(y9[0].float().cpu().numpy(), y64[0], torch.float16, "raw op, 9 rows")
+    assert torch.equal(y9[0], y9[8])
     with pytest.raises(NotImplementedError):
         hk.code1x16_matmat(T["x"].bfloat16(), T["codes"], T["codebooks"], T["scales"], T["bias"])
     # in-place edit of the codes: the cached buffer is stale and must not be used
@@ -917,10 +919,15 @@ def test_gemv_1x16_multi_is_bit_identical_to_separate_launches(hk, fin, fouts, g
                                                 [T["scales"] for T in Ts], [T["bias"] for T in Ts])
     assert len(outs) == len(fouts)
     for L, T, y in zip(Ls, Ts, outs):
-        single = hk.code1x16_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+        single = hk._gemv(x, T["codes"], T["codebooks"], T["scales"], T["bias"], "1x16")   # the matvec kernel, launch by launch
         assert y.shape == single.shape and torch.equal(y, single)
         y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
         check_close(y.float().cpu().numpy(), y64, dtype, f"multi 1x16g{g} {fin}->{L['codes'].shape[0]}")
+        # the raw op itself: the same kernel up to 6 rows, the MFMA kernel from 7 rows on -- the oracle holds either way
+        raw = hk.code1x16_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
+        check_close(raw.float().cpu().numpy(), y64, dtype, f"raw op, {batch} rows")
+        if batch < hk.MATMAT_GEMM_MIN_ROWS:
+            assert torch.equal(raw, single)
 
 
 @pytest.mark.parametrize("fin,fouts,dt", [

@@ -642,6 +642,9 @@ static void bench_trace(int in, int out) {
         if (us > 0) { sum += (double)h[(b * NWMAX + w) * 8 + 3] / us; ++cnt; }
       }
       printf("  shader clock (s_memtime cycles per microsecond of a wave's life, mean): %.0f MHz\n", cnt ? sum / cnt : 0.0);
+      double wsum = 0, ksum = 0; int wc = 0;
+      for (int b = 0; b < 256; ++b) for (int w = 0; w < NW; ++w) { const unsigned long long v = h[(b * NWMAX + w) * 8 + 7]; wsum += (double)(v >> 32); ksum += (double)(v & 0xffffffffull); ++wc; }
+      printf("  main-loop steps, shader cycles per wave (mean): waiting for entries %.0f, LDS reads + dots %.0f  (%d steps)\n", wsum / wc, ksum / wc, layers[0].desc.steps / 3 * 3);
     }
     {  // who finishes late?  "loop done" by XCD (block % 8) and by wave index
       printf("  loop done by block %% 8:");
