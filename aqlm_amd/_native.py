@@ -90,6 +90,7 @@ SIGNATURES = {
     "aqlm_hip_gemv_1x16_packed_cells": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_1x16_packed_chain": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed_partials": (_ci, [_descp, _vp, _vp, _vp, _ci, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemv_1x16_packed_publish": (_ci, [_descp, _vp, _vp, _vp, _ci, _cl, _ci, _xgp, _vp, _vp, _vp]),
     "aqlm_hip_xgmi_state_bytes": (_sz, [_ci]),
     "aqlm_hip_xgmi_finalize": (_ci, [_xgp, _vp, _vp, _vp, _vp, _ci, _ci, _cl, _ci, _vp]),
     "aqlm_hip_gemv_8x8_lut": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),

@@ -540,6 +540,13 @@ struct PackedGemvParams {
   // chain prefetch (optional): the layer that runs NEXT on this stream.  NPW extra waves of every workgroup pull the
   // next layer's stream of the same workgroup index (same XCD under the observed block % 8 placement) and a share of
   // its codebook slice towards this XCD's L2 while the other waves compute -- the next launch then starts L2-warm.
+  // row-parallel shards (one-shot all-reduce over xGMI, xgmi_reduce.hip): instead of writing y, the workgroup that owns
+  // a row's total PUBLISHES it -- fp32, system-scope store -- in this rank's pub buffer, and the last workgroup of the
+  // launch raises the rank's flag.  nullptr: ordinary launch.
+  float* pub;                    // this rank's pub[2][max_elems]
+  uint32_t* pub_flag;            // this rank's flag[2]
+  uint32_t* pub_epoch;           // [0] epoch, [4..11] arrival counters of the 8 workgroup shards, [12] top counter
+  uint32_t pub_max_elems;
   const uint8_t* next_ent;       // entry area of the next layer's packed buffer (nullptr: no prefetch)
   const uint8_t* next_codebook;
   uint32_t next_block_bytes;     // bytes of one workgroup's stream in the next layer (NW' * T' KiB)
@@ -917,6 +924,12 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   __syncthreads();
   AQLM_TRACE(5);
   // ---- epilogue: row r = rowval[r] + the column remainders of the columns it crosses, in column order -------------
+  float* pub_half = nullptr;
+  uint32_t pub_e = 0u;
+  if (p.pub != nullptr && p.acc != nullptr) {  // row-parallel shard: publish instead of writing y (epoch parity picks the half)
+    pub_e = __hip_atomic_load(p.pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pub_half = p.pub + (size_t)(pub_e & 1u) * p.pub_max_elems;
+  }
   {
     const uint32_t* rs = reinterpret_cast<const uint32_t*>(smem_raw + rowstart_off);
     const float* rowval = reinterpret_cast<const float*>(smem_raw + rowval_off);
@@ -970,8 +983,8 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
           mine[b] = ((unsigned long long)q << PK_VAL_SHIFT) + (finite ? 1ull : 1ull + (1ull << PK_CNT_BITS));
           old[b] = __hip_atomic_fetch_add(p.acc + (size_t)b * p.M + row, mine[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const float scale = T_::to_float(p.scales[row]);
-        const float bias = p.bias ? T_::to_float(p.bias[row]) : 0.f;
+        const float scale = pub_half ? 1.f : T_::to_float(p.scales[row]);
+        const float bias = (pub_half || !p.bias) ? 0.f : T_::to_float(p.bias[row]);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
           if ((old[b] & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
@@ -979,9 +992,34 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
             const long long sum = (long long)cell >> PK_VAL_SHIFT;
             float sv = (float)ldexp((double)sum, -sh[b]);
             if ((cell >> PK_CNT_BITS) & PK_CNT_MASK) sv = __builtin_nanf("");
-            p.y[(size_t)b * p.y_row_stride + row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
+            if (pub_half)  // the shard's fp32 total, visible to the peers (write-through, system scope); scale / bias later
+              __hip_atomic_store(pub_half + (size_t)b * p.M + row, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else
+              p.y[(size_t)b * p.y_row_stride + row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
             __hip_atomic_store(p.acc + (size_t)b * p.M + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+        }
+      }
+    }
+  }
+  if (pub_half) {
+    // Every row total of this launch is published by exactly one workgroup before that workgroup arrives here: when all
+    // PK_NST workgroups have arrived (8 sharded counters of PK_NST / 8 arrivals, then one of 8 -- a single counter would
+    // serialise 256 device-scope atomics), everything is out and the rank's flag goes up.  Stores are drained first
+    // (write-through + vmcnt(0) == published, cdna_hip_programming.md Guideline 16 R1).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t* shard = p.pub_epoch + 4 + (block & 7);
+      const uint32_t a = __hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a + 1u == (uint32_t)(PK_NST / 8)) {
+        __hip_atomic_store(shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t = __hip_atomic_fetch_add(p.pub_epoch + 12, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == 8u) {
+          __hip_atomic_store(p.pub_epoch + 12, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(p.pub_flag + (pub_e & 1u), pub_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -1014,6 +1052,10 @@ struct PackedGemvRest {
   const uint8_t* next_ent;
   const uint8_t* next_codebook;
   uint32_t next_block_bytes;
+  float* pub;
+  uint32_t* pub_flag;
+  uint32_t* pub_epoch;
+  uint32_t pub_max_elems;
 #ifdef AQLM_PACKED_TRACE
   unsigned long long* trace;
   int dbg;
@@ -1032,6 +1074,10 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* c
   p.next_ent = rest.next_ent;
   p.next_codebook = rest.next_codebook;
   p.next_block_bytes = rest.next_block_bytes;
+  p.pub = rest.pub;
+  p.pub_flag = rest.pub_flag;
+  p.pub_epoch = rest.pub_epoch;
+  p.pub_max_elems = rest.pub_max_elems;
   p.ent = ent;
   p.winfo = rest.winfo;
   p.rowstart = rowstart;
@@ -1677,6 +1723,11 @@ struct PackedFused {
   long y_row_stride = 0;
   float cb_absmax = 0.f;
   void* cells = nullptr;  // caller-owned accumulator cells [rows][M] u64, zero at rest (one set per stream); null: the cells inside the packed buffer
+  // row-parallel shard: publish the fp32 totals (aqlm_hip_gemv_1x16_packed_publish) instead of writing y
+  float* pub = nullptr;
+  uint32_t* pub_flag = nullptr;
+  uint32_t* pub_epoch = nullptr;
+  uint32_t pub_max_elems = 0;
 };
 
 // the layer that runs next on the stream (chain prefetch); all null = none
@@ -1689,7 +1740,7 @@ struct PackedNext {
 static int packed_launch_main(const PackedLayout& L, const void* packed, const void* codebook, const uint16_t* x, int nb,
                               long x_row_stride, int dtype, void* workspace, size_t workspace_bytes, hipStream_t stream,
                               const char* who, const PackedFused& fused = PackedFused{}, const PackedNext& next = PackedNext{}) {
-  const size_t need = fused.y ? 0 : (size_t)PK_S * nb * L.M * sizeof(float);
+  const size_t need = (fused.y || fused.pub) ? 0 : (size_t)PK_S * nb * L.M * sizeof(float);
   if (need && (!workspace || workspace_bytes < need)) {
     set_last_error("%s: workspace of %zu bytes required, got %zu", who, need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
@@ -1702,7 +1753,11 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.codebook = (const uint8_t*)codebook;
   p.x = x;
   p.partial = (float*)workspace;
-  if (fused.y) {
+  if (fused.y || fused.pub) {
+    p.pub = fused.pub;
+    p.pub_flag = fused.pub_flag;
+    p.pub_epoch = fused.pub_epoch;
+    p.pub_max_elems = fused.pub_max_elems;
     p.acc = fused.cells ? (unsigned long long*)fused.cells : (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);
     p.cb_absmax = fused.cb_absmax;
     p.scales = (const uint16_t*)fused.scales;
@@ -1735,6 +1790,10 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
     const size_t lds_final = decltype(lds_map)::total(L.in_groups, L.RG, npw);
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_final)) return e;
     PackedGemvRest rest{};
+    rest.pub = p.pub;
+    rest.pub_flag = p.pub_flag;
+    rest.pub_epoch = p.pub_epoch;
+    rest.pub_max_elems = p.pub_max_elems;
     if (npw) {
       rest.next_ent = next.ent;
       rest.next_codebook = next.codebook;
@@ -1911,6 +1970,29 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
                                        int num_segments, const void* x, int in_features, int batch, long x_row_stride,
                                        int dtype, void* workspace, size_t workspace_bytes, void* cells, size_t cells_bytes,
                                        void* stream_);
+
+extern "C" int aqlm_hip_gemv_1x16_packed_publish(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+                                                 const void* x, int batch, long x_row_stride, int dtype,
+                                                 const aqlm_hip_xgmi* xg, void* pub_own, void* flag_own, void* stream_) {
+  PackedLayout L;
+  int max_b = 0;
+  if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed_publish", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b))
+    return e;
+  if (!xg || !xg->epoch || !pub_own || !flag_own || !packed_fused(desc) || batch > max_b ||
+      (size_t)batch * desc->out_features > (size_t)xg->max_elems) {
+    set_last_error("aqlm_hip_gemv_1x16_packed_publish: needs the one-shot all-reduce state, a descriptor with the codebook range, "
+                   "and batch (%d) rows that fit one launch (<= %d) and the state (%d elements)", batch, max_b, xg ? xg->max_elems : 0);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  PackedFused fz;
+  fz.cb_absmax = desc->codebook_absmax;
+  fz.pub = (float*)pub_own;
+  fz.pub_flag = (uint32_t*)flag_own;
+  fz.pub_epoch = (uint32_t*)xg->epoch;
+  fz.pub_max_elems = (uint32_t)xg->max_elems;
+  return packed_launch_main(L, packed, codebook, (const uint16_t*)x, batch, x_row_stride, dtype, nullptr, 0, (hipStream_t)stream_,
+                            "aqlm_hip_gemv_1x16_packed_publish", fz);
+}
 
 extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
                                                int num_segments, const void* x, int in_features, int batch,

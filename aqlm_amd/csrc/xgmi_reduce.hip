@@ -135,7 +135,7 @@ extern "C" size_t aqlm_hip_xgmi_state_bytes(int max_elems) {
 extern "C" int aqlm_hip_xgmi_finalize(const aqlm_hip_xgmi* xg, const void* partial, const void* scales, const void* bias,
                                       void* y, int out_features, int batch, long y_row_stride, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!xg || !partial || !scales || !y || !xg->peer_pub || !xg->peer_flag || !xg->epoch || !xg->status) {
+  if (!xg || !scales || !y || !xg->peer_pub || !xg->peer_flag || !xg->epoch || !xg->status) {
     set_last_error("aqlm_hip_xgmi_finalize: null pointer argument");
     return AQLM_HIP_E_INVALID;
   }
@@ -166,7 +166,7 @@ extern "C" int aqlm_hip_xgmi_finalize(const aqlm_hip_xgmi* xg, const void* parti
   p.max_elems = (uint32_t)xg->max_elems;
   p.spin_limit = xg->spin_limit ? xg->spin_limit : (1u << 22);  // x ~0.5 us per poll: seconds, not forever
   const int blocks = (out_features * batch + 255) / 256;
-  hipLaunchKernelGGL(xgmi_publish_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  if (partial) hipLaunchKernelGGL(xgmi_publish_kernel, dim3(blocks), dim3(256), 0, stream, p);  // null: the matvec kernel has published
   if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(xgmi_reduce_kernel<F16>, dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(xgmi_reduce_kernel<BF16>, dim3(blocks), dim3(256), 0, stream, p);
   return check_hip(hipGetLastError(), "xgmi finalize launch");

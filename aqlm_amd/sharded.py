@@ -42,6 +42,9 @@ import torch.nn as nn
 from .inference_kernels import get_forward_pass_kernel
 
 
+XGMI_FUSED_PUBLISH = True  # collective="xgmi": the shard's matvec publishes its totals itself (2 launches instead of 3)
+
+
 def shard_bounds(n: int, world: int, rank: int, multiple: int = 1):
     """Contiguous, nearly equal split of ``n`` units in chunks of ``multiple`` units: returns [lo, hi)."""
     blocks = (n + multiple - 1) // multiple
@@ -183,8 +186,22 @@ class ShardedQuantizedLinear(nn.Module):
         x2 = hip_kernel._flat_rows(xs)
         dt = hip_kernel._dtype_id(xs)
         y = torch.empty((rows, self.out_features), dtype=xs.dtype, device=xs.device)
-        ws = hip_kernel._workspace(xs.device, 16 * rows * self.out_features * 4)
         stream = hip_kernel._stream_ptr(xs.device)
+        hip_kernel._refresh_range(self._packed, self.codebooks)
+        if XGMI_FUSED_PUBLISH and hip_kernel.FUSED_FINALIZE and self._packed.desc.codebook_absmax > 0.0:
+            # two launches: the matvec publishes the shard's totals itself (last-arrival branch of its finalize), then the
+            # reduce.  Falls back to partials + publish + reduce when the rows do not fit one launch.
+            pub, flag = self._xgmi.own_pub_flag()
+            with torch.cuda.device(xs.device):
+                rc = _native.lib.aqlm_hip_gemv_1x16_packed_publish(ctypes.byref(self._packed.desc), self._packed.data_ptr(),
+                                                                   self.codebooks.data_ptr(), x2.data_ptr(), rows, x2.stride(0),
+                                                                   dt, ctypes.byref(self._xgmi.xg), pub, flag, stream)
+                if rc == 0:
+                    self._xgmi.reduce(self.scales, self._bias_all, y, self.out_features, rows, dt, stream)
+                    return y.reshape(xs.shape[:-1] + (self.out_features,))
+                if rc != _native.E_UNSUPPORTED:
+                    _native.check(rc, "aqlm gemv_1x16_packed_publish")
+        ws = hip_kernel._workspace(xs.device, 16 * rows * self.out_features * 4)
         with torch.cuda.device(xs.device):
             rc = _native.lib.aqlm_hip_gemv_1x16_packed_partials(ctypes.byref(self._packed.desc), self._packed.data_ptr(),
                                                                 self.codebooks.data_ptr(), x2.data_ptr(), rows, x2.stride(0),

@@ -10,6 +10,7 @@ State layout per rank (int32 words of one zero-filled device allocation; mirrore
     [0, 2 n)            pub[2][n] fp32          n = max_elems
     [2 n, 2 n + 2)      flag[2]
     [2 n + 16, +3)      epoch (starts at 1), publish ticket, reduce ticket
+    [2 n + 20, +9)      arrival counters of the publishing matvec (8 workgroup shards + 1)
     [2 n + 32]          status (1 = a peer timed out)
 """
 from __future__ import annotations
@@ -99,6 +100,23 @@ class OneShotAllReduce:
                                                 out_features, dtype_id, stream)
         if rc:
             _native.check(rc, "aqlm xgmi finalize")
+
+    def own_pub_flag(self):
+        """Addresses of this rank's own pub buffer and flag words (what the publishing matvec writes)."""
+        base = self.state.data_ptr()
+        return base, base + 8 * self.max_elems
+
+    def reduce(self, scales: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, out_features: int, batch: int,
+               dtype_id: int, stream: int) -> None:
+        """The reduce half alone: the shard's matvec has published its totals itself
+        (aqlm_hip_gemv_1x16_packed_publish), so the call is one launch."""
+        from . import _native
+
+        rc = _native.lib.aqlm_hip_xgmi_finalize(ctypes.byref(self.xg), None, scales.data_ptr(),
+                                                None if bias is None else bias.data_ptr(), y.data_ptr(), out_features, batch,
+                                                out_features, dtype_id, stream)
+        if rc:
+            _native.check(rc, "aqlm xgmi reduce")
 
     def timed_out(self) -> bool:
         """Synchronising read of the status word (diagnostics / tests)."""

@@ -291,6 +291,17 @@ int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* desc, const v
                                        void* stream);
 int aqlm_hip_xgmi_finalize(const aqlm_hip_xgmi* xg, const void* partials, const void* scales, const void* bias, void* y,
                            int out_features, int batch, long y_row_stride, int dtype, void* stream);
+/*
+ * Two launches instead of three: aqlm_hip_gemv_1x16_packed_publish is the shard's matvec with the single-kernel finalize
+ * (descriptor with codebook_absmax > 0) whose last-arrival branch writes the row's fp32 total into this rank's pub buffer
+ * (`pub_own` / `flag_own` = the rank's own pub and flag addresses, i.e. peer_pub[rank] / peer_flag[rank]) and whose last
+ * workgroup raises the flag; then aqlm_hip_xgmi_finalize with partials == NULL runs the reduce only (poll the peers' flags,
+ * add the vectors in rank order, scale + bias + one rounding).  AQLM_HIP_E_UNSUPPORTED when the rows do not fit one launch
+ * or the codebook range is unknown: use the partials form above.  State words used: epoch + 4 .. + 12 (arrival counters).
+ */
+int aqlm_hip_gemv_1x16_packed_publish(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook, const void* x,
+                                      int batch, long x_row_stride, int dtype, const aqlm_hip_xgmi* xg, void* pub_own,
+                                      void* flag_own, void* stream);
 
 /*
  * Batch-1 matvec for 8 x 8-bit schemes (e.g. the 2-bit 8x8 g32 models; in_group_size 8, 16 or 32) through per-token

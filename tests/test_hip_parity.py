@@ -1373,10 +1373,14 @@ def test_derived_state_follows_the_parameters(hk):
 
 
 # ------------------------------------------------------------------ fused finalize + one-shot all-reduce (xGMI path)
-def test_xgmi_fused_finalize_world1(hk):
+@pytest.mark.parametrize("fused_publish", [True, False])
+def test_xgmi_fused_finalize_world1(hk, fused_publish):
     """ShardedQuantizedLinear(collective="xgmi") on a single rank: the published vector is read back through the same
     protocol (flag, system-scope loads) and must give exactly the ordinary prepacked result; repeated calls advance the
-    epoch (both halves of the double buffer), also inside a captured hipGraph."""
+    epoch (both halves of the double buffer), also inside a captured hipGraph.  Both forms: the matvec publishes its totals
+    itself (2 launches; same bits as the single-kernel finalize) and partials + publish + reduce (3 launches; same bits
+    as the two-kernel finalize)."""
+    import aqlm_amd.sharded as sharded
     from aqlm_amd.sharded import ShardedQuantizedLinear
 
     fin, fout = 2048, 1536
@@ -1387,38 +1391,40 @@ def test_xgmi_fused_finalize_world1(hk):
     import aqlm_amd.inference as inf
 
     old, inf.PREPACK_MIN_CODES = inf.PREPACK_MIN_CODES, 100_000
+    old_fp, sharded.XGMI_FUSED_PUBLISH = sharded.XGMI_FUSED_PUBLISH, fused_publish
     try:
         ys = [m(T["x"][:b]) for b in (1, 4, 2, 1, 3)]
+        assert m._xgmi is not None and m._xgmi_ok and not m._xgmi.timed_out()
+        hk.set_fused_finalize(fused_publish)   # the reference with the same arithmetic
+        try:
+            for y, b in zip(ys, (1, 4, 2, 1, 3)):
+                ref = hk.code1x16_matmat_packed(T["x"][:b], m._packed, T["codebooks"], T["scales"], T["bias"])
+                assert torch.equal(y, ref), b
+        finally:
+            hk.set_fused_finalize(True)
+        y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(ys[1].float().cpu().numpy(), y64, torch.float16, "xgmi world 1")
+        # graph capture: the epoch lives in device memory, so replays keep working
+        static_x = T["x"][:1].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(graph, stream=s):
+                y_static = m(static_x)
+        hk.set_fused_finalize(fused_publish)
+        try:
+            for k in range(5):
+                static_x.copy_(T["x"][k % 4:k % 4 + 1])
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(y_static, hk.code1x16_matmat_packed(T["x"][k % 4:k % 4 + 1], m._packed, T["codebooks"], T["scales"], T["bias"]))
+        finally:
+            hk.set_fused_finalize(True)
+        assert not m._xgmi.timed_out()
     finally:
         inf.PREPACK_MIN_CODES = old
-    assert m._xgmi is not None and m._xgmi_ok and not m._xgmi.timed_out()
-    hk.set_fused_finalize(False)  # the one-shot all-reduce finalizes fp32 slice partials like the two-kernel form: same bits
-    try:
-        for y, b in zip(ys, (1, 4, 2, 1, 3)):
-            ref = hk.code1x16_matmat_packed(T["x"][:b], m._packed, T["codebooks"], T["scales"], T["bias"])
-            assert torch.equal(y, ref), b
-    finally:
-        hk.set_fused_finalize(True)
-    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-    check_close(ys[1].float().cpu().numpy(), y64, torch.float16, "xgmi world 1")
-    # graph capture: the epoch lives in device memory, so replays keep working
-    static_x = T["x"][:1].clone()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(graph, stream=s):
-            y_static = m(static_x)
-    hk.set_fused_finalize(False)  # reference with the same arithmetic (fp32 slice partials, summed in slice order)
-    try:
-        for k in range(5):
-            static_x.copy_(T["x"][k % 4:k % 4 + 1])
-            graph.replay()
-            torch.cuda.synchronize()
-            assert torch.equal(y_static, hk.code1x16_matmat_packed(T["x"][k % 4:k % 4 + 1], m._packed, T["codebooks"], T["scales"], T["bias"]))
-    finally:
-        hk.set_fused_finalize(True)
-    assert not m._xgmi.timed_out()
+        sharded.XGMI_FUSED_PUBLISH = old_fp
 
 
 def _xgmi_two_rank_worker(rank, world, port, q):
