@@ -19,6 +19,7 @@ MAX_GEMV_BATCH = 8
 OP_GEMM_1X16_MFMA = 1
 OP_GEMV_1X16_PACKED = 3
 OP_GEMV_8X8_LUT = 4
+OP_GEMV_1X16_G16_PACKED = 5
 
 MAX_SEGMENTS = 4
 

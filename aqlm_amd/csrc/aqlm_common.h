@@ -151,7 +151,6 @@ struct Tuning {
   int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
   int gemm_variant = 0;          // large-batch 1x16 op: 0 = LDS-DMA pipeline (gemm_1x16_glds_kernel), 1 = register-staged split-K kernel (round 1)
-  int gemm_wk = 0;               // LDS-DMA pipeline: rows per block 128 (1) or 64 with the k steps of a chunk on two waves (2); 0 = by batch size
   int gemm_debug = 0;            // LDS-DMA pipeline: knock-out switches for timing experiments (never set in production: results are wrong)
   int gemm_store_nt = 0;         // LDS-DMA pipeline: fp32 partials stored with the non-temporal hint
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)

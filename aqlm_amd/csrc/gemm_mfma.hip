@@ -602,15 +602,14 @@ __global__ __launch_bounds__(256) void gemm_glds_finalize_kernel(const GldsFinal
 }
 
 struct GldsPlan {
-  int row_blocks, ksplit, chunks_base, chunks_rem, nbt, xw, wk;
+  int row_blocks, ksplit, chunks_base, chunks_rem, nbt, xw;
 };
 
 // K split: enough blocks for one round of the chip, K slices of >= 8 chunks (512 k) where K allows, never fewer than
 // NS - 1 chunks (the pipeline's prologue), chunks dealt evenly.
-static bool plan_glds(int B, int M, int K, GldsPlan& g, int wk = 0) {
+static bool plan_glds(int B, int M, int K, GldsPlan& g) {
   const int kchunks = K / BK;
   if (K % BK != 0 || kchunks < GL_NS - 1 || B < 1 || B > 128) return false;
-  g.wk = 1;
   g.row_blocks = (M + 127) / 128;
   int ksplit = std::max(1, 256 / g.row_blocks);
   ksplit = std::min(ksplit, std::max(1, kchunks / 8));
@@ -627,7 +626,7 @@ static bool plan_glds(int B, int M, int K, GldsPlan& g, int wk = 0) {
 template <class T, int G>
 static int launch_glds(const GldsParams& p, const GldsPlan& g, hipStream_t stream) {
   const int rb8 = ((p.M + 127) / 128 + 7) / 8;  // 128-row groups per XCD
-  const dim3 grid((unsigned)(8 * rb8 * g.wk * p.ksplit));
+  const dim3 grid((unsigned)(8 * rb8 * p.ksplit));
   auto go = [&](auto kern, size_t lds) -> int {
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3((GL_WAVES + GL_PRODUCERS) * 64), lds, stream, p);
@@ -684,16 +683,15 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   if (op == AQLM_HIP_OP_GEMV_8X8_LUT && batch > 0 && out_features > 0 && in_features > 0 && in_features % batch == 0)
     return aqlm::gemv_8x8_lut_workspace(out_features, in_features, /*in_group_size=*/batch);
   if (batch <= 0 || out_features <= 0 || in_features <= 0) return 0;
-  if (op == AQLM_HIP_OP_GEMV_1X16_PACKED)  // fp32 partials [16 slices][rows of x][out]
-    return (size_t)16 * std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * out_features * sizeof(float);
+  if (op == AQLM_HIP_OP_GEMV_1X16_PACKED || op == AQLM_HIP_OP_GEMV_1X16_G16_PACKED)  // fp32 partials [slices][rows of x][out]
+    return (size_t)(op == AQLM_HIP_OP_GEMV_1X16_PACKED ? 16 : 32) * std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * out_features * sizeof(float);
   if (op != AQLM_HIP_OP_GEMM_1X16_MFMA) return 0;
   // covers both kernels of the op (the LDS-DMA pipeline and the register-staged one behind the `gemm_variant` knob)
   const GemmPlan g = plan_gemm(batch, out_features, in_features);
   size_t need = (size_t)g.ksplit * out_features * g.Bpad * sizeof(float);
   GldsPlan q;
-  for (int wk = 1; wk <= 2; ++wk)  // whichever block shape the tuning picks at call time
-    if (plan_glds(std::min(batch, 128), out_features, in_features, q, wk) && q.ksplit > 1)
-      need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
+  if (plan_glds(std::min(batch, 128), out_features, in_features, q) && q.ksplit > 1)
+    need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
   return need;
 }
 
@@ -771,7 +769,7 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
         f.ksplit = q.ksplit;
         f.row_blocks = (out_features + 127) / 128;
         f.bchunks = (nb + 7) / 8;
-        f.rb_rows = 128 / q.wk;
+        f.rb_rows = 128;
         const dim3 grid((unsigned)(8 * ((f.row_blocks + 7) / 8) * f.bchunks));
         if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(gemm_glds_finalize_kernel<F16>, grid, dim3(256), 0, stream, f);
         else hipLaunchKernelGGL(gemm_glds_finalize_kernel<BF16>, grid, dim3(256), 0, stream, f);

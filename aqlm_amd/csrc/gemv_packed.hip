@@ -47,7 +47,44 @@
 
 #include "aqlm_common.h"
 
+// The file is compiled twice: as it is for 8-element codebook vectors (16 B; 16 slices of 4096 entries x 16 row groups), and
+// through gemv_packed_g16.hip for 16-element vectors (AQLM_PK_G 16, AQLM_PK_S_LOG 5, AQLM_PK_NG_LOG 3: 32 B per entry, 32 slices
+// of 2048 entries = 64 KiB, 8 row groups; two ds_read_b128 per side and entry).  The second build lives in its own namespace
+// and exports its entry points under aqlm_hip_g16_*; the public entries of the first build forward to them (in_group_size 16 /
+// a descriptor with slices_log2 == 5).  Matches the reference kernel's template on g in {8, 16} (cuda_kernel.cu:476-521).
+#ifndef AQLM_PK_G
+#define AQLM_PK_G 8
+#endif
+#if AQLM_PK_G == 16
+#define PK_NS pk_g16
+#define aqlm_hip_prepack_1x16_bytes aqlm_hip_g16_prepack_1x16_bytes
+#define aqlm_hip_prepack_1x16 aqlm_hip_g16_prepack_1x16
+#define aqlm_hip_packed_desc_read aqlm_hip_g16_packed_desc_read
+#define aqlm_hip_unpack_1x16 aqlm_hip_g16_unpack_1x16
+#define aqlm_hip_gemv_1x16_packed_cells aqlm_hip_g16_gemv_1x16_packed_cells
+#define aqlm_hip_gemv_1x16_packed aqlm_hip_g16_gemv_1x16_packed
+#define aqlm_hip_gemv_1x16_packed_chain aqlm_hip_g16_gemv_1x16_packed_chain
+#define aqlm_hip_gemv_1x16_packed_partials aqlm_hip_g16_gemv_1x16_packed_partials
+#define aqlm_hip_gemv_1x16_packed_publish aqlm_hip_g16_gemv_1x16_packed_publish
+#define aqlm_hip_gemv_1x16_packed_multi aqlm_hip_g16_gemv_1x16_packed_multi
+#define aqlm_hip_gemv_1x16_packed_multi_cells aqlm_hip_g16_gemv_1x16_packed_multi_cells
+#else
+#define PK_NS pk_g8
+#endif
+
 namespace aqlm {
+namespace PK_NS {
+
+constexpr int PK_G = AQLM_PK_G;                              // elements of a codebook vector
+constexpr int PK_VSH = PK_G == 8 ? 4 : 5;                    // log2(bytes of a vector)
+constexpr uint32_t PK_VB = 1u << PK_VSH;                     // bytes of a codebook vector == bytes of x per input group
+constexpr uint32_t PK_HMASK = 0xfff0u;                       // LDS byte offset inside a 16-bit half of an entry
+// 32-byte vectors are read as two 16-byte halves.  All vectors start at even 16-B slots, so a plain "first halves, then second
+// halves" would use only 8 of the 16 bank groups per read.  Odd lanes therefore read the halves in the opposite order: bit 4 of
+// BOTH halves of an entry (spare: the offsets are multiples of 32) is the parity of the lane the entry is stored for, the
+// first read uses the offsets as they are, the second flips bit 4.
+constexpr uint32_t PK_PARITY_BITS = PK_G == 16 ? 0x00100010u : 0u;
+static_assert(PK_G == 8 || PK_G == 16, "codebook vectors of 8 or 16 elements");
 
 #ifndef AQLM_PK_S_LOG
 #define AQLM_PK_S_LOG 4  // 16 slices of 64 KiB; 5 = 32 slices of 32 KiB (experiment builds: tools/microbench)
@@ -64,10 +101,10 @@ constexpr int PK_NST = PK_NG * PK_S;         // streams == workgroups of a layer
 #endif
 constexpr int PK_CODE_BITS = 16 - PK_S_LOG;  // bits of a code inside its slice
 constexpr int PK_SLICE_ENTRIES = 1 << PK_CODE_BITS;
-constexpr uint32_t PK_SLICE_BYTES = PK_SLICE_ENTRIES * 16;
+constexpr uint32_t PK_SLICE_BYTES = PK_SLICE_ENTRIES * PK_VB;
 constexpr int PK_MAX_NW = 16;
 constexpr int PK_MAX_T = 1024;
-constexpr int PK_MAX_GROUPS = 4094;          // j needs 12 bits, in_groups itself is the null slot
+constexpr int PK_MAX_GROUPS = (int)(65536u / PK_VB) - 2;  // the x offset of a group is a 16-bit byte offset; in_groups itself is the null slot
 constexpr uint32_t PK_MAGIC = 0x36505141u;   // "AQP6"
 constexpr int PK_VERSION = 6;
 constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (x first, slice behind it)
@@ -97,18 +134,18 @@ struct PackedLayout {
 __host__ __device__ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static bool packed_shape_ok(int out_features, int in_features, int g) {
-  return g == 8 && out_features > 0 && in_features > 0 && in_features % 8 == 0 && in_features / 8 <= PK_MAX_GROUPS &&
+  return g == PK_G && out_features > 0 && in_features > 0 && in_features % PK_G == 0 && in_features / PK_G <= PK_MAX_GROUPS &&
          (out_features + PK_NG - 1) / PK_NG <= 32767 - PK_MAX_NW;
 }
 
 static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1, int EB = 4) {
-  if (!packed_shape_ok(out_features, in_features, 8) || NW < 1 || NW > PK_MAX_NW || T < 1 || T > PK_MAX_T) return false;
-  if (XC < 1 || XC > pk_max_x_copies(in_features / 8)) return false;
-  if (EB != 4 && !(EB == 3 && T <= 32)) return false;  // 3-byte entries: the row-end flags of a column are one 32-bit mask
+  if (!packed_shape_ok(out_features, in_features, PK_G) || NW < 1 || NW > PK_MAX_NW || T < 1 || T > PK_MAX_T) return false;
+  if (XC < 1 || XC > pk_max_x_copies(in_features / PK_G) || (PK_G != 8 && XC != 1)) return false;
+  if (EB != 4 && !(EB == 3 && T <= 32 && PK_G == 8)) return false;  // 3-byte entries: the row-end flags of a column are one 32-bit mask
   L.XC = XC;
   L.EB = EB;
   L.M = out_features;
-  L.in_groups = in_features / 8;
+  L.in_groups = in_features / PK_G;
   L.RG = (out_features + PK_NG - 1) / PK_NG;
   L.NW = NW;
   L.T = T;
@@ -236,11 +273,18 @@ __global__ __launch_bounds__(256) void pk_scatter_kernel(const uint16_t* codes, 
         const size_t st = (size_t)g * PK_S + s;
         const uint32_t i = cnt[s] + __popcll(m & ((1ull << lane) - 1ull));
         const uint32_t q = a[st * (RG + 1) + r] + (i >> 2);
-        ent[pk_entry_index(q, i & 3, st, NW, T)] = ((uint32_t)j << 20) | ((code & (PK_SLICE_ENTRIES - 1)) << 4);
+        ent[pk_entry_index(q, i & 3, st, NW, T)] = ((uint32_t)j << (16 + PK_VSH)) | ((code & (PK_SLICE_ENTRIES - 1)) << PK_VSH);
       }
       cnt[s] += __popcll(m);
     }
   }
+}
+
+// K3c (32-byte vectors): stamp the lane parity into every entry (see PK_PARITY_BITS); entry (.., t, lane, k) sits at
+// word ((..) * 64 + lane) * 4 + k.
+__global__ __launch_bounds__(256) void pk_parity_kernel(uint32_t* ent, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    ent[i] = (ent[i] & ~PK_PARITY_BITS) | (((i >> 2) & 1u) ? PK_PARITY_BITS : 0u);
 }
 
 // K3b: bank-aware order of the entries.  In the gemv kernel the 64 lanes of a wave execute entry slot (t, k) together:
@@ -317,23 +361,24 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
     for (int grp = 0; grp < 4; ++grp) {
       uint32_t ux = 0u, uc = 0u;  // bank groups taken in this (slot, service group); wave-uniform
       bool null_placed = false;   // the null entry's two addresses are already being read (further nulls are free)
-      const uint32_t null_x = 1u << (null_j & 15u), null_c = 1u;
       for (int r = 0; r < 16; ++r) {
         const int tl = pk_group_lane(grp, (r - s) & 15);  // the lane whose turn it is
+        const uint32_t par = PK_G == 16 ? (uint32_t)(tl & 1) : 0u;  // 32-byte vectors: odd lanes read the upper half first
+        const uint32_t null_x = 1u << (((null_j << (PK_VSH - 4)) & 15u) ^ par), null_c = 1u << par;
         const uint32_t ra = rowa[tl * T + t];
         const uint32_t n = rem[ra];
         const uint32_t base = ra * 4u;
         uint32_t key = 0u;  // (score + 1) << 20 | copy << 16 | (0xffff - index): the maximum is the best, lowest-index candidate
         for (uint32_t i = (uint32_t)l; i < n; i += 64u) {
           const uint32_t v = pool[base + i];
-          const uint32_t j = v >> 20;
+          const uint32_t j = v >> (16 + PK_VSH);
           uint32_t score, copy = 0u;
           if (j == null_j) score = (null_placed || (!(ux & null_x) && !(uc & null_c))) ? 3u : 0u;
           else {
-            const bool cf = !((uc >> ((v >> 4) & 15u)) & 1u);
+            const bool cf = !((uc >> (((v >> 4) & 15u) ^ par)) & 1u);
             bool xf = false;
             for (uint32_t c = 0; c < (uint32_t)XC; ++c)
-              if (!((ux >> ((j + 4u * c) & 15u)) & 1u)) { xf = true; copy = c; break; }
+              if (!((ux >> ((((j << (PK_VSH - 4)) + 4u * c) & 15u) ^ par)) & 1u)) { xf = true; copy = c; break; }
             score = xf && cf ? 4u : (xf ? 2u : (cf ? 1u : 0u));
           }
           const uint32_t kk = ((score + 1u) << 20) | (copy << 16) | (0xffffu - i);
@@ -347,10 +392,10 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
         if (key == 0u) __builtin_trap();  // every slot of a row has an entry left in the row's pool
         const uint32_t idx = 0xffffu - (key & 0xffffu), copy = (key >> 16) & 3u;
         const uint32_t v = pool[base + idx];           // same address in every lane: broadcast
-        const uint32_t j = v >> 20;
+        const uint32_t j = v >> (16 + PK_VSH);
         if (j != null_j) {
-          ux |= 1u << ((j + 4u * copy) & 15u);
-          uc |= 1u << ((v >> 4) & 15u);
+          ux |= 1u << ((((j << (PK_VSH - 4)) + 4u * copy) & 15u) ^ par);
+          uc |= 1u << (((v >> 4) & 15u) ^ par);
         } else {
           ux |= null_x;
           uc |= null_c;
@@ -358,7 +403,7 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
         }
         __syncthreads();  // everybody has read pool[base + idx] and rem[ra]
         if (l == 0) {
-          const uint32_t out = j == null_j ? v : ((v & 0x000fffffu) | ((j + copy * xstride) << 20) | (copy << 16));
+          const uint32_t out = j == null_j ? v : ((v & ((1u << (16 + PK_VSH)) - 1u)) | ((j + copy * xstride) << (16 + PK_VSH)) | (copy << 16));
           wave_ent[((size_t)t * 64 + tl) * 4 + k] = out;
           pool[base + idx] = pool[base + n - 1u];      // swap-remove
           rem[ra] = (uint16_t)(n - 1u);
@@ -512,8 +557,8 @@ __global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, cons
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t v = e[k];
-      const int j = (int)(v >> 20) - (int)((v >> 16) & 3u) * xstride;
-      if (j < in_groups && row < M) codes[(size_t)row * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | ((v >> 4) & 0xfffu));
+      const int j = (int)(v >> (16 + PK_VSH)) - (int)((v >> 16) & 3u) * xstride;
+      if (j < in_groups && row < M) codes[(size_t)row * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | ((v >> PK_VSH) & (uint32_t)(PK_SLICE_ENTRIES - 1)));
     }
     local += (int)(e0 & 1u);
   }
@@ -590,7 +635,7 @@ struct PackedLds {
   static constexpr bool XFIRST = (B == 1) && AQLM_PK_XFIRST;
   static constexpr uint32_t SLICE = XFIRST ? XWIN : 0u;
   static constexpr uint32_t X = XFIRST ? 0u : PK_SLICE_BYTES;
-  __host__ __device__ static uint32_t plane(int in_groups) { return (uint32_t)(in_groups + 1) * 16u; }
+  __host__ __device__ static uint32_t plane(int in_groups) { return (uint32_t)(in_groups + 1) * PK_VB; }
   __host__ __device__ static uint32_t rowstart(int in_groups) {
     return XFIRST ? XWIN + PK_SLICE_BYTES : PK_SLICE_BYTES + plane(in_groups) * B;
   }
@@ -643,7 +688,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 
   // ---- prologue: everything that needs no other data is issued first, in one burst -------------------------------
   const uint32_t XP = LDS::plane(p.in_groups);
-  const uint32_t xstride16 = (uint32_t)pk_x_stride(p.in_groups) * 16u;
+  const uint32_t xstride16 = (uint32_t)pk_x_stride(p.in_groups) * PK_VB;
   __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
   const int wv = wave < p.NW ? wave : p.NW - 1;  // waves beyond the stream's wave count (shared-input launches) idle
   const uint32_t wbase = (uint32_t)(((size_t)block * p.NW + wv) * p.T) * (EB == 3 ? (uint32_t)PK_WREG3 : 1024u);
@@ -681,14 +726,15 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
       __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + i * 1024 + lane * 16),
                                        (lds_void_ptr)(size_t)(LDS::SLICE + (uint32_t)i * 1024u), 16, 0, 0);
     }
-    const int nchunk = (p.in_groups + 63) >> 6;  // KiB pieces per row of x
+    const int x16 = p.in_groups * (int)(PK_VB / 16);  // 16-byte units of a row of x
+    const int nchunk = (x16 + 63) >> 6;              // KiB pieces per row of x
     // B == 1: XC rotated copies of the row (copy c at slot c * xstride); B > 1: one plane per row
     const int ncopy = B == 1 ? p.XC : B;
     for (int c = wave; c < nchunk * ncopy; c += NWD) {
       const int b = c / nchunk, i = c - b * nchunk;
       const int idx = i * 64 + lane;
       const uint32_t dst = LDS::X + (uint32_t)b * (B == 1 ? xstride16 : XP) + (uint32_t)i * 1024u;
-      if (idx < p.in_groups)
+      if (idx < x16)
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(p.x + (B == 1 ? (size_t)0 : (size_t)b * p.x_row_stride) + (size_t)idx * 8),
                                          (lds_void_ptr)(size_t)dst, 16, 0, 0);
     }
@@ -728,7 +774,9 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     wave_start_row = wi[3];
   }
   // (4) LDS that needs no data: the zero vectors the null entries point at
-  if (tid < B) *reinterpret_cast<u32x4*>(smem_raw + LDS::X + (uint32_t)tid * XP + (uint32_t)p.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};
+  if (tid < B * (int)(PK_VB / 16))  // the null entries' x: PK_VB zero bytes per row of x
+    *reinterpret_cast<u32x4*>(smem_raw + LDS::X + (uint32_t)(tid / (int)(PK_VB / 16)) * XP + (uint32_t)p.in_groups * PK_VB +
+                              (uint32_t)(tid % (int)(PK_VB / 16)) * 16u) = u32x4{0u, 0u, 0u, 0u};
   const uint32_t xmax_off = LDS::xmax(p.in_groups, p.RG);
   if (tid < B * PK_MAX_NW) *reinterpret_cast<uint32_t*>(smem_raw + xmax_off + (uint32_t)tid * 4u) = 0u;  // slots of absent waves
   AQLM_TRACE(1);  // every load of the prologue has been issued
@@ -744,7 +792,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   __builtin_amdgcn_s_barrier();
   AQLM_TRACE(2);
 
-  uint32_t mask = 0xfff0u;
+  uint32_t mask = PK_HMASK;
   asm volatile("" : "+v"(mask));  // the SDWA operand must sit in a VGPR
   // One accumulator chain per row of x for every batch size: a row's result must not depend on how many rows share the
   // launch (tested bit for bit).  Several independent chains per row were measured: no gain (the loop is not bound by
@@ -761,46 +809,57 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // x[j] (inside the x area; for B > 1 `copy` is the x copy the entry names -- the planes hold one, so its offset is
   // taken out again).  ALL LDS reads of a group of entries are issued before the first dot product: with 2 waves per SIMD
   // the loop is bound by LDS latency, not bandwidth (traced: 0.3 us per step with two entries in flight per wave).
-  constexpr int EG = B <= 2 ? 4 : (B <= 4 ? 2 : 1);  // entries per read batch (registers: EG * (1 + B) * 4)
+  constexpr int NV = (int)(PK_VB / 16);  // 16-byte reads per vector: 1 (8 elements) or 2 (16 elements)
+  constexpr int EG0 = B <= 2 ? 4 : (B <= 4 ? 2 : 1);
+  constexpr int EG = NV > 1 && EG0 > 1 && B > 1 ? EG0 / 2 : EG0;  // entries per read batch (registers: EG * NV * (1 + B) * 4)
   auto entries = [&](const uint32_t (&a_cb)[4], const uint32_t (&a_x)[4], const uint32_t (&copy)[4]) {
 #ifdef AQLM_PACKED_TRACE
     if (p.dbg & 1) { acc[0][0] += __uint_as_float(a_cb[0] ^ a_x[1] ^ a_cb[2] ^ a_x[3]); return; }
 #endif
 #pragma unroll
     for (int g0 = 0; g0 < 4; g0 += EG) {
-      u32x4 ev[EG], xv[EG][B];
+      u32x4 ev[EG][NV], xv[EG][B][NV];
 #ifdef AQLM_PACKED_TRACE
       if (p.dbg & 8) {  // no LDS reads: the dot products run on register garbage (what does the VALU part cost alone?)
 #pragma unroll
-        for (int k = 0; k < EG; ++k) {
-          ev[k] = u32x4{a_cb[g0 + k], a_x[g0 + k], a_cb[g0 + k] ^ 0x3c00u, a_x[g0 + k] ^ 0x3c00u};
+        for (int k = 0; k < EG; ++k)
 #pragma unroll
-          for (int b = 0; b < B; ++b) xv[k][b] = u32x4{a_x[g0 + k], a_cb[g0 + k], a_x[g0 + k] ^ 0x3c00u, a_cb[g0 + k]};
-        }
+          for (int h = 0; h < NV; ++h) {
+            ev[k][h] = u32x4{a_cb[g0 + k], a_x[g0 + k], a_cb[g0 + k] ^ 0x3c00u, a_x[g0 + k] ^ 0x3c00u};
+#pragma unroll
+            for (int b = 0; b < B; ++b) xv[k][b][h] = u32x4{a_x[g0 + k], a_cb[g0 + k], a_x[g0 + k] ^ 0x3c00u, a_cb[g0 + k]};
+          }
       } else
 #endif
 #pragma unroll
       for (int k = 0; k < EG; ++k) {
-        ev[k] = *(lds_u32x4_ptr)(size_t)(a_cb[g0 + k] + LDS::SLICE);
-        if constexpr (B == 1) {
-          xv[k][0] = *(lds_u32x4_ptr)(size_t)(a_x[g0 + k] + LDS::X);
-        } else {
-          const uint32_t ax = a_x[g0 + k] + LDS::X - copy[g0 + k] * xstride16;
 #pragma unroll
-          for (int b = 0; b < B; ++b) xv[k][b] = *(lds_u32x4_ptr)(size_t)(ax + (uint32_t)b * XP);
+        for (int h = 0; h < NV; ++h) ev[k][h] = *(lds_u32x4_ptr)(size_t)((a_cb[g0 + k] ^ ((uint32_t)h * 16u)) + LDS::SLICE);
+        if constexpr (B == 1) {
+#pragma unroll
+          for (int h = 0; h < NV; ++h) xv[k][0][h] = *(lds_u32x4_ptr)(size_t)((a_x[g0 + k] ^ ((uint32_t)h * 16u)) + LDS::X);
+        } else {
+#pragma unroll
+          for (int h = 0; h < NV; ++h) {
+            const uint32_t ax = (a_x[g0 + k] ^ ((uint32_t)h * 16u)) + LDS::X - copy[g0 + k] * xstride16;
+#pragma unroll
+            for (int b = 0; b < B; ++b) xv[k][b][h] = *(lds_u32x4_ptr)(size_t)(ax + (uint32_t)b * XP);
+          }
         }
       }
 #ifdef AQLM_PACKED_TRACE
       if (p.dbg & 4) {  // LDS reads but no dot products: one op per entry keeps the reads alive
 #pragma unroll
-        for (int k = 0; k < EG; ++k) acc[0][0] += __uint_as_float((ev[k].x ^ xv[k][0].w) & 0x007fffffu);
+        for (int k = 0; k < EG; ++k) acc[0][0] += __uint_as_float((ev[k][NV - 1].x ^ xv[k][0][NV - 1].w) & 0x007fffffu);
         continue;
       }
 #endif
 #pragma unroll
       for (int k = 0; k < EG; ++k)
 #pragma unroll
-        for (int b = 0; b < B; ++b) acc[b][(g0 + k) % NA] = dot8<T_>(ev[k], xv[k][b], acc[b][(g0 + k) % NA]);
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int h = 0; h < NV; ++h) acc[b][(g0 + k) % NA] = dot8<T_>(ev[k][h], xv[k][b][h], acc[b][(g0 + k) % NA]);
     }
   };
   auto total = [&](int b) -> float {  // fixed summation order of the chains
@@ -902,7 +961,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       us2 m = {0, 0};
-      for (int idx = tid; idx < p.in_groups; idx += NT) {
+      for (int idx = tid; idx < p.in_groups * (int)(PK_VB / 16); idx += NT) {
         const u32x4 v = *(lds_u32x4_ptr)(size_t)(LDS::X + (uint32_t)b * (B == 1 ? 0u : XP) + (uint32_t)idx * 16u);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -974,7 +1033,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
               xm = d > xm ? d : xm;
             }
           }
-          const float bound = (float)p.in_groups * 8.f * p.cb_absmax * T_::to_float((uint16_t)xm);
+          const float bound = (float)p.in_groups * (float)PK_G * p.cb_absmax * T_::to_float((uint16_t)xm);
           int e = 0;
           (void)frexpf(bound, &e);                               // bound < 2^e (e = 0 for bound == 0)
           const bool finite = bound < __builtin_inff() && fabsf(v[b]) <= 2.f * bound;  // false for NaN / Inf anywhere
@@ -1504,7 +1563,7 @@ static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max
     max_rg = std::max(max_rg, Ls[k].RG);
     nwc = std::max(nwc, Ls[k].NW);
   }
-  if (PK_S_LOG != 4 || n < 2 || nwc + PP_DMA_WAVES > PK_MAX_NW || (uint32_t)(in_groups + 1) * 16u > PP_XWIN) return false;
+  if (PK_S_LOG != 4 || PK_G != 8 || n < 2 || nwc + PP_DMA_WAVES > PK_MAX_NW || (uint32_t)(in_groups + 1) * 16u > PP_XWIN) return false;
   return pipe_lds(max_rg).total <= 160u * 1024u;
 }
 
@@ -1575,17 +1634,52 @@ static int packed_max_batch(int in_groups, int RG) {
   return packed_lds_need(b, in_groups, RG) <= 160 * 1024 ? b : 0;
 }
 
+}  // namespace PK_NS
 }  // namespace aqlm
 
 using namespace aqlm;
+using namespace aqlm::PK_NS;
+
+#if AQLM_PK_G == 8
+// the 16-element twin of this file (same signatures)
+extern "C" {
+size_t aqlm_hip_g16_prepack_1x16_bytes(int, int, int);
+int aqlm_hip_g16_prepack_1x16(const void*, int, int, int, void*, size_t, aqlm_hip_packed_desc*, void*);
+int aqlm_hip_g16_packed_desc_read(const void*, size_t, aqlm_hip_packed_desc*);
+int aqlm_hip_g16_unpack_1x16(const aqlm_hip_packed_desc*, const void*, void*, void*);
+int aqlm_hip_g16_gemv_1x16_packed_cells(const aqlm_hip_packed_desc*, const void*, const void*, const void*, const void*, const void*, void*, int,
+                                        long, long, int, void*, size_t, void*);
+int aqlm_hip_g16_gemv_1x16_packed(const aqlm_hip_packed_desc*, void*, const void*, const void*, const void*, const void*, void*, int, long, long,
+                                  int, void*, size_t, void*);
+int aqlm_hip_g16_gemv_1x16_packed_chain(const aqlm_hip_packed_desc*, void*, const void*, const void*, const void*, const void*, void*, int, long,
+                                        long, int, void*, size_t, const aqlm_hip_packed_desc*, const void*, const void*, void*);
+int aqlm_hip_g16_gemv_1x16_packed_partials(const aqlm_hip_packed_desc*, const void*, const void*, const void*, int, long, int, void*, size_t, void*);
+int aqlm_hip_g16_gemv_1x16_packed_publish(const aqlm_hip_packed_desc*, void*, const void*, const void*, int, long, int, const aqlm_hip_xgmi*, void*,
+                                          void*, void*);
+int aqlm_hip_g16_gemv_1x16_packed_multi(const aqlm_hip_segment*, const aqlm_hip_packed_desc* const*, int, const void*, int, int, long, int, void*,
+                                        size_t, void*);
+int aqlm_hip_g16_gemv_1x16_packed_multi_cells(const aqlm_hip_segment*, const aqlm_hip_packed_desc* const*, int, const void*, int, int, long, int,
+                                              void*, size_t, void*);
+}
+// a descriptor of the twin's format (32 slices)
+static inline bool pk_is_g16(const aqlm_hip_packed_desc* d) { return d && d->slices_log2 == 5; }
+#define PK_G16_FORWARD(desc_expr, call) \
+  if (pk_is_g16(desc_expr)) return call
+#define PK_G16_FORWARD_IF(cond, call) \
+  if (cond) return call
+#else
+#define PK_G16_FORWARD(desc_expr, call)
+#define PK_G16_FORWARD_IF(cond, call)
+#endif
 
 extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size) {
+  PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16_bytes(out_features, in_features, in_group_size));
   if (!packed_shape_ok(out_features, in_features, in_group_size)) return 0;
   // capacity for codes that use the slices up to 25 % unevenly, plus the scratch of the repack (row starts);
   // the bytes actually used come back in the descriptor and the buffer may be trimmed to them
   const size_t nst = (size_t)PK_NG * PK_S;
   const size_t RG = (size_t)(out_features + PK_NG - 1) / PK_NG;
-  const size_t in_groups = (size_t)in_features / 8;
+  const size_t in_groups = (size_t)in_features / PK_G;
   const size_t lane_steps = RG * in_groups / (4 * PK_S) * 5 / 4 + RG + 64;   // per stream
   const size_t ent = nst * (lane_steps * 16 + 16 * 1024);
   const size_t meta = 4096 + nst * PK_MAX_NW * 16 + nst * (RG + 1) * 4 + (size_t)AQLM_HIP_MAX_GEMV_BATCH * out_features * 8;
@@ -1595,13 +1689,14 @@ extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features,
 
 extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
                                      void* packed, size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream_) {
+  PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16(codes, out_features, in_features, in_group_size, packed, packed_bytes, desc, stream_));
   hipStream_t stream = (hipStream_t)stream_;
   if (!codes || !packed || !desc) {
     set_last_error("aqlm_hip_prepack_1x16: null pointer argument");
     return AQLM_HIP_E_INVALID;
   }
   if (!packed_shape_ok(out_features, in_features, in_group_size)) {
-    set_last_error("aqlm_hip_prepack_1x16: unsupported shape (needs g=8, in/8 <= %d; got g=%d in=%d out=%d)", PK_MAX_GROUPS,
+    set_last_error("aqlm_hip_prepack_1x16: unsupported shape (needs g=%d, in/g <= %d; got g=%d in=%d out=%d)", PK_G, PK_MAX_GROUPS,
                    in_group_size, in_features, out_features);
     return AQLM_HIP_E_UNSUPPORTED;
   }
@@ -1610,7 +1705,7 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
     set_last_error("aqlm_hip_prepack_1x16: packed buffer needs %zu bytes (16-B aligned), got %zu", cap, packed_bytes);
     return AQLM_HIP_E_INVALID;
   }
-  const int M = out_features, in_groups = in_features / 8;
+  const int M = out_features, in_groups = in_features / PK_G;
   const int RG = (M + PK_NG - 1) / PK_NG;
   const size_t nst = (size_t)PK_NG * PK_S;
   uint8_t* base = (uint8_t*)packed;
@@ -1660,12 +1755,13 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   d.x_copies = (uint32_t)XC;
   d.codebook_absmax = 0.f;  // unknown: the caller sets it (see include/aqlm_hip.h) to enable the fused finalize
   if (int e = check_hip(hipMemcpyAsync(base, &d, sizeof(d), hipMemcpyHostToDevice, stream), "prepack header")) return e;
-  const uint32_t null_entry = (uint32_t)in_groups << 20;
+  const uint32_t null_entry = (uint32_t)in_groups << (16 + PK_VSH);
   hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4, null_entry);
   hipLaunchKernelGGL(pk_scatter_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, ent, M, in_groups, RG, NW, T);
   if (arrange)
     hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 256, stream, a,
                        ent, M, in_groups, RG, NW, T, XC);
+  if (PK_PARITY_BITS) hipLaunchKernelGGL(pk_parity_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4);
   hipLaunchKernelGGL(pk_flag_kernel, dim3((RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, M, RG, NW, T);
   hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, M, RG, NW, T);
   if (EB == 3)
@@ -1677,6 +1773,13 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
 }
 
 extern "C" int aqlm_hip_packed_desc_read(const void* header_host, size_t header_bytes, aqlm_hip_packed_desc* desc) {
+#if AQLM_PK_G == 8
+  if (header_host && desc && header_bytes >= sizeof(aqlm_hip_packed_desc)) {
+    aqlm_hip_packed_desc h;
+    memcpy(&h, header_host, sizeof(h));
+    if (pk_is_g16(&h)) return aqlm_hip_g16_packed_desc_read(header_host, header_bytes, desc);
+  }
+#endif
   if (!header_host || !desc || header_bytes < sizeof(aqlm_hip_packed_desc)) {
     set_last_error("aqlm_hip_packed_desc_read: need the first %zu bytes of the packed buffer", sizeof(aqlm_hip_packed_desc));
     return AQLM_HIP_E_INVALID;
@@ -1693,6 +1796,7 @@ extern "C" int aqlm_hip_packed_desc_read(const void* header_host, size_t header_
 }
 
 extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, void* codes, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_unpack_1x16(desc, packed, codes, stream_));
   hipStream_t stream = (hipStream_t)stream_;
   PackedLayout L;
   if (!packed || !codes || !desc_layout(desc, L)) {
@@ -1858,6 +1962,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_cells(const aqlm_hip_packed_desc* desc,
                                                const void* scales, const void* bias, const void* x, void* y, int batch,
                                                long x_row_stride, long y_row_stride, int dtype, void* cells,
                                                size_t cells_bytes, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed_cells(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, cells, cells_bytes, stream_));
   if (!cells || !desc || !(desc->codebook_absmax > 0.f) || cells_bytes < (size_t)std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * desc->out_features * 8 ||
       (reinterpret_cast<uintptr_t>(cells) & 7u)) {
     set_last_error("aqlm_hip_gemv_1x16_packed_cells: needs a descriptor with the codebook range and %zu bytes of 8-B aligned, "
@@ -1876,6 +1981,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void*
                                          const void* scales, const void* bias, const void* x, void* y, int batch,
                                          long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                          size_t workspace_bytes, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, workspace, workspace_bytes, stream_));
   return gemv_1x16_packed_impl(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, workspace,
                                workspace_bytes, stream_, PackedNext{});
 }
@@ -1885,6 +1991,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc,
                                                long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                                size_t workspace_bytes, const aqlm_hip_packed_desc* next_desc,
                                                const void* next_packed, const void* next_codebook, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed_chain(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, workspace, workspace_bytes, next_desc, next_packed, next_codebook, stream_));
   PackedNext next;
   PackedLayout LN;
   if (next_desc && next_packed && next_codebook) {
@@ -1953,6 +2060,7 @@ static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed,
 extern "C" int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
                                                   const void* x, int batch, long x_row_stride, int dtype, void* workspace,
                                                   size_t workspace_bytes, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed_partials(desc, packed, codebook, x, batch, x_row_stride, dtype, workspace, workspace_bytes, stream_));
   PackedLayout L;
   int max_b = 0;
   if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed_partials", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b))
@@ -1974,6 +2082,7 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
 extern "C" int aqlm_hip_gemv_1x16_packed_publish(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                                  const void* x, int batch, long x_row_stride, int dtype,
                                                  const aqlm_hip_xgmi* xg, void* pub_own, void* flag_own, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed_publish(desc, packed, codebook, x, batch, x_row_stride, dtype, xg, pub_own, flag_own, stream_));
   PackedLayout L;
   int max_b = 0;
   if (int e = packed_check_args("aqlm_hip_gemv_1x16_packed_publish", desc, packed, codebook, x, batch, x_row_stride, dtype, L, max_b))
@@ -1998,6 +2107,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
                                                int num_segments, const void* x, int in_features, int batch,
                                                long x_row_stride, int dtype, void* workspace, size_t workspace_bytes,
                                                void* stream_) {
+  PK_G16_FORWARD(descs && num_segments >= 1 ? descs[0] : nullptr, aqlm_hip_g16_gemv_1x16_packed_multi(segments, descs, num_segments, x, in_features, batch, x_row_stride, dtype, workspace, workspace_bytes, stream_));
   return gemv_1x16_packed_multi_impl(segments, descs, num_segments, x, in_features, batch, x_row_stride, dtype, workspace,
                                      workspace_bytes, nullptr, 0, stream_);
 }
@@ -2006,6 +2116,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi_cells(const aqlm_hip_segment* seg
                                                      int num_segments, const void* x, int in_features, int batch,
                                                      long x_row_stride, int dtype, void* cells, size_t cells_bytes,
                                                      void* stream_) {
+  PK_G16_FORWARD(descs && num_segments >= 1 ? descs[0] : nullptr, aqlm_hip_g16_gemv_1x16_packed_multi_cells(segments, descs, num_segments, x, in_features, batch, x_row_stride, dtype, cells, cells_bytes, stream_));
   if (!cells || (reinterpret_cast<uintptr_t>(cells) & 7u) || !tuning().packed_fused_finalize) {
     set_last_error("aqlm_hip_gemv_1x16_packed_multi_cells: needs 8-B aligned, zero-filled cells and the fused finalize switched on");
     return AQLM_HIP_E_INVALID;

@@ -19,7 +19,7 @@ from .utils import get_int_dtype
 # rows (batch * seq) at or below which the gemv op is used; the reference's value (inference.py:95-96)
 GEMV_MAX_ROWS = 6
 
-# 1x16 g8 matvecs (<= GEMV_MAX_ROWS rows) of layers with at least this many codes (out_features * in_features / 8) run on
+# 1x16 (g8 / g16) matvecs (<= GEMV_MAX_ROWS rows) of layers with at least this many codes (out_features * in_features / g) run on
 # slice-bucketed ("prepacked") codes (aqlm_hip_gemv_1x16_packed): 1.2-5x faster than the direct L2-gather kernel on
 # MI355X, at the price of a one-off repack at first use and ~2.3x the code bytes (kept next to the original codes unless
 # `drop_canonical_codes()` is called).  0 disables.  Measured cross-over (cold, single launch each): 4096->1024 (0.5 M
@@ -206,8 +206,8 @@ class QuantizedLinear(nn.Module):
             return  # the packed buffer IS the weights now
         self._packed_codes = None
         self._prepack_deferred = False
-        if (PREPACK_MIN_CODES and self.out_features * (self.in_features // 8) >= PREPACK_MIN_CODES and self.num_codebooks == 1
-                and self.nbits_per_codebook == 16 and self.in_group_size == 8 and self.out_group_size == 1
+        if (PREPACK_MIN_CODES and self.out_features * (self.in_features // self.in_group_size) >= PREPACK_MIN_CODES
+                and self.num_codebooks == 1 and self.nbits_per_codebook == 16 and self.in_group_size in (8, 16) and self.out_group_size == 1
                 and self.codes.is_cuda and self.codebooks.dtype in (torch.float16, torch.bfloat16)):
             if torch.cuda.is_current_stream_capturing():
                 # the repack synchronises its stream: not allowed inside a hipGraph capture.  This call runs on the
@@ -216,7 +216,7 @@ class QuantizedLinear(nn.Module):
                 return
             from .inference_kernels import hip_kernel
 
-            self._packed_codes = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
+            self._packed_codes = hip_kernel.prepack_1x16(self.codes, self.in_group_size, codebooks=self.codebooks)
             self._packed_fingerprint = self._codes_fingerprint()
         self._build_fast_lane()
 
@@ -243,7 +243,7 @@ class QuantizedLinear(nn.Module):
         elif self._codes_dropped or not (self.codes.is_cuda and self.codes.is_contiguous()):
             return
         elif scheme in ((1, 16, 8), (1, 16, 16)):
-            if hip_kernel.RAW_OP_PREPACK and self.out_features * (self.in_features // 8) >= hip_kernel.RAW_OP_PREPACK_MIN_CODES:
+            if hip_kernel.RAW_OP_PREPACK and self.out_features * (self.in_features // self.in_group_size) >= hip_kernel.RAW_OP_PREPACK_MIN_CODES:
                 return  # the raw op would pack this layer on its own (PREPACK_MIN_CODES was raised): leave it to the op
             kind, buf, desc = _front.KIND_GEMV_1X16, None, ""
         elif scheme in ((2, 8, 8), (1, 8, 8)):

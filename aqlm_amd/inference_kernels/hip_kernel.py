@@ -127,17 +127,20 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
 
 
 # ------------------------------------------------------------------------------------------------------
-# prepacked 1x16 g8 path (format v6): 1..8 input rows per launch on slice-bucketed codes
+# prepacked 1x16 path, g8 and g16 (format v6): 1..8 input rows per launch on slice-bucketed codes
 # ------------------------------------------------------------------------------------------------------
 class PackedCodes:
-    """A prepacked 1x16 g8 code buffer (``aqlm_hip_prepack_1x16``): device bytes + the host-side descriptor the
-    kernels are launched with.  Derived from ``codes`` (lossless: ``unpack_1x16`` gives them back); never saved."""
+    """A prepacked 1x16 code buffer (``aqlm_hip_prepack_1x16``; g8: 16 codebook slices, g16: 32): device bytes + the
+    host-side descriptor the kernels are launched with.  Derived from ``codes`` (lossless: ``unpack_1x16`` gives them
+    back); never saved."""
 
-    __slots__ = ("buf", "desc", "out_features", "in_features", "_ints", "_range_of")
+    __slots__ = ("buf", "desc", "out_features", "in_features", "in_group_size", "slices", "_ints", "_range_of")
 
     def __init__(self, buf: torch.Tensor, desc: "_native.PackedDesc"):
         self.buf, self.desc = buf, desc
         self.out_features, self.in_features = int(desc.out_features), int(desc.in_features)
+        self.slices = 1 << int(desc.slices_log2)
+        self.in_group_size = 16 if self.slices == 32 else 8  # the two instantiations of csrc/gemv_packed.hip
         self._ints = desc.as_ints()
         self._range_of = None  # fingerprint of the codebook tensor `desc.codebook_absmax` was taken from
 
@@ -174,7 +177,7 @@ class PackedCodes:
 
 
 def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8, codebooks: Optional[torch.Tensor] = None) -> Optional[PackedCodes]:
-    """Repack 1x16 g8 codes [out, in/8, 1] (int16) into the slice-bucketed buffer of aqlm_hip_gemv_1x16_packed.
+    """Repack 1x16 codes [out, in/g, 1] (int16; g = 8 or 16) into the slice-bucketed buffer of aqlm_hip_gemv_1x16_packed.
     Returns None when the packed path does not cover the layer.  One-off, at load / first use (the counterpart of the
     reference's load-time code permutation for its CPU kernel, inference.py:78-83).  With ``codebooks`` the descriptor
     also gets the layer's codebook range (``PackedCodes.set_codebook_range``): single-kernel matvecs."""
@@ -199,8 +202,8 @@ def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8, codebooks: Optiona
 
 
 def unpack_1x16(packed: PackedCodes) -> torch.Tensor:
-    """The canonical codes [out, in/8, 1] (int16) of a prepacked buffer (aqlm_hip_unpack_1x16; lossless)."""
-    codes = torch.empty((packed.out_features, packed.in_features // 8, 1), dtype=torch.int16, device=packed.device)
+    """The canonical codes [out, in/g, 1] (int16) of a prepacked buffer (aqlm_hip_unpack_1x16; lossless)."""
+    codes = torch.empty((packed.out_features, packed.in_features // packed.in_group_size, 1), dtype=torch.int16, device=packed.device)
     with torch.cuda.device(packed.device):
         rc = _lib.aqlm_hip_unpack_1x16(ctypes.byref(packed.desc), packed.data_ptr(), codes.data_ptr(),
                                        _stream_ptr(packed.device))
@@ -305,7 +308,7 @@ def code1x16_matmat_packed(input, packed: PackedCodes, codebooks, scales, bias=N
         ws_ptr, ws_len = None, 0
         cells = _packed_cells(input.device, stream, nb_max * out_features * 8)
     else:                                   # two kernels: fp32 slice partials in a workspace
-        ws = _workspace(input.device, 16 * nb_max * out_features * 4, stream)
+        ws = _workspace(input.device, packed.slices * nb_max * out_features * 4, stream)
         ws_ptr, ws_len = ws.data_ptr(), ws.numel() * 4
     with _device_guard(input.device):
         for b0 in range(0, B, _native.MAX_GEMV_BATCH):
@@ -499,7 +502,7 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
         ws_ptr, ws_len = None, 0
         cells = _packed_cells(input.device, stream, B * total * 8)
     else:
-        ws = _workspace(input.device, 16 * B * total * 4, stream)
+        ws = _workspace(input.device, packed[0].slices * B * total * 4, stream)
         ws_ptr, ws_len = ws.data_ptr(), ws.numel() * 4
     with _device_guard(input.device):
         if cells is not None:
@@ -555,7 +558,7 @@ def _raw_packed_for(codes, codebooks, input):
     """The cached packed form of `codes`, packing it at first sight; None = use the direct kernel."""
     if not RAW_OP_PREPACK or not codes.is_cuda or codes.dtype != torch.int16 or codes.dim() != 3 or codes.shape[2] != 1:
         return None
-    if codebooks.shape[3] != 8 or codes.shape[0] * codes.shape[1] < RAW_OP_PREPACK_MIN_CODES:
+    if codebooks.shape[3] not in (8, 16) or codes.shape[0] * codes.shape[1] < RAW_OP_PREPACK_MIN_CODES:
         return None
     if input.dtype != codebooks.dtype or input.numel() // input.shape[-1] > _native.MAX_GEMV_BATCH:
         return None
@@ -575,9 +578,10 @@ def _raw_packed_for(codes, codebooks, input):
     import weakref
 
     packed = None
-    cap = _lib.aqlm_hip_prepack_1x16_bytes(codes.shape[0], codes.shape[1] * 8, 8)
+    g = int(codebooks.shape[3])
+    cap = _lib.aqlm_hip_prepack_1x16_bytes(codes.shape[0], codes.shape[1] * g, g)
     if cap and _RAW_STATS["bytes"] + cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
-        packed = prepack_1x16(codes, 8)
+        packed = prepack_1x16(codes, g)
     try:
         ref = weakref.ref(codes, lambda _r, k=key: _raw_drop(k))
     except TypeError:

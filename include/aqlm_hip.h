@@ -343,6 +343,7 @@ int aqlm_hip_gemv_8x8_lut_multi_fused(const aqlm_hip_segment* segments, int num_
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3
 #define AQLM_HIP_OP_GEMV_8X8_LUT 4
+#define AQLM_HIP_OP_GEMV_1X16_G16_PACKED 5 /* prepacked codes of 16-element vectors: 32 slices */
 size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);
 
 /*

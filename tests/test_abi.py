@@ -91,7 +91,8 @@ def test_segment_struct_and_multi_validation(native):
     # prepacked entry points: descriptors are validated before anything is launched
     assert ctypes.sizeof(native.PackedDesc) == 48
     assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 8) > 2 * 4096 * 512 * 2
-    assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 16) == 0          # g16 is not packable
+    assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 16) > 2 * 4096 * 256 * 2   # 16-element vectors: the second instantiation
+    assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 32) == 0          # other group sizes are not packable
     assert L.aqlm_hip_prepack_1x16_bytes(64, 8 * 4095, 8) == 0         # in/8 > 4094: j does not fit 12 bits
     bad = native.PackedDesc()
     descs = (native._descp * 2)(ctypes.pointer(bad), ctypes.pointer(bad))
@@ -122,6 +123,7 @@ def test_workspace_bytes(native):
     assert L.aqlm_hip_workspace_bytes(native.OP_GEMM_1X16_MFMA, 7, 4096, 4096) < n
     assert L.aqlm_hip_workspace_bytes(native.OP_GEMV_1X16_PACKED, 1, 4096, 4096) == 16 * 4096 * 4
     assert L.aqlm_hip_workspace_bytes(native.OP_GEMV_1X16_PACKED, 4, 11008, 4096) == 16 * 4 * 11008 * 4
+    assert L.aqlm_hip_workspace_bytes(native.OP_GEMV_1X16_G16_PACKED, 4, 11008, 4096) == 32 * 4 * 11008 * 4
 
 
 def test_tuning_knobs(native):

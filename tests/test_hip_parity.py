@@ -311,15 +311,8 @@ def test_matmat_dequant_mfma_pipeline_shapes(hk, g, fin, fout, B, dt):
     else:  # large layers: W from the C restatement (fp32, exact sums of fp16 entries times an fp16 scale), product in fp64
         W = c_oracle.dequant_weight(L["codebooks"], L["codes"], L["scales"], 16)
         y64 = L["x"].astype(np.float64) @ W.T.astype(np.float64) + L["bias"].astype(np.float64)
-    from aqlm_amd import _native
-
-    for wk in (0, 1, 2):  # block shape: by batch size (default), 128 rows, 64 rows with the k steps on two waves
-        _native.set_tuning("gemm_wk", wk)
-        try:
-            y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
-        finally:
-            _native.set_tuning("gemm_wk", 0)
-        check_close(y, y64, dtype, f"mfma pipeline g{g} {fin}->{fout} B{B} wk{wk}")
+    y = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
+    check_close(y, y64, dtype, f"mfma pipeline g{g} {fin}->{fout} B{B}")
 
 
 @pytest.mark.parametrize("K,g", [(2, 8), (1, 8), (8, 32)])
@@ -517,6 +510,90 @@ def test_gemv_1x16_packed(hk, fin, fout, dt, bias, entry_bytes):
     y3d = hk.code1x16_matmat_packed(T["x"].reshape(2, 4, fin), packed, T["codebooks"], T["scales"], T["bias"])
     assert y3d.shape == (2, 4, fout)
     check_close(y3d.reshape(8, fout).float().cpu().numpy(), y64, dtype, "packed 3-D")
+
+
+# 16-element codebook vectors (the reference kernel's second template instance, cuda_kernel.cu:476-521; BASELINE config
+# "1x16g16"): the second instantiation of csrc/gemv_packed.hip -- 32 slices of 2048 x 32 B, lane-parity half order.
+PACKED_G16_SHAPES = [
+    (4096, 4096, "float16", True),
+    (4096, 11008, "float16", True),
+    (4096, 1000, "bfloat16", False),     # ragged row groups
+    (8192, 1024, "float16", True),
+    (11008, 640, "float16", True),       # 688 input groups
+    (128, 256, "float16", True),         # 8 input groups: null lane-steps almost everywhere
+    (1040, 70, "bfloat16", True),        # 65 input groups, fewer rows than 8 x waves
+    (28672, 512, "float16", True),       # the widest x image (56 KiB) behind the slice
+]
+
+
+@pytest.mark.parametrize("fin,fout,dt,bias", PACKED_G16_SHAPES)
+def test_gemv_1x16_g16_packed(hk, fin, fout, dt, bias):
+    dtype = tdtype(dt)
+    L = orc.make_layer(900 + fin + fout, fin, fout, 1, 16, 16, batch=8, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    cu = L["codes_unsigned"].copy()
+    cu[1, :, 0] = cu[1, :, 0] & 0x07FF                             # a row that lives in one slice
+    cu[2, ::2, 0] = (cu[2, ::2, 0] & 0x07FF) | (5 << 11)
+    cu[fout - 1, :, 0] = (cu[fout - 1, :, 0] & 0x07FF) | (31 << 11)
+    L = dict(L, codes=orc.pack_int_data(cu, 16), codes_unsigned=cu)
+    T = to_dev(L, dtype)
+    packed = hk.prepack_1x16(T["codes"], 16)
+    assert packed is not None and packed.in_group_size == 16 and packed.slices == 32 and packed.desc.entry_bytes == 4
+    # lossless, also through a re-attached descriptor
+    assert torch.equal(hk.unpack_1x16(packed), T["codes"])
+    assert torch.equal(hk.unpack_1x16(hk.PackedCodes.from_buffer(packed.buf.clone())), T["codes"])
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    for fused in (True, False):  # single kernel (fixed-point cells) and the two-kernel form (fp32 slice partials)
+        hk.set_fused_finalize(fused)
+        try:
+            if fused:
+                packed.set_codebook_range(T["codebooks"])
+            y1 = hk.code1x16_matmat_packed(T["x"][:1], packed, T["codebooks"], T["scales"], T["bias"])
+            check_close(y1.float().cpu().numpy(), y64[:1], dtype, f"packed 1x16g16 {fin}->{fout} fused={fused}")
+            if bias:
+                yz = hk.code1x16_matmat_packed(torch.zeros_like(T["x"][:1]), packed, T["codebooks"], T["scales"], T["bias"])
+                assert torch.equal(yz[0], T["bias"])
+            for _ in range(5):
+                assert torch.equal(y1, hk.code1x16_matmat_packed(T["x"][:1], packed, T["codebooks"], T["scales"], T["bias"]))
+            for B in (2, 3, 5, 8):
+                yb = hk.code1x16_matmat_packed(T["x"][:B], packed, T["codebooks"], T["scales"], T["bias"])
+                check_close(yb.float().cpu().numpy(), y64[:B], dtype, f"packed g16 batch {B}")
+                assert torch.equal(yb[0], y1[0])
+                alone = hk.code1x16_matmat_packed(T["x"][B - 1:B].contiguous(), packed, T["codebooks"], T["scales"], T["bias"])
+                assert torch.equal(yb[B - 1], alone[0])
+        finally:
+            hk.set_fused_finalize(True)
+    # the direct (L2-gather) kernel on the same layer agrees to rounding
+    yd = hk._gemv(T["x"][:1], T["codes"], T["codebooks"], T["scales"], T["bias"], "1x16")
+    check_close(y1.float().cpu().numpy(), yd.float().cpu().numpy().astype(np.float64), dtype, "packed g16 vs direct")
+
+
+def test_g16_layers_share_one_launch_and_the_module_prepacks_them(hk):
+    """q/k/v-style shared-input launch of two 1x16g16 layers == separate launches, bit for bit; QuantizedLinear prepacks a
+    large g16 layer like a g8 one and can drop / restore its canonical codes."""
+    from aqlm_amd import QuantizedLinear
+
+    fin = 4096
+    Ls = [orc.make_layer(77 + k, fin, fo, 1, 16, 16, batch=2, bias=(k == 0)) for k, fo in enumerate((4096, 1024))]
+    Ts = [to_dev(L, torch.float16) for L in Ls]
+    pks = [hk.prepack_1x16(T["codes"], 16, codebooks=T["codebooks"]) for T in Ts]
+    x = Ts[0]["x"]
+    outs = hk.code1x16_matmat_packed_multi(x, pks, [T["codebooks"] for T in Ts], [T["scales"] for T in Ts],
+                                           [Ts[0]["bias"], None])
+    for k in range(2):
+        assert torch.equal(outs[k], hk.code1x16_matmat_packed(x, pks[k], Ts[k]["codebooks"], Ts[k]["scales"],
+                                                              Ts[0]["bias"] if k == 0 else None))
+    m = QuantizedLinear(fin, 4096, 16, 1, 1, 16, bias=True, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        m.codes.copy_(Ts[0]["codes"]); m.codebooks.copy_(Ts[0]["codebooks"]); m.scales.copy_(Ts[0]["scales"])
+        m.bias.copy_(Ts[0]["bias"])
+    y = m(x[:1])
+    assert m._packed_codes is not None and m._packed_codes.in_group_size == 16
+    assert torch.equal(y, outs[0][:1])
+    assert m.drop_canonical_codes()
+    assert torch.equal(m(x[:1]), y)
+    m.restore_canonical_codes()
+    assert torch.equal(m.codes, Ts[0]["codes"])
 
 
 # The shipped kernel at the shapes the bench and the 70B configuration run (BASELINE.json configs 2 and 5), against the

@@ -442,7 +442,7 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     }
     CK(hipDeviceSynchronize());
     printf("# packed %d->%d: waves %d steps %d entry bytes %d x copies %d, %.3f B per code (capacity %.1f MB, used %.1f MB)\n", in, out,
-           v[0].desc.waves, v[0].desc.steps, v[0].desc.entry_bytes, (int)v[0].desc.x_copies, (double)v[0].desc.used_bytes / ((double)out * (in / 8)), pb * 1e-6, v[0].desc.used_bytes * 1e-6);
+           v[0].desc.waves, v[0].desc.steps, v[0].desc.entry_bytes, (int)v[0].desc.x_copies, (double)v[0].desc.used_bytes / ((double)out * (in / s.g)), pb * 1e-6, v[0].desc.used_bytes * 1e-6);
   }
   return v;
 }
@@ -453,15 +453,17 @@ static void free_layers(std::vector<Layer>& v) {
 
 struct Scheme; static void check_packed(const Scheme& s, const Layer& L, int in, int out, const Layer* next = nullptr);
 static void bench_gemv(int argc, char** argv) {
-  g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
+  g_ws_bytes = (size_t)32 * 8 * 32768 * 4 + (1u << 22);
   CK(hipMalloc(&g_ws, g_ws_bytes));
   const Scheme S1x16P{"1x16g8P", 1, 16, 8, false, true};
+  const Scheme S1x16g16P{"1x16g16P", 1, 16, 16, false, true};
   const Scheme S8x8L{"8x8g32LUT", 8, 8, 32, false, false, true};
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
   std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672}, {S1x16P, 1024, 28672}, {S1x16P, 2048, 28672}, {S1x16P, 8192, 8192}, {S1x16P, 28672, 8192}, {S1x16P, 8192, 1024},
                              {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
-                             {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
+                             {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S1x16g16, 4096, 11008}, {S1x16g16, 8192, 28672},
+                             {S1x16g16P, 4096, 4096}, {S1x16g16P, 4096, 11008}, {S1x16g16P, 11008, 4096}, {S1x16g16P, 4096, 14336}, {S1x16g16P, 8192, 8192}, {S1x16g16P, 8192, 28672}, {S1x16g16P, 28672, 8192}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
                              {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}, {S8x8L, 4096, 4096}, {S8x8L, 4096, 11008}, {S8x8L, 11008, 4096}};
   const bool quick = argc > 2 && !strcmp(argv[2], "quick");
   const char* only = argc > 3 ? argv[3] : nullptr;  // run only schemes whose name contains this
@@ -573,7 +575,7 @@ static void bench_gemv(int argc, char** argv) {
         one[0] = layers[0];
         for (auto& w : warm) w = layers[0];
         printf("# repacked: waves %d steps %d entry bytes %d x copies %d, %.3f B per code\n", layers[0].desc.waves, layers[0].desc.steps,
-               layers[0].desc.entry_bytes, (int)layers[0].desc.x_copies, (double)layers[0].desc.used_bytes / ((double)c.out * (c.in / 8)));
+               layers[0].desc.entry_bytes, (int)layers[0].desc.x_copies, (double)layers[0].desc.used_bytes / ((double)c.out * (c.in / c.s.g)));
       }
       for (int batch : {1, 2, 4, 8}) {
         if (batch > 1 && (!var.empty() || quick)) continue;
