@@ -691,11 +691,11 @@ extern "C" int aqlm_hip_gemv_kx8(const void* codes, const void* codebooks, const
     return run_generic(codes, codebooks, scales, bias, x, y, out_features, in_features, K, 8, G, batch, xs, ys, dtype,
                        stream);
   // batch 1, g = 8, 1 or 2 codebooks, enough rows (>= 16 per CU) to amortise the 64-128 KiB replicated fill:
-  // conflict-free replicated-LDS kernel (measured cold, profiles/r02_final_mb_gemv.log: 4096->11008 7.2 vs 9.3 us,
-  // 4096->4096 5.1 vs 5.4 us; wide-input layers with few rows are better off on the plain kernel: 11008->4096 9.2 vs 8.5 us)
+  // conflict-free replicated-LDS kernel (measured cold, profiles/r03_mb_kx8_hoisted_loads.log: 4096->4096 4.9 vs 5.4 us,
+  // 4096->11008 7.4 vs 9.0 us, 11008->4096 7.7 vs 8.3 us -- with the code words requested before the fill the wide-input
+  // layers gain too; round 2 kept those on the plain kernel)
   const int rep = tuning().kx8_replicas;  // 1 = auto, 0 = never, 2 = whenever the shape fits
-  if (batch == 1 && G == 8 && (K == 1 || K == 2) && rep != 0 &&
-      (rep == 2 || (out_features >= 4096 && 2L * out_features > in_features))) {
+  if (batch == 1 && G == 8 && (K == 1 || K == 2) && rep != 0 && (rep == 2 || out_features >= 4096)) {
     const int e = gemv_kx8_replicated(codes, codebooks, scales, bias, x, y, out_features, in_features, K, dtype, stream);
     if (e != AQLM_HIP_E_UNSUPPORTED) return e;
   }

@@ -44,7 +44,9 @@ __device__ __forceinline__ float rep_reduce4(float a, float b, float c, float d,
 }
 
 // `block` = the workgroup's index within its own code matrix (== blockIdx.x for a single-matrix launch)
-template <class T, int KC, int ITERS>
+// NQ = rows a wave owns per round: 4 (rows base + w + 16 q), or 1 when the workgroup has <= 16 rows (4096-row layers: no
+// clamped duplicate requests, a quarter of the code-word registers).
+template <class T, int KC, int ITERS, int NQ>
 __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int block) {
   constexpr int NT = 1024;
   constexpr int UB = 8 * KC;       // code bytes per unit of 8 groups
@@ -60,42 +62,12 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.rows_per_block ? nrows : p.rows_per_block);
 
-  // replicated codebook fill: thread t writes copy r = t & 15 of entries (t >> 4) + 64 k.  The 8 lanes of a
-  // ds_write_b128 service group then hit 8 distinct 16-B slots (conflict free); the 16 threads of an entry read the
-  // same 16 B from L2 (one request).
-  {
-    const int r = tid & 15;
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebooks);
-    u32x4 v[ENTRIES / 64];
-#pragma unroll
-    for (int k = 0; k < ENTRIES / 64; ++k) v[k] = src[(tid >> 4) + 64 * k];
-#pragma unroll
-    for (int k = 0; k < ENTRIES / 64; ++k) cbl[((tid >> 4) + 64 * k) * 16 + r] = v[k];
-  }
-  for (int q0 = tid; q0 < p.in_groups; q0 += NT * 2) {  // x: staged loads (no load-wait-store round trips)
-    u32x4 v[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int q = q0 + k * NT < p.in_groups ? q0 + k * NT : p.in_groups - 1;
-      v[k] = *reinterpret_cast<const u32x4*>(p.x + (long)q * 8);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int q = q0 + k * NT;
-      if (q < p.in_groups) xl[(q & 7) * p.pitch + (q >> 3)] = v[k];
-    }
-  }
-  __syncthreads();
-
-  const uint32_t rep_off = (uint32_t)(lane & 15) << 4;  // this lane's replica: conflict-free in every service group
-  const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
-
   // Rows are dealt round-robin: in round `base`, wave w owns rows base + w + 16 q (q = 0..3).  All code words of the
-  // wave's (up to 4 x ITERS) row pieces are requested up front with clamped, always-valid addresses -- the first
-  // round even before the LDS fill -- so a wave pays ONE HBM latency per round, not one per row.
-  auto load_round = [&](int base, uint32_t (&cwq)[4][ITERS][CW]) {
+  // wave's (up to 4 x ITERS) row pieces are requested up front with clamped, always-valid addresses, so a wave pays ONE
+  // HBM latency per round, not one per row.
+  auto load_round = [&](int base, uint32_t (&cwq)[NQ][ITERS][CW]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       int r = base + wave + 16 * q;
       r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
 #pragma unroll
@@ -114,12 +86,62 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
     }
   };
 
-  for (int base = 0; base < nrows; base += 64) {
-    uint32_t cwq[4][ITERS][CW];
-    load_round(base, cwq);
+  // scale and bias of the row a lane will write in round `base` (lanes with lane % 16 == 0 do): requested with the round's
+  // code words instead of behind its last cross-lane step
+  uint16_t scale_h = 0, bias_h = 0;
+  auto load_epilogue = [&](int base) {
+    int r = base + wave + 16 * (lane >> 4);
+    r = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+    const uint16_t* bp = p.bias ? p.bias : p.scales;  // branch-free: a conditional load would end in a vmcnt(0) at the join
+    scale_h = p.scales[row_begin + r];
+    bias_h = bp[row_begin + r];
+    bias_h = p.bias ? bias_h : (uint16_t)0;
+  };
+
+  // Every global load of the prologue is issued before the first LDS write: codebook entries, x, and the code words of
+  // the first round (for <= 64 x 256 rows the only one).  Loads return in order, so the LDS fill proceeds as the codebook
+  // arrives while the code words -- the one HBM latency of the kernel -- are already on their way; issued behind the
+  // barrier (as in round 2) their latency was paid again on top of the fill's.
+  // Replicated fill: thread t writes copy r = t & 15 of entries (t >> 4) + 64 k.  The 8 lanes of a ds_write_b128 service
+  // group then hit 8 distinct 16-B slots (conflict free); the 16 threads of an entry read the same 16 B from L2 (one
+  // request).  x (in_groups <= 1536 < 2 NT): at most two vectors per thread.
+  uint32_t cwq[NQ][ITERS][CW];
+  {
+    const int r = tid & 15;
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.codebooks);
+    u32x4 v[ENTRIES / 64], xv[2];
+#pragma unroll
+    for (int k = 0; k < ENTRIES / 64; ++k) v[k] = src[(tid >> 4) + 64 * k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups - 1;
+      xv[k] = *reinterpret_cast<const u32x4*>(p.x + (long)q * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep this order: loads return in order, and the fill must not wait for the codes
+    load_round(0, cwq);
+    load_epilogue(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < ENTRIES / 64; ++k) cbl[((tid >> 4) + 64 * k) * 16 + r] = v[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // unconditional (threads past the end rewrite the last vector): a guarded store would pull
+      const int q = tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups - 1;  // its load into the branch, behind a vmcnt(0)
+      xl[(q & 7) * p.pitch + (q >> 3)] = xv[k];
+    }
+  }
+  __syncthreads();
+
+  const uint32_t rep_off = (uint32_t)(lane & 15) << 4;  // this lane's replica: conflict-free in every service group
+  const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
+
+  for (int base = 0; base < nrows; base += 16 * NQ) {
+    if (base > 0) {
+      load_round(base, cwq);
+      load_epilogue(base);
+    }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int r = base + wave + 16 * q;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -140,11 +162,9 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
     }
     const float tot = rep_reduce4(acc[0], acc[1], acc[2], acc[3], lane);
     const int r = base + wave + 16 * (lane >> 4);
-    if ((lane & 15) == 0 && r < nrows) {
+    if ((lane & 15) == 0 && (lane >> 4) < NQ && r < nrows) {
       const int row = row_begin + r;
-      const float scale = T::to_float(p.scales[row]);
-      const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
-      p.y[row] = T::from_float(__builtin_fmaf(tot, scale, bias));
+      p.y[row] = T::from_float(__builtin_fmaf(tot, T::to_float(scale_h), T::to_float(bias_h)));
     }
   }
 }
@@ -156,7 +176,7 @@ struct RepRest {
   uint16_t* y;
 };
 
-template <class T, int KC, int ITERS>
+template <class T, int KC, int ITERS, int NQ>
 __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const uint8_t* codes, const uint8_t* codebooks, const uint16_t* x, int M,
                                                             int in_groups, int nunits, int iters, int pitch, int rows_per_block,
                                                             long code_row_bytes, const RepRest rest) {
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_kernel(const uint8_t* codes
   p.pitch = pitch;
   p.rows_per_block = rows_per_block;
   p.code_row_bytes = code_row_bytes;
-  gemv_kx8_rep_body<T, KC, ITERS>(p, blockIdx.x);
+  gemv_kx8_rep_body<T, KC, ITERS, NQ>(p, blockIdx.x);
 }
 
 // Shared-input launch: up to AQLM_HIP_MAX_SEGMENTS code matrices (own codebooks / scales / bias / y) times one x.
@@ -194,7 +214,7 @@ struct RepMultiParams {
   RepSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
-template <class T, int KC, int ITERS>
+template <class T, int KC, int ITERS, int NQ>
 __global__ __launch_bounds__(1024) void gemv_kx8_rep_multi_kernel(const RepMultiParams mp) {
   RepParams p = mp.common;
   int begin = 0;
@@ -211,16 +231,23 @@ __global__ __launch_bounds__(1024) void gemv_kx8_rep_multi_kernel(const RepMulti
       begin = mp.seg[k].block_begin;
     }
   }
-  gemv_kx8_rep_body<T, KC, ITERS>(p, (int)blockIdx.x - begin);
+  gemv_kx8_rep_body<T, KC, ITERS, NQ>(p, (int)blockIdx.x - begin);
 }
 
-template <class T, int KC, int ITERS>
-static int launch_rep_multi_i(const RepMultiParams& mp, int blocks, hipStream_t stream) {
-  auto kern = gemv_kx8_rep_multi_kernel<T, KC, ITERS>;
+template <class T, int KC, int ITERS, int NQ>
+static int launch_rep_multi_q(const RepMultiParams& mp, int blocks, hipStream_t stream) {
+  auto kern = gemv_kx8_rep_multi_kernel<T, KC, ITERS, NQ>;
   const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * mp.common.pitch * 16;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, mp);
   return check_hip(hipGetLastError(), "gemv_kx8_rep_multi launch");
+}
+
+template <class T, int KC, int ITERS>
+static int launch_rep_multi_i(const RepMultiParams& mp, int blocks, hipStream_t stream) {
+  int max_rows = 0;
+  for (int k = 0; k < mp.nseg; ++k) max_rows = std::max(max_rows, mp.seg[k].rows_per_block);
+  return max_rows <= 16 ? launch_rep_multi_q<T, KC, ITERS, 1>(mp, blocks, stream) : launch_rep_multi_q<T, KC, ITERS, 4>(mp, blocks, stream);
 }
 
 template <class T, int KC>
@@ -232,15 +259,20 @@ static int launch_rep_multi(const RepMultiParams& mp, int blocks, hipStream_t st
   }
 }
 
-template <class T, int KC, int ITERS>
-static int launch_rep_i(const RepParams& p, int blocks, hipStream_t stream) {
-  auto kern = gemv_kx8_rep_kernel<T, KC, ITERS>;
+template <class T, int KC, int ITERS, int NQ>
+static int launch_rep_q(const RepParams& p, int blocks, hipStream_t stream) {
+  auto kern = gemv_kx8_rep_kernel<T, KC, ITERS, NQ>;
   const size_t lds = (size_t)KC * 256 * 16 * 16 + (size_t)8 * p.pitch * 16;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   RepRest rest{p.scales, p.bias, p.y};
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p.codes, p.codebooks, p.x, p.M, p.in_groups, p.nunits, p.iters,
                      p.pitch, p.rows_per_block, p.code_row_bytes, rest);
   return check_hip(hipGetLastError(), "gemv_kx8_rep launch");
+}
+
+template <class T, int KC, int ITERS>
+static int launch_rep_i(const RepParams& p, int blocks, hipStream_t stream) {
+  return p.rows_per_block <= 16 ? launch_rep_q<T, KC, ITERS, 1>(p, blocks, stream) : launch_rep_q<T, KC, ITERS, 4>(p, blocks, stream);
 }
 
 template <class T, int KC>
