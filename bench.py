@@ -63,7 +63,7 @@ class Layer:
         self.y = torch.empty((batch, fout), device=device, dtype=torch.float16)
         self.bytes = algorithmic_bytes(fin, fout, K, nbits, g, batch)
         self.packed = None
-        if PACK_MIN_OUT and (K, nbits, g) == (1, 16, 8) and fout * (fin // 8) >= PACK_MIN_OUT:
+        if PACK_MIN_OUT and (K, nbits) == (1, 16) and g in (8, 16) and fout * (fin // g) >= PACK_MIN_OUT:
             from aqlm_amd import _native
 
             self.prepack(_native.lib)
@@ -78,7 +78,7 @@ class Layer:
         self.packed = hk.prepack_1x16(self.codes, self.g, codebooks=self.codebooks)  # + the codebook range: single-kernel matvecs
         if self.packed is not None:
             nb = self.x.shape[0]
-            self.ws = torch.empty((16 * nb * self.fout,), dtype=torch.float32, device=self.codes.device)
+            self.ws = torch.empty((self.packed.slices * nb * self.fout,), dtype=torch.float32, device=self.codes.device)
 
     def launch(self, lib, stream, batch=1):
         import ctypes
@@ -132,7 +132,7 @@ class FusedLayers:
             sg.codebook, sg.scales, sg.bias = m.codebooks.data_ptr(), m.scales.data_ptr(), None
             sg.y, sg.y_row_stride, sg.out_features = m.y.data_ptr(), m.fout, m.fout
         if self.packed:
-            self.ws = torch.empty((16 * sum(m.fout for m in members),), dtype=torch.float32, device=self.x.device)
+            self.ws = torch.empty((members[0].packed.slices * sum(m.fout for m in members),), dtype=torch.float32, device=self.x.device)
             self.descs = (_native._descp * len(members))(*[ctypes.pointer(m.packed.desc) for m in members])
 
     def alg_bytes(self, batch=1):
@@ -657,6 +657,22 @@ def main():
             rows["B1"]["vs_B1"] = 1.0
             detail["batch_rows_1x16g8_4096x11008_prepacked"] = rows
             del nb_layers
+            # 16-element codebook vectors (1 bit per weight; the reference kernel's second template instance,
+            # cuda_kernel.cu:476-521): prepacked (32 slices of 2048 x 32 B) vs the direct L2-gather kernel
+            g16 = {}
+            for fi, fo in ((4096, 4096), (4096, 11008)):
+                ls = [Layer(fi, fo, 1, 16, 16, 6500 + rank * 10000 + i, dev) for i in range(int(600e6 / algorithmic_bytes(fi, fo, g=16)) + 1)]
+                gpp = GraphedPass(ls, lib)
+                us_p = gpp.time_replays(reps) * 1e3 / gpp.n
+                del gpp
+                for l in ls:
+                    l.packed = None
+                gpd = GraphedPass(ls, lib)
+                us_d = gpd.time_replays(reps) * 1e3 / gpd.n
+                g16[f"{fi}->{fo}"] = {"prepacked_cold_us": us_p, "direct_cold_us": us_d, "prepacked_GBps": ls[0].bytes / us_p * 1e-3,
+                                      "prepacked_frac_of_8TBps": ls[0].bytes / us_p * 1e-3 / HBM_PEAK_GBPS}
+                del gpd, ls
+            detail["1x16g16_prepacked_vs_direct"] = g16
         # true Llama-3-8B decode token: 32 x [q,o 4096->4096; k,v 4096->1024; gate,up 4096->14336; down 14336->4096]
         shapes = [(4096, 4096), (4096, 1024), (4096, 1024), (4096, 4096), (4096, 14336), (4096, 14336), (14336, 4096)]
         tok = [Layer(fi, fo, 1, 16, 8, 7000 + rank * 10000 + 7 * b + j, dev) for b in range(32) for j, (fi, fo) in enumerate(shapes)]
