@@ -1728,10 +1728,10 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   // rotated copies of x: 1 by default -- with the row pools the x reads are already spread well, and up to 4 copies
   // measured within +-1 % (profiles/r02_mb_packed_variants.log); the knob keeps the mechanism testable
   int XC = 1;
-  if (AQLM_PK_XFIRST && arrange && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
+  if (AQLM_PK_XFIRST && PK_G == 8 && arrange && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
   // 32-bit entries by default (1-3 % faster: two operations instead of four to form an entry's addresses); 24-bit entries
   // (-23 % bytes; wave ranges of at most 32 steps) are the compact choice for inference-only deployments
-  const int EB = (tuning().packed_entry_bytes == 3 && T <= 32) ? 3 : 4;
+  const int EB = (PK_G == 8 && tuning().packed_entry_bytes == 3 && T <= 32) ? 3 : 4;  // (the 3-byte form exists for 16-B vectors only)
   PackedLayout L, L4;
   if (!packed_layout(M, in_features, NW, T, L, XC, EB) || !packed_layout(M, in_features, NW, T, L4, XC, 4) ||
       L.used + (EB == 3 ? L4.ent_bytes + 1024 : 0) > packed_bytes) {

@@ -508,6 +508,8 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"waves=6", "packed_waves", 6}});
       variants.push_back({{"waves=4", "packed_waves", 4}});
       variants.push_back({{"waves=8", "packed_waves", 8}});
+      variants.push_back({{"waves=13", "packed_waves", 13}});
+      variants.push_back({{"waves=14", "packed_waves", 14}});
       variants.push_back({{"waves=16", "packed_waves", 16}});
       variants.push_back({{"prefetch=3", "packed_prefetch", 3}});
       variants.push_back({{"prefetch=4", "packed_prefetch", 4}});
