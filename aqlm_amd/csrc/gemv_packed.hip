@@ -787,7 +787,19 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // the parameters of the epilogue (the non-preloaded tail of the kernel arguments) are fetched NOW, under the LDS fill:
   // left to the compiler their s_load sits at the first use, behind the loop, with its whole latency exposed (0.3 us)
   asm volatile("" : : "s"(p.acc), "s"(p.partial), "s"(p.scales), "s"(p.bias), "s"(p.y), "s"(p.y_row_stride), "s"(p.cb_absmax));
-  if (!pfw) __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD) lgkmcnt(0)
+  // ... and so are scale and bias of the row this thread finalizes (cold they are an HBM round trip: requested behind the
+  // last-arrival test they sat at the very end of the kernel's critical path).  Unconditional, always-valid addresses
+  // (a branch around a load ends in a vmcnt(0) at the join); younger than the ring, so the wait below lets them fly too.
+  uint16_t scale_h, bias_h;
+  {
+    const int r = tid < nrows ? tid : (nrows > 0 ? nrows - 1 : 0);
+    const uint16_t* sp = p.scales ? p.scales : reinterpret_cast<const uint16_t*>(p.rowstart);  // partials mode: unused
+    const uint16_t* bp = p.bias ? p.bias : sp;
+    scale_h = sp[row_begin + r];
+    bias_h = bp[row_begin + r];
+  }
+  constexpr int PDW = PD + 2;
+  if (!pfw) __builtin_amdgcn_s_waitcnt((PDW & 15) | (7 << 4) | (0 << 8) | ((PDW >> 4) << 14));  // vmcnt(PD + 2) lgkmcnt(0)
   else __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));                          // prefetch waves: lgkmcnt(0) only
   __builtin_amdgcn_s_barrier();
   AQLM_TRACE(2);
@@ -1042,8 +1054,9 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
           mine[b] = ((unsigned long long)q << PK_VAL_SHIFT) + (finite ? 1ull : 1ull + (1ull << PK_CNT_BITS));
           old[b] = __hip_atomic_fetch_add(p.acc + (size_t)b * p.M + row, mine[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const float scale = pub_half ? 1.f : T_::to_float(p.scales[row]);
-        const float bias = (pub_half || !p.bias) ? 0.f : T_::to_float(p.bias[row]);
+        const bool first = r == tid;  // this thread's first (usually only) row: scale and bias were requested in the prologue
+        const float scale = pub_half ? 1.f : T_::to_float(first ? scale_h : p.scales[row]);
+        const float bias = (pub_half || !p.bias) ? 0.f : T_::to_float(first ? bias_h : p.bias[row]);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
           if ((old[b] & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
