@@ -655,7 +655,10 @@ struct PackedLds {
 };
 
 // `block` in [0, 256): the workgroup's index within its own layer (== blockIdx.x for a single-layer launch).
-template <class T_, int B, int PD, uint32_t XWIN, int EB>
+// PUB: the row-parallel shard's variant (the last arrival publishes the fp32 total for the peers instead of writing y).  A
+// template parameter, not a run-time test of p.pub: carrying the publish branches in the ordinary kernel cost 0.15 us per
+// launch (same box, profiles/r03_mb_ab_commits.log).
+template <class T_, int B, int PD, uint32_t XWIN, int EB, bool PUB = false>
 __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block, const int NWB) {
   using LDS = PackedLds<B, XWIN>;
   using ring_t = typename std::conditional<EB == 3, u32x3, u32x4>::type;
@@ -997,7 +1000,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   // ---- epilogue: row r = rowval[r] + the column remainders of the columns it crosses, in column order -------------
   float* pub_half = nullptr;
   uint32_t pub_e = 0u;
-  if (p.pub != nullptr && p.acc != nullptr) {  // row-parallel shard: publish instead of writing y (epoch parity picks the half)
+  if (PUB && p.pub != nullptr && p.acc != nullptr) {  // row-parallel shard: publish instead of writing y (epoch parity picks the half)
     pub_e = __hip_atomic_load(p.pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pub_half = p.pub + (size_t)(pub_e & 1u) * p.pub_max_elems;
   }
@@ -1134,7 +1137,7 @@ struct PackedGemvRest {
 #endif
 };
 
-template <class T_, int B, int PD, uint32_t XWIN, int EB>
+template <class T_, int B, int PD, uint32_t XWIN, int EB, bool PUB = false>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* codebook, const uint16_t* x, const uint32_t* ent,
                                                                 const uint32_t* rowstart, int in_groups, uint32_t geom, int RG,
                                                                 uint32_t ent_bytes, int M, const PackedGemvRest rest) {
@@ -1174,7 +1177,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* c
   p.trace = rest.trace;
   p.dbg = rest.dbg;
 #endif
-  gemv_1x16_packed_body<T_, B, PD, XWIN, EB>(p, blockIdx.x, NW + NPW);
+  gemv_1x16_packed_body<T_, B, PD, XWIN, EB, PUB>(p, blockIdx.x, NW + NPW);
 }
 
 // Several prepacked layers that multiply the same x (q/k/v, gate/up) in one launch of 256 workgroups per layer; the
@@ -1621,6 +1624,10 @@ struct SingleKernels {
   template <class T_, int B, int PD, int EB>
   static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL, EB>; }
 };
+struct PublishKernels {  // row-parallel shards (aqlm_hip_gemv_1x16_packed_publish)
+  template <class T_, int B, int PD, int EB>
+  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL, EB, true>; }
+};
 struct MultiKernels {
   template <class T_, int B, int PD, int EB>
   static auto get() { return gemv_1x16_packed_multi_kernel<T_, B, PD, PK_XWIN_FULL, EB>; }
@@ -1934,6 +1941,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
                        p.ent_bytes, p.M, rest);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
+  if (p.pub != nullptr) return dispatch_packed<PublishKernels>(dtype, nb, pick_pd(L), L.EB, launch);
   return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, launch);
 }
 
