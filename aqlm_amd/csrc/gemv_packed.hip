@@ -133,9 +133,12 @@ struct PackedLayout {
 
 __host__ __device__ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+static int packed_max_batch(int in_groups, int RG);  // rows of x whose LDS image fits a CU (0: not even one)
+
 static bool packed_shape_ok(int out_features, int in_features, int g) {
   return g == PK_G && out_features > 0 && in_features > 0 && in_features % PK_G == 0 && in_features / PK_G <= PK_MAX_GROUPS &&
-         (out_features + PK_NG - 1) / PK_NG <= 32767 - PK_MAX_NW;
+         (out_features + PK_NG - 1) / PK_NG <= 32767 - PK_MAX_NW &&
+         packed_max_batch(in_features / PK_G, (out_features + PK_NG - 1) / PK_NG) >= 1;  // slice + x + the row tables of a row group in 160 KiB
 }
 
 static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1, int EB = 4) {
@@ -632,7 +635,7 @@ __device__ __forceinline__ void lds_store_f32(uint32_t byte_addr, float v) {
 //   column accumulated after its last row end: the head of a row that continues in the next column)
 template <int B, uint32_t XWIN>
 struct PackedLds {
-  static constexpr bool XFIRST = (B == 1) && AQLM_PK_XFIRST;
+  static constexpr bool XFIRST = (B == 1) && AQLM_PK_XFIRST && XWIN != 0u;  // XWIN == 0: slice first also for one row (tall layers)
   static constexpr uint32_t SLICE = XFIRST ? XWIN : 0u;
   static constexpr uint32_t X = XFIRST ? 0u : PK_SLICE_BYTES;
   __host__ __device__ static uint32_t plane(int in_groups) { return (uint32_t)(in_groups + 1) * PK_VB; }
@@ -1594,9 +1597,12 @@ static int pick_pd(const PackedLayout& L) {
 
 // Instantiations: (dtype, B, PD, entry bytes).  Only the batch-1 kernels come with the deeper ring (PD = 8): with more
 // rows the loop is LDS-bound and 4 steps in flight cover the stream.
+// slice_first: the one-row image with the slice in front (no 64 KiB x window): for layers whose row tables do not fit
+// behind the window (packed_b1_slice_first).
 template <class KP, class Launch>
-static int dispatch_packed(int dtype, int batch, int pd, int eb, Launch&& launch) {
-#define AQLM_PK_GO(TT, BB, PP, EE) launch(KP::template get<TT, BB, PP, EE>(), PackedLds<BB, PK_XWIN_FULL>{})
+static int dispatch_packed(int dtype, int batch, int pd, int eb, bool slice_first, Launch&& launch) {
+#define AQLM_PK_GO(TT, BB, PP, EE) launch(KP::template get<TT, BB, PP, EE, PK_XWIN_FULL>(), PackedLds<BB, PK_XWIN_FULL>{})
+#define AQLM_PK_GO0(TT, PP, EE) launch(KP::template get<TT, 1, PP, EE, 0u>(), PackedLds<1, 0u>{})
 #define AQLM_PK_CASE(BB)                                                                                      \
   case BB:                                                                                                    \
     if (dtype == AQLM_HIP_F16) return eb == 3 ? AQLM_PK_GO(F16, BB, 4, 3) : AQLM_PK_GO(F16, BB, 4, 4);          \
@@ -1604,6 +1610,10 @@ static int dispatch_packed(int dtype, int batch, int pd, int eb, Launch&& launch
   switch (batch) {
     case 1:
 #define AQLM_PK_B1(TT, EE) (pd == 8 ? AQLM_PK_GO(TT, 1, 8, EE) : (pd == 4 ? AQLM_PK_GO(TT, 1, 4, EE) : AQLM_PK_GO(TT, 1, 3, EE)))
+      if (slice_first) {  // (ring depth 3, the default, only)
+        if (dtype == AQLM_HIP_F16) return eb == 3 ? AQLM_PK_GO0(F16, 3, 3) : AQLM_PK_GO0(F16, 3, 4);
+        return eb == 3 ? AQLM_PK_GO0(BF16, 3, 3) : AQLM_PK_GO0(BF16, 3, 4);
+      }
       if (dtype == AQLM_HIP_F16) return eb == 3 ? AQLM_PK_B1(F16, 3) : AQLM_PK_B1(F16, 4);
       return eb == 3 ? AQLM_PK_B1(BF16, 3) : AQLM_PK_B1(BF16, 4);
 #undef AQLM_PK_B1
@@ -1617,28 +1627,31 @@ static int dispatch_packed(int dtype, int batch, int pd, int eb, Launch&& launch
   }
 #undef AQLM_PK_CASE
 #undef AQLM_PK_GO
+#undef AQLM_PK_GO0
   return AQLM_HIP_E_INVALID;
 }
 
 struct SingleKernels {
-  template <class T_, int B, int PD, int EB>
-  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL, EB>; }
+  template <class T_, int B, int PD, int EB, uint32_t XW>
+  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, XW, EB>; }
 };
 struct PublishKernels {  // row-parallel shards (aqlm_hip_gemv_1x16_packed_publish)
-  template <class T_, int B, int PD, int EB>
-  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, PK_XWIN_FULL, EB, true>; }
+  template <class T_, int B, int PD, int EB, uint32_t XW>
+  static auto get() { return gemv_1x16_packed_kernel<T_, B, PD, XW, EB, true>; }
 };
 struct MultiKernels {
-  template <class T_, int B, int PD, int EB>
-  static auto get() { return gemv_1x16_packed_multi_kernel<T_, B, PD, PK_XWIN_FULL, EB>; }
+  template <class T_, int B, int PD, int EB, uint32_t XW>
+  static auto get() { return gemv_1x16_packed_multi_kernel<T_, B, PD, XW, EB>; }
 };
 
 // largest batch whose LDS image fits the CU
 template <int BB>
 static size_t packed_lds_total(int in_groups, int RG) { return PackedLds<BB, PK_XWIN_FULL>::total(in_groups, RG); }
+// one row: x first (a 64 KiB window, both reads without an address add) where that fits, else slice first
+static bool packed_b1_slice_first(int in_groups, int RG) { return packed_lds_total<1>(in_groups, RG) > 160 * 1024; }
 static size_t packed_lds_need(int b, int in_groups, int RG) {
   switch (b) {
-    case 1: return packed_lds_total<1>(in_groups, RG);
+    case 1: return std::min(packed_lds_total<1>(in_groups, RG), PackedLds<1, 0u>::total(in_groups, RG));
     case 2: return packed_lds_total<2>(in_groups, RG);
     case 3: return packed_lds_total<3>(in_groups, RG);
     case 4: return packed_lds_total<4>(in_groups, RG);
@@ -1649,6 +1662,8 @@ static size_t packed_lds_need(int b, int in_groups, int RG) {
   }
 }
 static int packed_max_batch(int in_groups, int RG) {
+  // (the single-row image is not always the smallest: x first keeps a 64 KiB window in front of the slice)
+  if (packed_lds_need(1, in_groups, RG) > 160 * 1024) return 0;
   int b = AQLM_HIP_MAX_GEMV_BATCH;
   while (b > 1 && packed_lds_need(b, in_groups, RG) > 160 * 1024) --b;
   return packed_lds_need(b, in_groups, RG) <= 160 * 1024 ? b : 0;
@@ -1748,7 +1763,7 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   // rotated copies of x: 1 by default -- with the row pools the x reads are already spread well, and up to 4 copies
   // measured within +-1 % (profiles/r02_mb_packed_variants.log); the knob keeps the mechanism testable
   int XC = 1;
-  if (AQLM_PK_XFIRST && PK_G == 8 && arrange && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
+  if (AQLM_PK_XFIRST && PK_G == 8 && arrange && !packed_b1_slice_first(in_groups, RG) && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
   // 32-bit entries by default (1-3 % faster: two operations instead of four to form an entry's addresses); 24-bit entries
   // (-23 % bytes; wave ranges of at most 32 steps) are the compact choice for inference-only deployments
   const int EB = (PK_G == 8 && tuning().packed_entry_bytes == 3 && T <= 32) ? 3 : 4;  // (the 3-byte form exists for 16-B vectors only)
@@ -1941,8 +1956,9 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
                        p.ent_bytes, p.M, rest);
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
-  if (p.pub != nullptr) return dispatch_packed<PublishKernels>(dtype, nb, pick_pd(L), L.EB, launch);
-  return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, launch);
+  const bool sf = nb == 1 && packed_b1_slice_first(L.in_groups, L.RG);
+  if (p.pub != nullptr) return dispatch_packed<PublishKernels>(dtype, nb, pick_pd(L), L.EB, sf, launch);
+  return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, sf, launch);
 }
 
 static int packed_check_args(const char* who, const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
@@ -2280,7 +2296,7 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
     hipLaunchKernelGGL(kern, dim3(PK_NST * num_segments), dim3(nw * 64), lds, stream, mp);
     return check_hip(hipGetLastError(), "gemv_1x16_packed_multi launch");
   };
-  if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, eb, launch)) return e;
+  if (int e = dispatch_packed<MultiKernels>(dtype, batch, pd, eb, batch == 1 && packed_b1_slice_first(mp.in_groups, max_rg), launch)) return e;
   if (fused) return 0;
   if (dtype == AQLM_HIP_F16)
     hipLaunchKernelGGL(gemv_1x16_packed_finalize_multi<F16>, dim3(fblocks), dim3(256), 0, stream, fm);

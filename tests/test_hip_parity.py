@@ -465,6 +465,7 @@ PACKED_SHAPES = [
     (512, 7168, "bfloat16", False),
     (2048, 1500, "float16", True),
     (520, 64, "float16", True),          # 65 input groups (not a multiple of 8)
+    (256, 57344, "float16", False),      # 3584 rows per row group: the one-row image puts the slice first (no x window)
 ]
 
 
@@ -523,6 +524,7 @@ PACKED_G16_SHAPES = [
     (128, 256, "float16", True),         # 8 input groups: null lane-steps almost everywhere
     (1040, 70, "bfloat16", True),        # 65 input groups, fewer rows than 8 x waves
     (28672, 512, "float16", True),       # the widest x image (56 KiB) behind the slice
+    (1024, 28672, "float16", True),      # 3584 rows per row group: the one-row image puts the slice first (no x window)
 ]
 
 
