@@ -105,6 +105,10 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
   // Replicated fill: thread t writes copy r = t & 15 of entries (t >> 4) + 64 k.  The 8 lanes of a ds_write_b128 service
   // group then hit 8 distinct 16-B slots (conflict free); the 16 threads of an entry read the same 16 B from L2 (one
   // request).  x (in_groups <= 1536 < 2 NT): at most two vectors per thread.
+  // Measured on one box (profiles/r03_mb_kx8_hoisted_loads.log): with one row per wave (NQ = 1: 4096-row layers) the early
+  // request gains 4 % (4096 -> 4096: 5.11 -> 4.90 us) to 10 % (11008 -> 4096: 8.6 -> 7.7 us); with four rows per wave
+  // (4096 -> 11008) it LOSES 6 % (7.08 -> 7.49 us), so those keep requesting their code words behind the barrier.
+  constexpr bool HOIST = NQ == 1;
   uint32_t cwq[NQ][ITERS][CW];
   {
     const int r = tid & 15;
@@ -113,20 +117,23 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
 #pragma unroll
     for (int k = 0; k < ENTRIES / 64; ++k) v[k] = src[(tid >> 4) + 64 * k];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int q = tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups - 1;
-      xv[k] = *reinterpret_cast<const u32x4*>(p.x + (long)q * 8);
+    for (int k = 0; k < 2; ++k) {  // guarded load HERE, guarded store below: two separate branches, so hipcc cannot sink the
+      xv[k] = u32x4{0u, 0u, 0u, 0u};  // load into the store's block (behind the code words, where it would wait for them
+      const int q = tid + k * NT;     // with vmcnt(0)); an unguarded store of a clamped address serialises hundreds of
+      if (q < p.in_groups) xv[k] = *reinterpret_cast<const u32x4*>(p.x + (long)q * 8);  // threads on one LDS slot (+0.3 us)
     }
     __builtin_amdgcn_sched_barrier(0);  // keep this order: loads return in order, and the fill must not wait for the codes
-    load_round(0, cwq);
-    load_epilogue(0);
+    if constexpr (HOIST) {
+      load_round(0, cwq);
+      load_epilogue(0);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < ENTRIES / 64; ++k) cbl[((tid >> 4) + 64 * k) * 16 + r] = v[k];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {  // unconditional (threads past the end rewrite the last vector): a guarded store would pull
-      const int q = tid + k * NT < p.in_groups ? tid + k * NT : p.in_groups - 1;  // its load into the branch, behind a vmcnt(0)
-      xl[(q & 7) * p.pitch + (q >> 3)] = xv[k];
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT;
+      if (q < p.in_groups) xl[(q & 7) * p.pitch + (q >> 3)] = xv[k];
     }
   }
   __syncthreads();
@@ -135,7 +142,7 @@ __device__ __forceinline__ void gemv_kx8_rep_body(const RepParams& p, const int 
   const unsigned char* const cb_bytes = reinterpret_cast<const unsigned char*>(cbl);
 
   for (int base = 0; base < nrows; base += 16 * NQ) {
-    if (base > 0) {
+    if (!HOIST || base > 0) {
       load_round(base, cwq);
       load_epilogue(base);
     }
