@@ -154,15 +154,17 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
   // nslabs - 1 earlier arrivals applies scale and bias, rounds once, writes y and zeroes the cell.  The returned values
   // of a round are looked at one round later, so the atomics' round trip hides behind the next rows' table reads.
   unsigned long long pend_old[4], pend_mine[4];
-  int pend_row[4] = {-1, -1, -1, -1};
+  uint16_t pend_scale[4] = {0, 0, 0, 0}, pend_bias[4] = {0, 0, 0, 0};  // requested with the atomic: behind the last-arrival test they
+  int pend_row[4] = {-1, -1, -1, -1};                                  // were a second round trip at the very end of the kernel
+  const uint16_t* const bias_src = p.bias ? p.bias : p.scales;
   auto settle = [&](int k) {
     if (pend_row[k] >= 0 && (pend_old[k] & 1023ull) == (unsigned long long)(p.nslabs - 1)) {
       const int row = pend_row[k];
       const unsigned long long cell = pend_old[k] + pend_mine[k];
       float sv = (float)ldexp((double)((long long)cell >> 20), -sh);
       if ((cell >> 10) & 1023ull) sv = __builtin_nanf("");
-      const float scale = T::to_float(p.scales[row]);
-      const float bias = p.bias ? T::to_float(p.bias[row]) : 0.f;
+      const float scale = T::to_float(pend_scale[k]);
+      const float bias = p.bias ? T::to_float(pend_bias[k]) : 0.f;
       p.y[row] = T::from_float(__builtin_fmaf(sv, scale, bias));
       __hip_atomic_store(p.cells + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -196,6 +198,8 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
           pend_mine[k] = ((unsigned long long)q << 20) + (finite ? 1ull : 1025ull);
           pend_row[k] = row_begin + r;
           pend_old[k] = __hip_atomic_fetch_add(p.cells + pend_row[k], pend_mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pend_scale[k] = p.scales[pend_row[k]];
+          pend_bias[k] = bias_src[pend_row[k]];
         }
       }
     }
