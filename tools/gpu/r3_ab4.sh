@@ -5,7 +5,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 AB=$PWD/tools/microbench/ab
 for pass in 1 2 3; do
-  for c in new3 new4; do
+  for c in new4 new5; do
     timeout 200 $AB/mb_$c gemv quick 8x8g32LUT > $OUT/mb_${c}_$pass.log 2>&1
     grep " 1 default  \| 1 two" $OUT/mb_${c}_$pass.log | sed "s/^/$c pass $pass: /"
   done
