@@ -271,7 +271,8 @@ int aqlm_hip_gemv_1x16_packed_multi_cells(const aqlm_hip_segment* segments, cons
  * slice-summed vector in a buffer the peers have mapped (IPC), raises a flag, waits (bounded) for the peers' flags, reads
  * their vectors over xGMI and adds them in rank order, then scale + bias + one rounding -- y is bit-identical on every rank.
  * State per rank: one device allocation of aqlm_hip_xgmi_state_bytes(max_elems) bytes, zero-filled except epoch = 1, laid
- * out as  [pub: 2 x max_elems fp32][flag: 2 x u32 at byte 8 * max_elems][epoch, 2 tickets: 3 x u32 at +64][status: u32 at +128];
+ * out as  [pub: 2 x max_elems fp32][flag: 2 x u32 at byte 8 * max_elems][epoch, 2 tickets: 3 x u32 at +64][arrival counters of
+ * aqlm_hip_gemv_1x16_packed_publish: 9 x u32 at +80][status: u32 at +128];
  * `peer_pub[r]` / `peer_flag[r]` are DEVICE arrays (world entries) of the peers' pub / flag addresses as mapped into this
  * process (own entries included).  Collective semantics: every rank calls it the same number of times.  On a time-out
  * (spin_limit polls, 0 = default ~seconds) status becomes 1 and y is NaN.  Graph-capturable (the epoch lives in device memory).
