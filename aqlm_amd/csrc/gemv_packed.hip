@@ -68,8 +68,10 @@
 #define aqlm_hip_gemv_1x16_packed_publish aqlm_hip_g16_gemv_1x16_packed_publish
 #define aqlm_hip_gemv_1x16_packed_multi aqlm_hip_g16_gemv_1x16_packed_multi
 #define aqlm_hip_gemv_1x16_packed_multi_cells aqlm_hip_g16_gemv_1x16_packed_multi_cells
+#define PK_API __attribute__((visibility("hidden")))  // internal to libaqlm_hip.so: reached through the public entries only
 #else
 #define PK_NS pk_g8
+#define PK_API
 #endif
 
 namespace aqlm {
@@ -1676,7 +1678,8 @@ using namespace aqlm;
 using namespace aqlm::PK_NS;
 
 #if AQLM_PK_G == 8
-// the 16-element twin of this file (same signatures)
+// the 16-element twin of this file (same signatures; hidden symbols of this library)
+#pragma GCC visibility push(hidden)
 extern "C" {
 size_t aqlm_hip_g16_prepack_1x16_bytes(int, int, int);
 int aqlm_hip_g16_prepack_1x16(const void*, int, int, int, void*, size_t, aqlm_hip_packed_desc*, void*);
@@ -1696,6 +1699,7 @@ int aqlm_hip_g16_gemv_1x16_packed_multi(const aqlm_hip_segment*, const aqlm_hip_
 int aqlm_hip_g16_gemv_1x16_packed_multi_cells(const aqlm_hip_segment*, const aqlm_hip_packed_desc* const*, int, const void*, int, int, long, int,
                                               void*, size_t, void*);
 }
+#pragma GCC visibility pop
 // a descriptor of the twin's format (32 slices)
 static inline bool pk_is_g16(const aqlm_hip_packed_desc* d) { return d && d->slices_log2 == 5; }
 #define PK_G16_FORWARD(desc_expr, call) \
@@ -1707,7 +1711,7 @@ static inline bool pk_is_g16(const aqlm_hip_packed_desc* d) { return d && d->sli
 #define PK_G16_FORWARD_IF(cond, call)
 #endif
 
-extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size) {
+extern "C" PK_API size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size) {
   PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16_bytes(out_features, in_features, in_group_size));
   if (!packed_shape_ok(out_features, in_features, in_group_size)) return 0;
   // capacity for codes that use the slices up to 25 % unevenly, plus the scratch of the repack (row starts);
@@ -1722,7 +1726,7 @@ extern "C" size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features,
   return align_up(meta + ent + ent * PK_WREG3 / 1024 + 4096, 1024);
 }
 
-extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
+extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
                                      void* packed, size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream_) {
   PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16(codes, out_features, in_features, in_group_size, packed, packed_bytes, desc, stream_));
   hipStream_t stream = (hipStream_t)stream_;
@@ -1807,7 +1811,7 @@ extern "C" int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in
   return 0;
 }
 
-extern "C" int aqlm_hip_packed_desc_read(const void* header_host, size_t header_bytes, aqlm_hip_packed_desc* desc) {
+extern "C" PK_API int aqlm_hip_packed_desc_read(const void* header_host, size_t header_bytes, aqlm_hip_packed_desc* desc) {
 #if AQLM_PK_G == 8
   if (header_host && desc && header_bytes >= sizeof(aqlm_hip_packed_desc)) {
     aqlm_hip_packed_desc h;
@@ -1830,7 +1834,7 @@ extern "C" int aqlm_hip_packed_desc_read(const void* header_host, size_t header_
   return 0;
 }
 
-extern "C" int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, void* codes, void* stream_) {
+extern "C" PK_API int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, void* codes, void* stream_) {
   PK_G16_FORWARD(desc, aqlm_hip_g16_unpack_1x16(desc, packed, codes, stream_));
   hipStream_t stream = (hipStream_t)stream_;
   PackedLayout L;
@@ -1995,7 +1999,7 @@ static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed,
                                  size_t workspace_bytes, void* stream_, const PackedNext& next, void* cells = nullptr,
                                  size_t cells_bytes = 0);
 
-extern "C" int aqlm_hip_gemv_1x16_packed_cells(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed_cells(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
                                                const void* scales, const void* bias, const void* x, void* y, int batch,
                                                long x_row_stride, long y_row_stride, int dtype, void* cells,
                                                size_t cells_bytes, void* stream_) {
@@ -2014,7 +2018,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_cells(const aqlm_hip_packed_desc* desc,
                                nullptr, 0, stream_, PackedNext{}, cells, cells_bytes);
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                          const void* scales, const void* bias, const void* x, void* y, int batch,
                                          long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                          size_t workspace_bytes, void* stream_) {
@@ -2023,7 +2027,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed(const aqlm_hip_packed_desc* desc, void*
                                workspace_bytes, stream_, PackedNext{});
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                                const void* scales, const void* bias, const void* x, void* y, int batch,
                                                long x_row_stride, long y_row_stride, int dtype, void* workspace,
                                                size_t workspace_bytes, const aqlm_hip_packed_desc* next_desc,
@@ -2094,7 +2098,7 @@ static int gemv_1x16_packed_impl(const aqlm_hip_packed_desc* desc, void* packed,
   return 0;
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed_partials(const aqlm_hip_packed_desc* desc, const void* packed, const void* codebook,
                                                   const void* x, int batch, long x_row_stride, int dtype, void* workspace,
                                                   size_t workspace_bytes, void* stream_) {
   PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed_partials(desc, packed, codebook, x, batch, x_row_stride, dtype, workspace, workspace_bytes, stream_));
@@ -2116,7 +2120,7 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
                                        int dtype, void* workspace, size_t workspace_bytes, void* cells, size_t cells_bytes,
                                        void* stream_);
 
-extern "C" int aqlm_hip_gemv_1x16_packed_publish(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed_publish(const aqlm_hip_packed_desc* desc, void* packed, const void* codebook,
                                                  const void* x, int batch, long x_row_stride, int dtype,
                                                  const aqlm_hip_xgmi* xg, void* pub_own, void* flag_own, void* stream_) {
   PK_G16_FORWARD(desc, aqlm_hip_g16_gemv_1x16_packed_publish(desc, packed, codebook, x, batch, x_row_stride, dtype, xg, pub_own, flag_own, stream_));
@@ -2140,7 +2144,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_publish(const aqlm_hip_packed_desc* des
                             "aqlm_hip_gemv_1x16_packed_publish", fz);
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
                                                int num_segments, const void* x, int in_features, int batch,
                                                long x_row_stride, int dtype, void* workspace, size_t workspace_bytes,
                                                void* stream_) {
@@ -2149,7 +2153,7 @@ extern "C" int aqlm_hip_gemv_1x16_packed_multi(const aqlm_hip_segment* segments,
                                      workspace_bytes, nullptr, 0, stream_);
 }
 
-extern "C" int aqlm_hip_gemv_1x16_packed_multi_cells(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
+extern "C" PK_API int aqlm_hip_gemv_1x16_packed_multi_cells(const aqlm_hip_segment* segments, const aqlm_hip_packed_desc* const* descs,
                                                      int num_segments, const void* x, int in_features, int batch,
                                                      long x_row_stride, int dtype, void* cells, size_t cells_bytes,
                                                      void* stream_) {
