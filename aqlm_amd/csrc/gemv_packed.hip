@@ -627,6 +627,25 @@ __device__ __forceinline__ uint32_t half_and(uint32_t w, uint32_t mask) {
 __device__ __forceinline__ void lds_store_f32(uint32_t byte_addr, float v) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(byte_addr), "v"(v) : "memory");
 }
+// LDS reads hipcc does not see (pipelined kernel's epilogue): while LDS-DMA requests are in flight the compiler guards every
+// LDS read it knows of with vmcnt(0) -- it cannot tell which addresses the DMA writes.  The caller waits (lds_asm_wait)
+// before it uses the values.
+__device__ __forceinline__ uint32_t lds_asm_load_b32(uint32_t byte_addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(byte_addr));  // no "memory" clobber: with one hipcc treats the asm as a possible LDS reader and puts vmcnt(0) in front
+  return v;
+}
+__device__ __forceinline__ u32x4 lds_asm_load_b128(uint32_t byte_addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+// the wait names the registers it guards ("+v"): a bare `s_waitcnt` asm orders nothing for the compiler's scheduler, which
+// is free to move a USE of an asm-loaded value in front of it (it happened: wrong row sums in one build, right ones in the next)
+__device__ __forceinline__ void lds_asm_wait(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_asm_wait(uint32_t& a, uint32_t& b, uint32_t& c, u32x4& d0, u32x4& d1, u32x4& d2, u32x4& d3) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+}
 
 // LDS map (byte offsets from the start of the workgroup's LDS, which is address 0: the kernel has no static LDS).
 //   B == 1: x at 0 (XWIN bytes reserved), slice at XWIN, bookkeeping behind the slice   (x-first: both reads cost one op)
@@ -1341,6 +1360,7 @@ __host__ __device__ static inline PipeLds pipe_lds(int max_rg) {
 struct PipeParams {
   const uint16_t* x;
   int in_groups, nseg, max_rg, nwc;  // nwc: compute waves of the workgroup
+  int dma_waves;                     // PP_DMA_WAVES, or 0: every compute wave requests its share of the next slice itself
   PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
@@ -1350,7 +1370,7 @@ __device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_vgpr, uint3
   return d;
 }
 
-template <class T_>
+template <class T_, bool SELF_DMA>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeParams mp) {
   constexpr int PD = 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1358,6 +1378,11 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NWC = mp.nwc;
+  // Layers packed for 15 or 16 waves leave no room for DMA waves: then every compute wave requests its share of segment
+  // k + 1's slice when its own steps of segment k are done -- the requests land under the epilogue (barrier, row sums,
+  // atomic round trip).  Not earlier: loads return in order, so a request in front of ring fetches would stall the loop
+  // for the slice's latency, and hipcc guards VGPR loads with vmcnt(0) while LDS-DMA is in flight.
+  constexpr bool self_dma = SELF_DMA;  // == (mp.dma_waves == 0)
   const bool dma_wave = wave >= NWC;
   const int dw = wave - NWC;  // 0 / 1 for the DMA waves
   const int block = (int)blockIdx.x;
@@ -1395,7 +1420,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
 
   // ---- prologue: every wave helps with the first fill (slice 0, x, row starts 0), as in the single-layer kernel ---------
   PackedSegment s0 = segment(0);
-  const int NWB = NWC + PP_DMA_WAVES;
+  const int NWB = NWC + mp.dma_waves;
   dma_slice(s0, 0, wave, NWB);
   {
     const int nchunk = (mp.in_groups + 63) >> 6;
@@ -1521,6 +1546,15 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       if (lane == 0) *reinterpret_cast<uint32_t*>(smem_raw + L.xmax + (uint32_t)wave * 4u) = mm;
     }
     if (wave < s.NW) lds_store_f32(L.colend + (uint32_t)(wave * 64 + lane) * 4u, acc);
+    // every entry fetch of this wave has landed (the next segment's first steps were requested a loop ago): said with the
+    // builtin on EVERY path, so that hipcc's wait-count pass knows no VGPR load is pending when the epilogue reuses the
+    // ring's registers -- otherwise it guards that reuse with vmcnt(0), i.e. waits for the LDS-DMA issued just below
+    if constexpr (SELF_DMA) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+    if (self_dma && k + 1 < mp.nseg) {  // this wave's share of the next slice and row-start table (buffer (k + 1) & 1 is free: its
+      const PackedSegment sn = segment(k + 1);  // last readers passed F_{k-1})
+      dma_slice(sn, (k + 1) & 1, wave, NWC);
+      dma_rowstart(sn, (k + 1) & 1, wave, NWC);
+    }
     rs_ent = rs_next;
 #pragma unroll
     for (int j = 0; j < PD; ++j) ring[j] = ring_next[j];
@@ -1528,21 +1562,43 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     __builtin_amdgcn_s_barrier();                          // M_k
     // ---- epilogue of segment k (compute waves): row sums -> fixed-point cell -> last arrival writes y ---------------------
     {
-      const uint32_t* rs = reinterpret_cast<const uint32_t*>(smem_raw + L.rs0 + (uint32_t)(k & 1) * L.rs_bytes);
-      const float* rowval = reinterpret_cast<const float*>(smem_raw + L.rowval);
-      const float* colend = reinterpret_cast<const float*>(smem_raw + L.colend);
+      const uint32_t rs_off = L.rs0 + (uint32_t)(k & 1) * L.rs_bytes;
       const uint32_t T = (uint32_t)s.T;
       const int row_begin = group * s.RG;
       for (int r = tid; r < nrows; r += NTC) {
-        const uint32_t q0 = rs[r], q1 = rs[r + 1];
-        const uint32_t c0 = q0 / T, c1 = (q1 - 1u) / T;
-        float v = rowval[r];
-        for (uint32_t c = c0; c < c1; ++c) v += colend[c];
-        uint32_t xm = 0u;
-        {
-          u32x4 sl[4];
+        uint32_t q0, q1;
+        float v;
+        u32x4 sl[4];
+        if constexpr (SELF_DMA) {  // asm reads: segment k + 1's slice is on its way into the other buffer (lds_asm_load_b32)
+          q0 = lds_asm_load_b32(rs_off + (uint32_t)r * 4u);
+          q1 = lds_asm_load_b32(rs_off + (uint32_t)r * 4u + 4u);
+          uint32_t vbits = lds_asm_load_b32(L.rowval + (uint32_t)r * 4u);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sl[q] = lds_asm_load_b128(L.xmax + (uint32_t)(q * 4) * 4u);
+          lds_asm_wait(q0, q1, vbits, sl[0], sl[1], sl[2], sl[3]);
+          v = __uint_as_float(vbits);
+          const uint32_t c0 = q0 / T;
+          uint32_t c1 = (q1 - 1u) / T;
+          c1 = c1 < (uint32_t)(PK_MAX_NW * 64) ? c1 : (uint32_t)(PK_MAX_NW * 64 - 1);  // a column index, whatever was read
+          for (uint32_t c = c0; c < c1; ++c) {
+            uint32_t ce = lds_asm_load_b32(L.colend + c * 4u);
+            lds_asm_wait(ce);
+            v += __uint_as_float(ce);
+          }
+        } else {
+          const uint32_t* rs = reinterpret_cast<const uint32_t*>(smem_raw + rs_off);
+          const float* rowval = reinterpret_cast<const float*>(smem_raw + L.rowval);
+          const float* colend = reinterpret_cast<const float*>(smem_raw + L.colend);
+          q0 = rs[r];
+          q1 = rs[r + 1];
+          const uint32_t c0 = q0 / T, c1 = (q1 - 1u) / T;
+          v = rowval[r];
+          for (uint32_t c = c0; c < c1; ++c) v += colend[c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) sl[q] = *(lds_u32x4_ptr)(size_t)(L.xmax + (uint32_t)(q * 4) * 4u);
+        }
+        uint32_t xm = 0u;
+        {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t a = sl[q].x > sl[q].y ? sl[q].x : sl[q].y, c = sl[q].z > sl[q].w ? sl[q].z : sl[q].w;
@@ -1572,11 +1628,12 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    if (self_dma) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0): my share of slice k + 1 has landed
     __builtin_amdgcn_s_barrier();                          // F_k
   }
 }
 
-static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max_rg, int& nwc) {
+static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max_rg, int& nwc, int& dma_waves) {
   max_rg = 0;
   nwc = 0;
   for (int k = 0; k < n; ++k) {
@@ -1584,7 +1641,10 @@ static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max
     max_rg = std::max(max_rg, Ls[k].RG);
     nwc = std::max(nwc, Ls[k].NW);
   }
-  if (PK_S_LOG != 4 || PK_G != 8 || n < 2 || nwc + PP_DMA_WAVES > PK_MAX_NW || (uint32_t)(in_groups + 1) * 16u > PP_XWIN) return false;
+  if (PK_S_LOG != 4 || PK_G != 8 || n < 2 || nwc > PK_MAX_NW || (uint32_t)(in_groups + 1) * 16u > PP_XWIN) return false;
+  dma_waves = nwc + PP_DMA_WAVES <= PK_MAX_NW ? PP_DMA_WAVES : 0;
+  if (tuning().packed_pipe == 2) dma_waves = 0;  // experiments: self-service DMA for every shape
+  if (tuning().packed_pipe == 3 && dma_waves == 0) return false;  // experiments: round-3 first cut (DMA waves only)
   return pipe_lds(max_rg).total <= 160u * 1024u;
 }
 
@@ -2276,22 +2336,24 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
   if (fused && batch == 1 && tuning().packed_pipe) {
     PackedLayout Ls[AQLM_HIP_MAX_SEGMENTS];
     for (int k = 0; k < num_segments; ++k) desc_layout(descs[k], Ls[k]);
-    int prg = 0, nwc = 0;
-    if (pipe_eligible(Ls, num_segments, mp.in_groups, prg, nwc)) {
+    int prg = 0, nwc = 0, dmaw = 0;
+    if (pipe_eligible(Ls, num_segments, mp.in_groups, prg, nwc, dmaw)) {
       PipeParams pp{};
       pp.x = mp.x;
       pp.in_groups = mp.in_groups;
       pp.nseg = num_segments;
       pp.max_rg = prg;
       pp.nwc = nwc;
+      pp.dma_waves = dmaw;
       for (int k = 0; k < num_segments; ++k) pp.seg[k] = mp.seg[k];
       const size_t lds = pipe_lds(prg).total;
       auto go = [&](auto kern) -> int {
         if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(PK_NST), dim3((nwc + PP_DMA_WAVES) * 64), lds, stream, pp);
+        hipLaunchKernelGGL(kern, dim3(PK_NST), dim3((nwc + dmaw) * 64), lds, stream, pp);
         return check_hip(hipGetLastError(), "gemv_1x16_packed_pipe launch");
       };
-      return dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16>) : go(gemv_1x16_packed_pipe_kernel<BF16>);
+      if (dmaw == 0) return dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16, true>) : go(gemv_1x16_packed_pipe_kernel<BF16, true>);
+      return dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16, false>) : go(gemv_1x16_packed_pipe_kernel<BF16, false>);
     }
   }
   auto launch = [&](auto kern, auto lds_map) -> int {

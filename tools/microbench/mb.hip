@@ -843,6 +843,12 @@ static void bench_multi() {
       const double pipe = time_it(true);
       printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "one launch, pipelined segments", pipe, ab / pipe * 1e-3);
     }
+    {  // every compute wave requests its share of the next slice itself (the mode of 15- / 16-wave layers) for every shape
+      aqlm_hip_set_tuning("packed_pipe", 2);
+      const double selfdma = time_it(true);
+      printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "pipelined, no DMA waves", selfdma, ab / selfdma * 1e-3);
+      aqlm_hip_set_tuning("packed_pipe", 1);
+    }
     // outputs of the pipelined launch vs separate launches (layer set 0)
     {
       std::vector<std::vector<uint16_t>> ref(nseg);
