@@ -1361,6 +1361,7 @@ struct PipeParams {
   const uint16_t* x;
   int in_groups, nseg, max_rg, nwc;  // nwc: compute waves of the workgroup
   int dma_waves;                     // PP_DMA_WAVES, or 0: every compute wave requests its share of the next slice itself
+  int defer;                         // DMA-wave mode: look at a segment's atomics one segment later (packed_pipe == 4 switches it off)
   PackedSegment seg[AQLM_HIP_MAX_SEGMENTS];
 };
 
@@ -1469,7 +1470,35 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
   }
   __builtin_amdgcn_s_waitcnt((PD & 15) | (7 << 4) | (0 << 8) | ((PD >> 4) << 14));  // vmcnt(PD): the fill, not the ring
   __builtin_amdgcn_s_barrier();                            // B0
+  // the first ring steps: waited for here, by the builtin, so that the segment loop is ENTERED with nothing pending -- hipcc's
+  // wait-count pass merges the entry state with the back edge's (a deferred atomic in flight) and would otherwise guard the
+  // first use of the ring with vmcnt(0) on every segment (it emitted this wait itself before; now it knows)
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
 
+  // A row's hand-shake (returning atomic) is looked at one segment LATER, behind the next segment's loop, so its round trip
+  // to the memory side is off the critical path (the compute waves wait for nothing else between segments; in the
+  // self-service mode the wait for the LDS-DMA is counted so that it leaves the atomic in flight).  Only when every thread
+  // has at most one row per segment.
+  const bool tuning_defer = mp.defer != 0;
+  bool defer_k = false;
+  bool pend = false;
+  unsigned long long pend_old = 0ull, pend_mine = 0ull;
+  unsigned long long* pend_cell = nullptr;
+  uint16_t* pend_y = nullptr;
+  uint16_t pend_scale = 0, pend_bias = 0;
+  int pend_sh = 0;
+  bool pend_has_bias = false;
+  auto settle_pending = [&]() {
+    if (pend && (pend_old & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
+      const unsigned long long cell = pend_old + pend_mine;
+      const long long sum = (long long)cell >> PK_VAL_SHIFT;
+      float sv = (float)ldexp((double)sum, -pend_sh);
+      if ((cell >> PK_CNT_BITS) & PK_CNT_MASK) sv = __builtin_nanf("");
+      *pend_y = T_::from_float(__builtin_fmaf(sv, T_::to_float(pend_scale), pend_has_bias ? T_::to_float(pend_bias) : 0.f));
+      __hip_atomic_store(pend_cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pend = false;
+  };
   for (int k = 0; k < mp.nseg; ++k) {
     const PackedSegment s = segment(k);
     const int RG1 = s.RG + 1;
@@ -1549,7 +1578,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     // every entry fetch of this wave has landed (the next segment's first steps were requested a loop ago): said with the
     // builtin on EVERY path, so that hipcc's wait-count pass knows no VGPR load is pending when the epilogue reuses the
     // ring's registers -- otherwise it guards that reuse with vmcnt(0), i.e. waits for the LDS-DMA issued just below
-    if constexpr (SELF_DMA) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // (both modes: the deferred atomic of the DMA-wave mode must be the only thing pending at the loop's back edge)
     if (self_dma && k + 1 < mp.nseg) {  // this wave's share of the next slice and row-start table (buffer (k + 1) & 1 is free: its
       const PackedSegment sn = segment(k + 1);  // last readers passed F_{k-1})
       dma_slice(sn, (k + 1) & 1, wave, NWC);
@@ -1565,6 +1594,9 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       const uint32_t rs_off = L.rs0 + (uint32_t)(k & 1) * L.rs_bytes;
       const uint32_t T = (uint32_t)s.T;
       const int row_begin = group * s.RG;
+      settle_pending();  // segment k - 1's rows: their atomics went out one loop ago
+      const bool defer = nrows <= NTC && k + 1 < mp.nseg && tuning_defer;
+      defer_k = defer;
       for (int r = tid; r < nrows; r += NTC) {
         uint32_t q0, q1;
         float v;
@@ -1614,23 +1646,30 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
         const long long qv = finite ? __float2ll_rn(ldexpf(v, sh)) : 0ll;
         const unsigned long long mine = ((unsigned long long)qv << PK_VAL_SHIFT) + (finite ? 1ull : 1ull + (1ull << PK_CNT_BITS));
         const int row = row_begin + r;
-        const unsigned long long old = __hip_atomic_fetch_add(s.acc + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
-          const unsigned long long cell = old + mine;
-          const long long sum = (long long)cell >> PK_VAL_SHIFT;
-          float sv = (float)ldexp((double)sum, -sh);
-          if ((cell >> PK_CNT_BITS) & PK_CNT_MASK) sv = __builtin_nanf("");
-          const float scale = T_::to_float(s.scales[row]);
-          const float bias = s.bias ? T_::to_float(s.bias[row]) : 0.f;
-          s.y[row] = T_::from_float(__builtin_fmaf(sv, scale, bias));
-          __hip_atomic_store(s.acc + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // the hand-shake goes out; it is looked at right away, or (defer, uniform) behind the next segment's loop.  The atomic
+        // returns straight into the carried variable: a copy of its result would make hipcc wait for it here.
+        pend_mine = mine;
+        pend_sh = sh;
+        pend_cell = s.acc + row;
+        pend_y = s.y + row;
+        pend_has_bias = s.bias != nullptr;
+        pend_old = __hip_atomic_fetch_add(pend_cell, pend_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_scale = s.scales[row];
+        pend_bias = (s.bias ? s.bias : s.scales)[row];
+        pend = true;
+        if (!defer) settle_pending();
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-    if (self_dma) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0): my share of slice k + 1 has landed
+    if (self_dma) {  // my share of slice k + 1 has landed.  With a deferred hand-shake the wave's atomic and its scale / bias loads
+      // are YOUNGER than the LDS-DMA (loads return in order): "at most 3 outstanding" then means the DMA is in, and the atomic
+      // may stay in flight through the next loop.  A wave without rows issued none of the three and has to wait for everything.
+      if (defer_k && (wave << 6) < nrows) __builtin_amdgcn_s_waitcnt(3 | (7 << 4) | (15 << 8));
+      else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+    }
     __builtin_amdgcn_s_barrier();                          // F_k
   }
+  settle_pending();
 }
 
 static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max_rg, int& nwc, int& dma_waves) {
@@ -2345,6 +2384,7 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
       pp.max_rg = prg;
       pp.nwc = nwc;
       pp.dma_waves = dmaw;
+      pp.defer = tuning().packed_pipe == 4 ? 0 : 1;
       for (int k = 0; k < num_segments; ++k) pp.seg[k] = mp.seg[k];
       const size_t lds = pipe_lds(prg).total;
       auto go = [&](auto kern) -> int {
