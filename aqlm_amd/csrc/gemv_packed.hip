@@ -171,14 +171,20 @@ static bool desc_layout(const aqlm_hip_packed_desc* d, PackedLayout& L) {
          L.used == d->used_bytes;
 }
 
-// Wave-steps of work in the longest stream -> waves per workgroup.  Large layers: 16 waves (measured: 13-15 waves with
-// fewer wasted tail steps are 10-18 % slower on the 14336-wide shapes -- parallelism beats bytes).  Small layers
-// (< 48 wave-steps per workgroup): the wave ranges have T = ceil(q / NW) steps each, so the capacity NW * T overshoots
-// the content by up to NW - 1 steps, a large share of such a layer: pick 4..8 waves with the least overshoot.
+// Wave-steps of work in the longest stream -> waves per workgroup.
+// Long streams (>= 13 steps per wave at 16 waves: the 28672-row / 28672-wide layers) are bound by the entry stream and want
+// every wave the CU can hold: 16 (8192 -> 28672 with 14 / 12 waves: 30.9 / 30.7 us against 25.1; r03_mb_packed_variants.log).
+// Mid-size layers are bound by the LDS and run as fast or faster on 14 waves (single-kernel regime, same box: 8192 -> 8192
+// 10.6 vs 10.9 us, 14336 -> 4096 10.3 vs 10.5, 4096 -> 14336 10.45 vs 10.55, 4096 -> 11008 9.10 vs 9.09) -- and 14 waves
+// leave room for the two DMA waves of the pipelined shared-input kernel, whose fill then hides completely (2 x 4096 ->
+// 14336 in one launch: 18.85 us packed for 14 waves, 19.75 for 16).  (Round 2's "13-15 waves are 10-18 % slower" was
+// measured with the two-kernel finalize and no longer holds.)  Small layers (< 48 wave-steps per workgroup): the wave
+// ranges have T = ceil(q / NW) steps each, so the capacity NW * T overshoots the content by up to NW - 1 steps, a large
+// share of such a layer: pick 4..8 waves with the least overshoot.
 static int choose_waves(uint32_t max_lane_steps) {
   const int q = (int)((max_lane_steps + 63) / 64);
   if (tuning().packed_waves >= 1 && tuning().packed_waves <= PK_MAX_NW) return tuning().packed_waves;
-  if (q >= 48) return 16;
+  if (q >= 48) return (q + 15) / 16 >= 13 ? 16 : 14;
   // ... and a step count that is a multiple of the ring depth (3): a remainder of one or two steps runs through the
   // kernel's tail code and leaves late requests behind (measured, profiles/r02_mb_wave_counts.log: 4096x4096 with
   // 6 waves x 6 steps 6.09 us, 7 x 5 6.23 us, 5 x 7 6.22 us; 8192->1024 with 6 x 3 = 7 x 3 5.23 us, 5 x 4 5.55 us)

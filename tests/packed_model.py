@@ -31,8 +31,8 @@ def align_up(v, a):
 
 def choose_waves(max_lane_steps):
     q = (max_lane_steps + 63) // 64  # wave-steps of work per workgroup
-    if q >= 48:
-        return 16
+    if q >= 48:  # long streams (entry-stream bound): 16 waves; mid-size layers: 14 (room for the pipelined kernel's DMA waves)
+        return 16 if (q + 15) // 16 >= 13 else 14
     best, best_cost = 8, 1 << 30
     for nw in range(8, 3, -1):
         t = (q + nw - 1) // nw

@@ -785,6 +785,7 @@ static void bench_multi() {
   CK(hipMalloc(&g_ws, g_ws_bytes));
   CK(hipMemset(g_ws, 0, g_ws_bytes));
   const Scheme s{"1x16g8P", 1, 16, 8, false, true};
+  if (const char* w = getenv("MB_WAVES")) { aqlm_hip_set_tuning("packed_waves", atoi(w)); printf("# layers packed for %d waves\n", atoi(w)); }
   struct Group { const char* name; int in; std::vector<int> outs; };
   const std::vector<Group> groups = {{"3 x 4096->4096", 4096, {4096, 4096, 4096}}, {"Llama-3-8B q/k/v", 4096, {4096, 1024, 1024}},
                                      {"Llama-3-8B gate/up", 4096, {14336, 14336}}, {"Llama-2-7B gate/up", 4096, {11008, 11008}},
