@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaqlm_hip.so")
+# AQLM_AMD_HIP_LIB: another build of the same library (same-box A/B runs of two commits, tools/gpu/r3_ab*.sh); default: in-tree
+LIB_PATH = os.environ.get("AQLM_AMD_HIP_LIB") or os.path.join(_HERE, "libaqlm_hip.so")
 ABI_VERSION = 4
 
 F16, BF16 = 0, 1
