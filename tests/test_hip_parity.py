@@ -1686,14 +1686,17 @@ def test_sharded_layer_repacks_when_its_codes_change(hk):
     assert torch.equal(ya, ya2)
 
 
-@pytest.mark.parametrize("outs,fin,dt", [
-    ((4096, 1024, 1024), 4096, "float16"),      # Llama-3-8B q / k / v: different wave and step counts per segment
-    ((14336, 14336), 4096, "float16"),          # gate / up: 16 waves each, 896-row groups
-    ((1024, 1024, 1024, 1024), 4096, "bfloat16"),
-    ((4096, 4096, 4096), 4096, "float16"),
-    ((1536, 2048), 8192, "float16"),            # 8192-wide input: x fills the window to 16400 of 16640 bytes
+@pytest.mark.parametrize("outs,fin,dt,waves", [
+    ((4096, 1024, 1024), 4096, "float16", 0),      # Llama-3-8B q / k / v: different wave and step counts per segment
+    ((14336, 14336), 4096, "float16", 0),          # gate / up: 14 waves each + 2 DMA waves, 896-row groups (LDS 163.6 of 163.8 KB)
+    ((14336, 14336), 4096, "float16", 16),         # the same packed for 16 waves: no DMA waves, every wave requests its share itself
+    ((12288, 12288), 8192, "float16", 0),          # 13 steps per wave at 16 waves: packed for 16 by the default rule (self-service mode)
+    ((1024, 1024, 1024, 1024), 4096, "bfloat16", 0),
+    ((4096, 4096, 4096), 4096, "float16", 0),
+    ((1536, 2048), 8192, "float16", 0),            # 8192-wide input: x fills the window to 16400 of 16640 bytes
+    ((11008, 4096, 1024), 4096, "bfloat16", 15),   # mixed sizes, 15 waves: self-service mode with waves that have no rows in a segment
 ])
-def test_pipelined_shared_input_launch(hk, outs, fin, dt):
+def test_pipelined_shared_input_launch(hk, outs, fin, dt, waves):
     """The pipelined shared-input kernel (one workgroup per CU walks the segments, codebook slices double-buffered, two DMA
     waves; gemv_1x16_packed_pipe_kernel): bit-identical to the per-segment kernel of the plain multi launch and to separate
     single-layer launches, repeatable (cells zero at rest), within tolerance of the oracle."""
@@ -1704,8 +1707,18 @@ def test_pipelined_shared_input_launch(hk, outs, fin, dt):
                          float_dtype=np.float16 if dt == "float16" else "bfloat16") for i, o in enumerate(outs)]
     Ts = [to_dev(L, dtype) for L in Ls]
     x = Ts[0]["x"]
-    packed = [hk.prepack_1x16(T["codes"], 8, codebooks=T["codebooks"]) for T in Ts]
+    _native.set_tuning("packed_waves", waves)
+    try:
+        packed = [hk.prepack_1x16(T["codes"], 8, codebooks=T["codebooks"]) for T in Ts]
+    finally:
+        _native.set_tuning("packed_waves", 0)
     assert all(p is not None for p in packed)
+    if waves:
+        assert all(p.desc.waves == waves for p in packed)
+    elif outs == (12288, 12288):
+        assert all(p.desc.waves == 16 for p in packed)
+    elif outs == (14336, 14336):
+        assert all(p.desc.waves == 14 for p in packed)
     args = (x, packed, [T["codebooks"] for T in Ts], [T["scales"] for T in Ts], [T["bias"] for T in Ts])
     singles = [hk.code1x16_matmat_packed(x, p, T["codebooks"], T["scales"], T["bias"]) for p, T in zip(packed, Ts)]
     _native.set_tuning("packed_pipe", 0)
