@@ -727,10 +727,11 @@ def code1x8_dequant(codes, codebooks, scales):
 # large-batch ops
 # ------------------------------------------------------------------------------------------------------
 # Rows (batch x sequence) up to which the large-batch 1x16 op runs the fused dequant->MFMA kernel.  The fused kernel
-# re-gathers the codebook entries for every slab of 128 rows (~30 us per slab at 4096x4096), whereas dequantising W once
-# costs 14 us and lets hipBLASLt run the GEMM at matrix-core speed: measured crossover between 128 and 256 rows
-# (DESIGN.md section 4.6), so long prefills take the dequant + GEMM route like the reference does (cuda_kernel.cpp:249-301).
-FUSED_MFMA_MAX_ROWS = 128
+# re-gathers the codebook entries for every slab of 128 rows (~21 us per slab at 4096x4096 since round 3), whereas
+# dequantising W once costs 14 us and lets hipBLASLt run the GEMM at matrix-core speed.  Measured (bench.py detail,
+# hipGraph, 4096x4096): 128 rows 23.3 vs 38.9 us, 256 rows 42.8 vs 54.1 us, 1024 rows 167 vs 72 us -- two slabs still win,
+# long prefills take the dequant + GEMM route like the reference does (cuda_kernel.cpp:249-301).
+FUSED_MFMA_MAX_ROWS = 256
 
 
 def _scale_bias_fp32(y, scales, bias):
