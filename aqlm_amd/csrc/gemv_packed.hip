@@ -1342,8 +1342,13 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const Pac
 //   operations per entry as the single-layer kernel -- plus the constant offset of buffer 0 in the ds_read.
 //   Waves: NWC compute waves (max over the segments' wave counts) + 2 DMA waves.  The compute waves' VMEM queue holds ring
 //   fetches and the returning atomics only (hipcc counts those); the DMA waves hold LDS-DMA only (waited with vmcnt(0)).
+//   Layers packed for 15 / 16 waves (SELF_DMA): no DMA waves; every compute wave requests its share of slice k + 1 when its
+//   own steps of segment k are done, and the epilogue reads its row tables through asm (hipcc guards every LDS read it sees
+//   with vmcnt(0) while LDS-DMA is in flight).
 //   Barriers per segment: M_k (loop k done -> epilogue k may read rowval / colend) and F_k (epilogue k done AND slice
 //   k + 1 landed).
+//   Hand-shake: segment k's returning atomic is looked at in epilogue k + 1 (settle_pending), i.e. behind loop k + 1 -- its
+//   round trip is off the critical path; the last segment settles at once.
 constexpr uint32_t PP_XWIN = 16640;                                 // x window: (in_groups + 1) * 16 <= PP_XWIN
 constexpr uint32_t PP_BUF0 = PP_XWIN;
 constexpr uint32_t PP_BOOK = PP_XWIN + 2u * PK_SLICE_BYTES;         // bookkeeping area
