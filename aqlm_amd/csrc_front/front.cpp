@@ -77,6 +77,8 @@ static void* stream_cells(const at::Tensor& like, void* stream, int64_t need_byt
   return it->second.data_ptr();
 }
 
+class FastGroup;
+
 class FastLinear {
  public:
   // params: the module's _parameters dict (codes, codebooks, scales, bias).  packed / desc_bytes: the prepacked buffer
@@ -155,6 +157,7 @@ class FastLinear {
   int kind() const { return kind_; }
 
  private:
+  friend class FastGroup;
   py::dict params_;
   int kind_;
   int64_t in_, out_;
@@ -168,12 +171,83 @@ class FastLinear {
   aqlm_hip_packed_desc desc_{};
 };
 
+// Shared-input launch of 2..AQLM_HIP_MAX_SEGMENTS prepacked members (q/k/v, gate/up; aqlm_amd/fusion.py): one check of x, one
+// allocation per output, ONE launch of aqlm_hip_gemv_1x16_packed_multi_cells -- the pipelined kernel where it applies.  The
+// parking of the siblings' outputs stays in Python (fusion.SharedInputGroup); this is only its launch.
+class FastGroup {
+ public:
+  explicit FastGroup(std::vector<std::shared_ptr<FastLinear>> members) : m_(std::move(members)) {
+    TORCH_CHECK(m_.size() >= 2 && m_.size() <= (size_t)AQLM_HIP_MAX_SEGMENTS, "FastGroup: 2..", AQLM_HIP_MAX_SEGMENTS, " members");
+    for (const auto& f : m_) {
+      TORCH_CHECK(f && f->kind_ == kPacked1x16, "FastGroup: prepacked 1x16 members only");
+      TORCH_CHECK(f->in_ == m_[0]->in_ && f->dtype_ == m_[0]->dtype_ && f->codebooks_.device() == m_[0]->codebooks_.device(),
+                  "FastGroup: members must agree on in_features, dtype and device");
+    }
+  }
+
+  // list of outputs (member order), or None when the call is not for this lane
+  py::object forward(const at::Tensor& x) {
+    FastLinear& a = *m_[0];
+    if (!x.is_cuda() || x.scalar_type() != a.codebooks_.scalar_type() || x.device() != a.codebooks_.device() || x.dim() < 1 ||
+        x.size(-1) != a.in_ || (x.requires_grad() && at::GradMode::is_enabled()))
+      return py::none();
+    const int64_t rows = a.in_ ? x.numel() / a.in_ : 0;
+    if (rows < 1 || rows > a.max_rows_) return py::none();
+    int64_t total = 0;
+    for (const auto& f : m_) {
+      if (!f->is_current()) return py::none();
+      total += f->out_;
+    }
+    at::Tensor x2 = x.reshape({rows, a.in_});
+    if (x2.stride(1) != 1 || (rows > 1 && x2.stride(0) % 8 != 0) || (reinterpret_cast<uintptr_t>(x2.data_ptr()) & 15u)) x2 = x2.contiguous();
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
+    void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream();
+    void* cells = stream_cells(x, stream, rows * total * 8);
+    if (!cells) return py::none();
+    const int n = (int)m_.size();
+    aqlm_hip_segment seg[AQLM_HIP_MAX_SEGMENTS];
+    const aqlm_hip_packed_desc* descs[AQLM_HIP_MAX_SEGMENTS];
+    std::vector<at::Tensor> ys;
+    ys.reserve(n);
+    for (int k = 0; k < n; ++k) {
+      FastLinear& f = *m_[k];
+      ys.push_back(at::empty({rows, f.out_}, x.options()));
+      seg[k].codes = f.packed_.data_ptr();
+      seg[k].codebook = f.codebooks_.data_ptr();
+      seg[k].scales = f.scales_.data_ptr();
+      seg[k].bias = f.bias_ ? f.bias_->data_ptr() : nullptr;
+      seg[k].y = ys[k].data_ptr();
+      seg[k].y_row_stride = f.out_;
+      seg[k].out_features = (int)f.out_;
+      seg[k].reserved = 0;
+      descs[k] = &f.desc_;
+    }
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = aqlm_hip_gemv_1x16_packed_multi_cells(seg, descs, n, x2.data_ptr(), (int)a.in_, (int)rows, x2.stride(0), a.dtype_, cells,
+                                                 (size_t)kCellsBytes, stream);
+    }
+    if (rc != 0) return py::none();
+    py::list out;
+    std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
+    for (int k = 0; k < n; ++k) {
+      shape.back() = m_[k]->out_;
+      out.append(py::cast(ys[k].view(shape)));
+    }
+    return std::move(out);
+  }
+
+ private:
+  std::vector<std::shared_ptr<FastLinear>> m_;
+};
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled host glue of aqlm_amd's decode path (see aqlm_amd/csrc_front/front.cpp)";
   m.attr("ABI_VERSION") = AQLM_HIP_ABI_VERSION;
-  py::class_<FastLinear>(m, "FastLinear")
+  py::class_<FastLinear, std::shared_ptr<FastLinear>>(m, "FastLinear")
       .def(py::init<py::dict, int, c10::optional<at::Tensor>, std::string, int64_t, int64_t, int64_t, int64_t, bool, int64_t>(), py::arg("params"),
            py::arg("kind"), py::arg("packed"), py::arg("desc_bytes"), py::arg("in_features"), py::arg("out_features"),
            py::arg("num_codebooks"), py::arg("in_group_size"), py::arg("watch_codes"), py::arg("max_rows"))
@@ -181,4 +255,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("forward", &FastLinear::forward)
       .def("__call__", &FastLinear::forward)
       .def_property_readonly("kind", &FastLinear::kind);
+  py::class_<FastGroup>(m, "FastGroup")
+      .def(py::init<std::vector<std::shared_ptr<FastLinear>>>(), py::arg("members"))
+      .def("forward", &FastGroup::forward)
+      .def("__call__", &FastGroup::forward);
 }

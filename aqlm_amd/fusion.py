@@ -60,6 +60,8 @@ class SharedInputGroup:
         self._pending: Dict[int, torch.Tensor] = {}
         self.launches = 0  # statistics: fused launches issued / outputs served from a previous launch
         self.served = 0
+        self._fast_group = None      # compiled launch of the group (csrc_front FastGroup), valid for exactly these lanes:
+        self._fast_group_of = None   # ids of the members' FastLinear objects it was built from
 
     def applicable(self, input: torch.Tensor) -> bool:
         if not input.is_cuda or math.prod(input.shape[:-1]) > GEMV_MAX_ROWS:
@@ -82,6 +84,22 @@ class SharedInputGroup:
         self.launches += 1
         return outs[idx]
 
+    def _compiled_group(self):
+        from . import _front
+
+        lanes = [m._fast for m in self.members]
+        if any(f is None for f in lanes) or not _front.available():
+            return None
+        key = tuple(id(f) for f in lanes)
+        if self._fast_group_of != key:
+            self._fast_group, self._fast_group_of = None, key
+            if all(f.kind == _front.KIND_PACKED_1X16 for f in lanes) and hasattr(_front.ext, "FastGroup"):
+                try:
+                    self._fast_group = _front.ext.FastGroup(lanes)
+                except RuntimeError:
+                    self._fast_group = None
+        return self._fast_group
+
     def _launch(self, input: torch.Tensor) -> List[torch.Tensor]:
         from .inference_kernels import hip_kernel
 
@@ -89,6 +107,13 @@ class SharedInputGroup:
         for m in ms:
             if m.gemv_op is None or m._derived_state_is_stale():
                 m.prepare_matmul_op(input)
+        # all members prepacked and served by a compiled lane: check x once, allocate, ONE launch, without the interpreter
+        # (an eager q/k/v call through the Python path below costs ~35 us of host time, as much as three separate calls)
+        fg = self._compiled_group()
+        if fg is not None:
+            res = fg(input)  # None: not a call for the lane (a parameter changed, rows, dtype, ...) -> Python path
+            if res is not None:
+                return list(res)
         # every member runs on the kernel it would use alone (so outputs stay bit-identical to the unfused modules):
         # prepacked members share one packed launch, the others one direct launch
         packed_idx = [i for i, m in enumerate(ms) if m._packed_codes is not None and input.dtype == m.codebooks.dtype]

@@ -1154,6 +1154,9 @@ def test_fused_shared_input_modules_match_unfused(hk):
                 assert torch.isfinite(ref).all()
                 assert torch.equal(out, ref) and torch.equal(q0, q1) and torch.equal(k0, k1) and torch.equal(v0, v1)
                 assert [(g.launches, g.served) for g in groups] == [(1, 2), (1, 1)]
+                from aqlm_amd import _front
+                if _front.available():  # gate / up are prepacked: their launch is the compiled one (csrc_front FastGroup)
+                    assert groups[1]._fast_group is not None and groups[0]._fast_group is None
                 assert all(g._input is None and not g._pending for g in groups)  # nothing kept alive
                 # a different tensor object (even with equal values) is a new launch; a repeated call too
                 out2, _ = block(h.clone())
@@ -1178,6 +1181,46 @@ def test_fused_shared_input_modules_match_unfused(hk):
         assert xg.grad is not None and groups[0].launches == 0
     finally:
         inf.PREPACK_MIN_CODES = old
+
+
+def test_compiled_group_launch_equals_separate_modules(hk):
+    """q / k / v of Llama-3-8B size through the compiled group launch (front.cpp FastGroup -> the pipelined kernel): the
+    outputs are those of the unfused modules, bit for bit; a parameter written in place sends the call back to the Python
+    path, which rebuilds the lanes; 7 rows bypass the group."""
+    import aqlm
+    from aqlm_amd import _front
+
+    if not _front.available():
+        pytest.skip("aqlm_amd/_aqlm_front.so not built")
+    fin = 4096
+    mods = {}
+    for k, (n, fo) in enumerate((("q_proj", 4096), ("k_proj", 1024), ("v_proj", 1024))):
+        L = orc.make_layer(1300 + k, fin, fo, 1, 16, 8, batch=3, bias=(k == 1))
+        mods[n], T = _module_from(L, 1, 16, 8, fin, fo, torch.float16)
+        if k == 0:
+            x = T["x"]
+    with torch.no_grad():
+        ref = {n: m(x) for n, m in mods.items()}          # unfused (each through its own compiled lane)
+        holder = torch.nn.Module()
+        for n, m in mods.items():
+            setattr(holder, n, m)
+        groups = aqlm.fuse_shared_input_linears(holder)
+        assert len(groups) == 1 and len(groups[0].members) == 3
+        for rows in (1, 3):
+            h = x[:rows].clone()
+            out = {n: m(h) for n, m in mods.items()}
+            assert groups[0]._fast_group is not None
+            for n in mods:
+                assert torch.equal(out[n], ref[n][:rows]), n
+        assert groups[0].launches == 2 and groups[0].served == 4
+        # an in-place update of one member's scales: the lanes notice, the Python path rebuilds them, results follow
+        mods["k_proj"].scales.mul_(2.0)
+        h = x[:1].clone()
+        out = {n: m(h) for n, m in mods.items()}
+        assert torch.equal(out["q_proj"], ref["q_proj"][:1])
+        assert torch.equal(out["k_proj"], mods["k_proj"].__class__.forward(mods["k_proj"], h.clone()))
+        assert not torch.equal(out["k_proj"], ref["k_proj"][:1])
+        aqlm.unfuse_shared_input_linears(holder)
 
 
 def test_fused_group_inside_hipgraph(hk):
