@@ -171,17 +171,19 @@ class FastLinear {
   aqlm_hip_packed_desc desc_{};
 };
 
-// Shared-input launch of 2..AQLM_HIP_MAX_SEGMENTS prepacked members (q/k/v, gate/up; aqlm_amd/fusion.py): one check of x, one
-// allocation per output, ONE launch of aqlm_hip_gemv_1x16_packed_multi_cells -- the pipelined kernel where it applies.  The
+// Shared-input launch of 2..AQLM_HIP_MAX_SEGMENTS members of one kind (q/k/v, gate/up; aqlm_amd/fusion.py): one check of x, one
+// allocation per output, ONE launch of the kind's multi entry -- aqlm_hip_gemv_1x16_packed_multi_cells (the pipelined kernel
+// where it applies), aqlm_hip_gemv_1x16_multi or aqlm_hip_gemv_kx8_multi.  The
 // parking of the siblings' outputs stays in Python (fusion.SharedInputGroup); this is only its launch.
 class FastGroup {
  public:
   explicit FastGroup(std::vector<std::shared_ptr<FastLinear>> members) : m_(std::move(members)) {
     TORCH_CHECK(m_.size() >= 2 && m_.size() <= (size_t)AQLM_HIP_MAX_SEGMENTS, "FastGroup: 2..", AQLM_HIP_MAX_SEGMENTS, " members");
     for (const auto& f : m_) {
-      TORCH_CHECK(f && f->kind_ == kPacked1x16, "FastGroup: prepacked 1x16 members only");
-      TORCH_CHECK(f->in_ == m_[0]->in_ && f->dtype_ == m_[0]->dtype_ && f->codebooks_.device() == m_[0]->codebooks_.device(),
-                  "FastGroup: members must agree on in_features, dtype and device");
+      TORCH_CHECK(f && f->kind_ == m_[0]->kind_, "FastGroup: members of one kind (prepacked 1x16, direct 1x16 or K x 8)");
+      TORCH_CHECK(f->in_ == m_[0]->in_ && f->dtype_ == m_[0]->dtype_ && f->codebooks_.device() == m_[0]->codebooks_.device() &&
+                      f->K_ == m_[0]->K_ && f->g_ == m_[0]->g_,
+                  "FastGroup: members must agree on in_features, scheme, dtype and device");
     }
   }
 
@@ -202,8 +204,8 @@ class FastGroup {
     if (x2.stride(1) != 1 || (rows > 1 && x2.stride(0) % 8 != 0) || (reinterpret_cast<uintptr_t>(x2.data_ptr()) & 15u)) x2 = x2.contiguous();
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
     void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream();
-    void* cells = stream_cells(x, stream, rows * total * 8);
-    if (!cells) return py::none();
+    void* cells = a.kind_ == kPacked1x16 ? stream_cells(x, stream, rows * total * 8) : nullptr;
+    if (a.kind_ == kPacked1x16 && !cells) return py::none();
     const int n = (int)m_.size();
     aqlm_hip_segment seg[AQLM_HIP_MAX_SEGMENTS];
     const aqlm_hip_packed_desc* descs[AQLM_HIP_MAX_SEGMENTS];
@@ -212,7 +214,7 @@ class FastGroup {
     for (int k = 0; k < n; ++k) {
       FastLinear& f = *m_[k];
       ys.push_back(at::empty({rows, f.out_}, x.options()));
-      seg[k].codes = f.packed_.data_ptr();
+      seg[k].codes = a.kind_ == kPacked1x16 ? f.packed_.data_ptr() : f.codes_.data_ptr();
       seg[k].codebook = f.codebooks_.data_ptr();
       seg[k].scales = f.scales_.data_ptr();
       seg[k].bias = f.bias_ ? f.bias_->data_ptr() : nullptr;
@@ -225,8 +227,13 @@ class FastGroup {
     int rc;
     {
       py::gil_scoped_release nogil;
-      rc = aqlm_hip_gemv_1x16_packed_multi_cells(seg, descs, n, x2.data_ptr(), (int)a.in_, (int)rows, x2.stride(0), a.dtype_, cells,
-                                                 (size_t)kCellsBytes, stream);
+      if (a.kind_ == kPacked1x16)
+        rc = aqlm_hip_gemv_1x16_packed_multi_cells(seg, descs, n, x2.data_ptr(), (int)a.in_, (int)rows, x2.stride(0), a.dtype_, cells,
+                                                   (size_t)kCellsBytes, stream);
+      else if (a.kind_ == kGemv1x16)
+        rc = aqlm_hip_gemv_1x16_multi(seg, n, x2.data_ptr(), (int)a.in_, a.g_, (int)rows, x2.stride(0), a.dtype_, stream);
+      else
+        rc = aqlm_hip_gemv_kx8_multi(seg, n, x2.data_ptr(), (int)a.in_, a.K_, a.g_, (int)rows, x2.stride(0), a.dtype_, stream);
     }
     if (rc != 0) return py::none();
     py::list out;

@@ -93,7 +93,7 @@ class SharedInputGroup:
         key = tuple(id(f) for f in lanes)
         if self._fast_group_of != key:
             self._fast_group, self._fast_group_of = None, key
-            if all(f.kind == _front.KIND_PACKED_1X16 for f in lanes) and hasattr(_front.ext, "FastGroup"):
+            if all(f.kind == lanes[0].kind for f in lanes) and hasattr(_front.ext, "FastGroup"):
                 try:
                     self._fast_group = _front.ext.FastGroup(lanes)
                 except RuntimeError:
@@ -107,7 +107,8 @@ class SharedInputGroup:
         for m in ms:
             if m.gemv_op is None or m._derived_state_is_stale():
                 m.prepare_matmul_op(input)
-        # all members prepacked and served by a compiled lane: check x once, allocate, ONE launch, without the interpreter
+        # all members served by compiled lanes of one kind (prepacked / direct 1x16, K x 8): check x once, allocate, ONE launch,
+        # without the interpreter
         # (an eager q/k/v call through the Python path below costs ~35 us of host time, as much as three separate calls)
         fg = self._compiled_group()
         if fg is not None:

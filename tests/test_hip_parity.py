@@ -1155,8 +1155,8 @@ def test_fused_shared_input_modules_match_unfused(hk):
                 assert torch.equal(out, ref) and torch.equal(q0, q1) and torch.equal(k0, k1) and torch.equal(v0, v1)
                 assert [(g.launches, g.served) for g in groups] == [(1, 2), (1, 1)]
                 from aqlm_amd import _front
-                if _front.available():  # gate / up are prepacked: their launch is the compiled one (csrc_front FastGroup)
-                    assert groups[1]._fast_group is not None and groups[0]._fast_group is None
+                if _front.available():  # both groups launch through the compiled front end (csrc_front FastGroup): gate / up on
+                    assert groups[1]._fast_group is not None and groups[0]._fast_group is not None  # the prepacked, q / k / v on the direct entry
                 assert all(g._input is None and not g._pending for g in groups)  # nothing kept alive
                 # a different tensor object (even with equal values) is a new launch; a repeated call too
                 out2, _ = block(h.clone())
