@@ -1384,7 +1384,10 @@ __device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_vgpr, uint3
 
 template <class T_, bool SELF_DMA>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeParams mp) {
-  constexpr int PD = 3;
+#ifndef AQLM_PP_PD
+#define AQLM_PP_PD 3
+#endif
+  constexpr int PD = AQLM_PP_PD;  // entry steps in flight per wave (and requested ahead for the next segment)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();
   const int tid = threadIdx.x, lane = tid & 63;
