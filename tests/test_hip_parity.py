@@ -1183,6 +1183,45 @@ def test_fused_shared_input_modules_match_unfused(hk):
         inf.PREPACK_MIN_CODES = old
 
 
+def test_pipelined_launch_randomized(hk):
+    """Seeded random shared-input groups (2..4 segments, mixed sizes, forced wave counts 3..16 -> both DMA modes, deferred and
+    immediate hand-shakes, waves without rows) through the pipelined kernel: every output bit-identical to the segment's own
+    single-layer launch, repeatedly (accumulator cells zero at rest).  AQLM_TEST_PIPE_CASES raises the case count."""
+    import os
+    import random
+
+    from aqlm_amd import _native
+
+    rng = random.Random(20260924)
+    ncases = int(os.environ.get("AQLM_TEST_PIPE_CASES", "20"))
+    for case in range(ncases):
+        fin = rng.choice([512, 1024, 2048, 4096, 4096, 8192])
+        nseg = rng.randint(2, 4)
+        outs = [rng.choice([64, 200, 512, 1024, 1536, 2048, 4096, 6000, 11008]) for _ in range(nseg)]
+        waves = rng.choice([0, 0, 0, 3, 6, 9, 13, 14, 15, 16])
+        dt = rng.choice(["float16", "float16", "bfloat16"])
+        dtype = tdtype(dt)
+        Ls = [orc.make_layer(5000 + 17 * case + i, fin, o, 1, 16, 8, batch=1, bias=bool((case + i) % 2),
+                             float_dtype=np.float16 if dt == "float16" else "bfloat16") for i, o in enumerate(outs)]
+        Ts = [to_dev(L, dtype) for L in Ls]
+        x = Ts[0]["x"]
+        _native.set_tuning("packed_waves", waves)
+        try:
+            packed = [hk.prepack_1x16(T["codes"], 8, codebooks=T["codebooks"]) for T in Ts]
+        finally:
+            _native.set_tuning("packed_waves", 0)
+        if any(p is None for p in packed):
+            continue
+        args = (x, packed, [T["codebooks"] for T in Ts], [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+        singles = [hk.code1x16_matmat_packed(x, p, T["codebooks"], T["scales"], T["bias"]) for p, T in zip(packed, Ts)]
+        for rep in range(3):
+            piped = hk.code1x16_matmat_packed_multi(*args)
+            for k in range(nseg):
+                assert torch.equal(piped[k], singles[k]), f"case {case}: fin {fin} outs {outs} waves {waves} {dt}, segment {k}, repeat {rep}"
+        del Ls, Ts, packed, singles, piped
+    torch.cuda.synchronize()
+
+
 def test_compiled_group_launch_equals_separate_modules(hk):
     """q / k / v of Llama-3-8B size through the compiled group launch (front.cpp FastGroup -> the pipelined kernel): the
     outputs are those of the unfused modules, bit for bit; a parameter written in place sends the call back to the Python
