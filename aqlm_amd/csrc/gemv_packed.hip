@@ -1438,18 +1438,20 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
   const int NWB = NWC + mp.dma_waves;
   dma_slice(s0, 0, wave, NWB);
   {
-    const int nchunk = (mp.in_groups + 63) >> 6;
+    const int x16 = mp.in_groups * (int)(PK_VB / 16);  // 16-byte units of x
+    const int nchunk = (x16 + 63) >> 6;
     for (int c = wave; c < nchunk; c += NWB) {
       const int idx = c * 64 + lane;
-      if (idx < mp.in_groups)
+      if (idx < x16)
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(mp.x + (size_t)idx * 8), (lds_void_ptr)(size_t)((uint32_t)c * 1024u), 16, 0, 0);
     }
   }
   dma_rowstart(s0, 0, wave, NWB);
-  if (tid == 0) *reinterpret_cast<u32x4*>(smem_raw + (uint32_t)mp.in_groups * 16u) = u32x4{0u, 0u, 0u, 0u};  // the null entries' x
+  if (tid < (int)(PK_VB / 16))  // the null entries' x
+    *reinterpret_cast<u32x4*>(smem_raw + (uint32_t)mp.in_groups * PK_VB + (uint32_t)tid * 16u) = u32x4{0u, 0u, 0u, 0u};
   if (tid < PK_MAX_NW) *reinterpret_cast<uint32_t*>(smem_raw + L.xmax + (uint32_t)tid * 4u) = 0u;
 
-  uint32_t mask = 0xfff0u;
+  uint32_t mask = PK_HMASK;
   asm volatile("" : "+v"(mask));  // SDWA operand in a VGPR
 
   if (dma_wave) {
@@ -1547,14 +1549,19 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
         a_cb[j] = and_or(w[j], mask, bufsel);
         a_x[j] = half_and<1>(w[j], mask);
       }
-      u32x4 ev[4], xv[4];
+      constexpr int NV = (int)(PK_VB / 16);  // 16-byte reads per vector (2: second half at offset ^ 16, see PK_PARITY_BITS)
+      u32x4 ev[4][NV], xv[4][NV];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ev[j] = *(lds_u32x4_ptr)(size_t)(a_cb[j] + PP_BUF0);
-        xv[j] = *(lds_u32x4_ptr)(size_t)(a_x[j]);
-      }
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = dot8<T_>(ev[j], xv[j], acc);
+        for (int h = 0; h < NV; ++h) {
+          ev[j][h] = *(lds_u32x4_ptr)(size_t)((a_cb[j] ^ ((uint32_t)h * 16u)) + PP_BUF0);
+          xv[j][h] = *(lds_u32x4_ptr)(size_t)(a_x[j] ^ ((uint32_t)h * 16u));
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < NV; ++h) acc = dot8<T_>(ev[j][h], xv[j][h], acc);
       if (e.x & 1u) {  // a row ends here: unique writer
         lds_store_f32(row_addr, acc);
         acc = 0.f;
@@ -1579,7 +1586,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     if (k == 0) {  // largest |x| (every segment multiplies the same x): per-wave maxima, once
       typedef unsigned short us2 __attribute__((ext_vector_type(2)));
       us2 m = {0, 0};
-      for (int idx = tid; idx < mp.in_groups; idx += NTC) {
+      for (int idx = tid; idx < mp.in_groups * (int)(PK_VB / 16); idx += NTC) {
         const u32x4 v = *(lds_u32x4_ptr)(size_t)((uint32_t)idx * 16u);
         const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1652,7 +1659,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
             xm = d > xm ? d : xm;
           }
         }
-        const float bound = (float)mp.in_groups * 8.f * s.cb_absmax * T_::to_float((uint16_t)xm);
+        const float bound = (float)mp.in_groups * (float)PK_G * s.cb_absmax * T_::to_float((uint16_t)xm);
         int e = 0;
         (void)frexpf(bound, &e);
         const bool finite = bound < __builtin_inff() && fabsf(v) <= 2.f * bound;
@@ -1694,7 +1701,7 @@ static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max
     max_rg = std::max(max_rg, Ls[k].RG);
     nwc = std::max(nwc, Ls[k].NW);
   }
-  if (PK_S_LOG != 4 || PK_G != 8 || n < 2 || nwc > PK_MAX_NW || (uint32_t)(in_groups + 1) * 16u > PP_XWIN) return false;
+  if (PK_SLICE_BYTES != 65536u || PK_NST != 256 || n < 2 || nwc > PK_MAX_NW || (uint32_t)(in_groups + 1) * PK_VB > PP_XWIN) return false;
   dma_waves = nwc + PP_DMA_WAVES <= PK_MAX_NW ? PP_DMA_WAVES : 0;
   if (tuning().packed_pipe == 2) dma_waves = 0;  // experiments: self-service DMA for every shape
   if (tuning().packed_pipe == 3 && dma_waves == 0) return false;  // experiments: round-3 first cut (DMA waves only)

@@ -1200,14 +1200,15 @@ def test_pipelined_launch_randomized(hk):
         outs = [rng.choice([64, 200, 512, 1024, 1536, 2048, 4096, 6000, 11008]) for _ in range(nseg)]
         waves = rng.choice([0, 0, 0, 3, 6, 9, 13, 14, 15, 16])
         dt = rng.choice(["float16", "float16", "bfloat16"])
+        g = rng.choice([8, 8, 16])  # 16-element codebook vectors: the second build of the same kernel
         dtype = tdtype(dt)
-        Ls = [orc.make_layer(5000 + 17 * case + i, fin, o, 1, 16, 8, batch=1, bias=bool((case + i) % 2),
+        Ls = [orc.make_layer(5000 + 17 * case + i, fin, o, 1, 16, g, batch=1, bias=bool((case + i) % 2),
                              float_dtype=np.float16 if dt == "float16" else "bfloat16") for i, o in enumerate(outs)]
         Ts = [to_dev(L, dtype) for L in Ls]
         x = Ts[0]["x"]
         _native.set_tuning("packed_waves", waves)
         try:
-            packed = [hk.prepack_1x16(T["codes"], 8, codebooks=T["codebooks"]) for T in Ts]
+            packed = [hk.prepack_1x16(T["codes"], g, codebooks=T["codebooks"]) for T in Ts]
         finally:
             _native.set_tuning("packed_waves", 0)
         if any(p is None for p in packed):
@@ -1217,7 +1218,7 @@ def test_pipelined_launch_randomized(hk):
         for rep in range(3):
             piped = hk.code1x16_matmat_packed_multi(*args)
             for k in range(nseg):
-                assert torch.equal(piped[k], singles[k]), f"case {case}: fin {fin} outs {outs} waves {waves} {dt}, segment {k}, repeat {rep}"
+                assert torch.equal(piped[k], singles[k]), f"case {case}: fin {fin} g {g} outs {outs} waves {waves} {dt}, segment {k}, repeat {rep}"
         del Ls, Ts, packed, singles, piped
     torch.cuda.synchronize()
 
