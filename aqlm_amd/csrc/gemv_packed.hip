@@ -1349,21 +1349,26 @@ __global__ __launch_bounds__(256) void gemv_1x16_packed_finalize_multi(const Pac
 //   k + 1 landed).
 //   Hand-shake: segment k's returning atomic is looked at in epilogue k + 1 (settle_pending), i.e. behind loop k + 1 -- its
 //   round trip is off the critical path; the last segment settles at once.
-constexpr uint32_t PP_XWIN = 16640;                                 // x window: (in_groups + 1) * 16 <= PP_XWIN
-constexpr uint32_t PP_BUF0 = PP_XWIN;
-constexpr uint32_t PP_BOOK = PP_XWIN + 2u * PK_SLICE_BYTES;         // bookkeeping area
+constexpr uint32_t PP_XWIN = 16640;        // x window: (in_groups + 1) * vector bytes <= the window (inputs of <= 8192 features) ...
+constexpr uint32_t PP_XWIN_SMALL = 8448;   // ... or <= 4096 features: 8 KiB more for the tables (template parameter XW of the kernel)
 constexpr int PP_DMA_WAVES = 2;
 
+// Bookkeeping behind the two slice buffers.  Two barriers per segment (M_k, F_k): row starts double-buffered, one set of row
+// sums.  ONE barrier (ONEB): the compute waves go from epilogue k straight into loop k + 1, so row sums / column ends are
+// double-buffered (loop k + 1 writes the other set) and the row starts triple-buffered (the DMA waves request segment
+// k + 2's while epilogue k may still read segment k's).
 struct PipeLds {
-  uint32_t rs0, rs_bytes, rowval, colend, xmax, total;  // row starts of buffer b at rs0 + b * rs_bytes
+  uint32_t rs0, rs_bytes, rowval, rowval_bytes, colend, colend_bytes, xmax, total;  // row starts of buffer b at rs0 + b * rs_bytes, ...
 };
-__host__ __device__ static inline PipeLds pipe_lds(int max_rg) {
+__host__ __device__ static inline PipeLds pipe_lds(int max_rg, uint32_t xwin, bool oneb) {
   PipeLds l;
-  l.rs_bytes = ((uint32_t)(max_rg + 1) * 4u + 1023u) & ~1023u;
-  l.rs0 = PP_BOOK;
-  l.rowval = l.rs0 + 2u * l.rs_bytes;
-  l.colend = l.rowval + (((uint32_t)(max_rg + 1) * 4u + 15u) & ~15u);
-  l.xmax = l.colend + (uint32_t)PK_MAX_NW * 64u * 4u;
+  l.rs_bytes = oneb ? (((uint32_t)(max_rg + 1) * 4u + 255u) & ~255u) : (((uint32_t)(max_rg + 1) * 4u + 1023u) & ~1023u);
+  l.rs0 = xwin + 2u * PK_SLICE_BYTES;
+  l.rowval = l.rs0 + (oneb ? 3u : 2u) * l.rs_bytes;
+  l.rowval_bytes = ((uint32_t)(max_rg + 1) * 4u + 15u) & ~15u;
+  l.colend = l.rowval + (oneb ? 2u : 1u) * l.rowval_bytes;
+  l.colend_bytes = (uint32_t)PK_MAX_NW * 64u * 4u;
+  l.xmax = l.colend + (oneb ? 2u : 1u) * l.colend_bytes;
   l.total = l.xmax + (uint32_t)PK_MAX_NW * 4u;
   return l;
 }
@@ -1382,8 +1387,10 @@ __device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_vgpr, uint3
   return d;
 }
 
-template <class T_, bool SELF_DMA>
+template <class T_, bool SELF_DMA, uint32_t XW, bool ONEB>
 __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeParams mp) {
+  static_assert(!(SELF_DMA && ONEB), "the single-barrier form needs the DMA waves");
+  constexpr uint32_t PP_BUF0 = XW;
 #ifndef AQLM_PP_PD
 #define AQLM_PP_PD 3
 #endif
@@ -1402,7 +1409,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
   const int dw = wave - NWC;  // 0 / 1 for the DMA waves
   const int block = (int)blockIdx.x;
   const int slice = block & (PK_S - 1), group = block >> PK_S_LOG;
-  const PipeLds L = pipe_lds(mp.max_rg);
+  const PipeLds L = pipe_lds(mp.max_rg, XW, ONEB);
   const int NTC = NWC << 6;  // compute threads
 
   // scalar select of a segment's parameters (no dynamic indexing of the kernel-argument struct)
@@ -1423,13 +1430,14 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
                                        (lds_void_ptr)(size_t)(PP_BUF0 + (uint32_t)buf * PK_SLICE_BYTES + (uint32_t)i * 1024u), 16, 0, 0);
     }
   };
+  auto rs_buf = [](int k) -> int { return ONEB ? k % 3 : (k & 1); };  // row-start buffer of segment k
   auto dma_rowstart = [&](const PackedSegment& s, int buf, int first, int stride) {
     const int RG1 = s.RG + 1;
     const uint32_t* rs_src = s.rowstart + (size_t)block * RG1;
     for (int i = first; i * 64 < RG1; i += stride) {
       const int idx = i * 64 + lane;
       if (idx < RG1)
-        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rs_src + idx), (lds_void_ptr)(size_t)(L.rs0 + (uint32_t)buf * L.rs_bytes + (uint32_t)i * 256u), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rs_src + idx), (lds_void_ptr)(size_t)(L.rs0 + (uint32_t)buf * L.rs_bytes + (uint32_t)i * 256u), 4, 0, 0);  // buf: rs_buf(segment)
     }
   };
 
@@ -1446,7 +1454,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(mp.x + (size_t)idx * 8), (lds_void_ptr)(size_t)((uint32_t)c * 1024u), 16, 0, 0);
     }
   }
-  dma_rowstart(s0, 0, wave, NWB);
+  dma_rowstart(s0, rs_buf(0), wave, NWB);
   if (tid < (int)(PK_VB / 16))  // the null entries' x
     *reinterpret_cast<u32x4*>(smem_raw + (uint32_t)mp.in_groups * PK_VB + (uint32_t)tid * 16u) = u32x4{0u, 0u, 0u, 0u};
   if (tid < PK_MAX_NW) *reinterpret_cast<uint32_t*>(smem_raw + L.xmax + (uint32_t)tid * 4u) = 0u;
@@ -1462,11 +1470,16 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       if (k + 1 < mp.nseg) {
         const PackedSegment sn = segment(k + 1);
         dma_slice(sn, (k + 1) & 1, dw, PP_DMA_WAVES);
-        dma_rowstart(sn, (k + 1) & 1, dw, PP_DMA_WAVES);
+        dma_rowstart(sn, rs_buf(k + 1), dw, PP_DMA_WAVES);
       }
-      __builtin_amdgcn_s_barrier();                        // M_k
-      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));
-      __builtin_amdgcn_s_barrier();                        // F_k: slice k + 1 is in LDS
+      if constexpr (ONEB) {
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));  // slice k + 1 is in LDS when the compute waves leave M_k
+        __builtin_amdgcn_s_barrier();                        // M_k
+      } else {
+        __builtin_amdgcn_s_barrier();                        // M_k
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));
+        __builtin_amdgcn_s_barrier();                        // F_k: slice k + 1 is in LDS
+      }
     }
     return;
   }
@@ -1522,6 +1535,8 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     nrows = nrows < 0 ? 0 : (nrows < s.RG ? nrows : s.RG);
     const int steps = wave < s.NW ? s.T : 0;
     const uint32_t bufsel = (uint32_t)(k & 1) << 16;
+    const uint32_t rowval_k = L.rowval + (ONEB ? (uint32_t)(k & 1) * L.rowval_bytes : 0u);  // this segment's row sums / column ends
+    const uint32_t colend_k = L.colend + (ONEB ? (uint32_t)(k & 1) * L.colend_bytes : 0u);
     const uint32_t wbase = (uint32_t)(((size_t)block * s.NW + (wave < s.NW ? wave : s.NW - 1)) * s.T) * 1024u;
     const int Tm1 = steps > 0 ? s.T - 1 : -1;
     // the first steps of the NEXT segment's entry stream are requested now: by the time the epilogue below waits for its
@@ -1569,7 +1584,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       }
     };
     if (steps > 0) {
-      row_addr = L.rowval + pk_get_start_row(ring[0].x, ring[0].y, ring[0].z, ring[0].w) * 4u;
+      row_addr = rowval_k + pk_get_start_row(ring[0].x, ring[0].y, ring[0].z, ring[0].w) * 4u;
       int t = 0;
       for (; t + PD <= steps; t += PD) {
 #pragma unroll
@@ -1595,7 +1610,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       const uint32_t mm = wave_max_u32(m.x > m.y ? (uint32_t)m.x : (uint32_t)m.y);
       if (lane == 0) *reinterpret_cast<uint32_t*>(smem_raw + L.xmax + (uint32_t)wave * 4u) = mm;
     }
-    if (wave < s.NW) lds_store_f32(L.colend + (uint32_t)(wave * 64 + lane) * 4u, acc);
+    if (wave < s.NW) lds_store_f32(colend_k + (uint32_t)(wave * 64 + lane) * 4u, acc);
     // every entry fetch of this wave has landed (the next segment's first steps were requested a loop ago): said with the
     // builtin on EVERY path, so that hipcc's wait-count pass knows no VGPR load is pending when the epilogue reuses the
     // ring's registers -- otherwise it guards that reuse with vmcnt(0), i.e. waits for the LDS-DMA issued just below
@@ -1603,7 +1618,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     if (self_dma && k + 1 < mp.nseg) {  // this wave's share of the next slice and row-start table (buffer (k + 1) & 1 is free: its
       const PackedSegment sn = segment(k + 1);  // last readers passed F_{k-1})
       dma_slice(sn, (k + 1) & 1, wave, NWC);
-      dma_rowstart(sn, (k + 1) & 1, wave, NWC);
+      dma_rowstart(sn, rs_buf(k + 1), wave, NWC);
     }
     rs_ent = rs_next;
 #pragma unroll
@@ -1612,7 +1627,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     __builtin_amdgcn_s_barrier();                          // M_k
     // ---- epilogue of segment k (compute waves): row sums -> fixed-point cell -> last arrival writes y ---------------------
     {
-      const uint32_t rs_off = L.rs0 + (uint32_t)(k & 1) * L.rs_bytes;
+      const uint32_t rs_off = L.rs0 + (uint32_t)rs_buf(k) * L.rs_bytes;
       const uint32_t T = (uint32_t)s.T;
       const int row_begin = group * s.RG;
       settle_pending();  // segment k - 1's rows: their atomics went out one loop ago
@@ -1625,7 +1640,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
         if constexpr (SELF_DMA) {  // asm reads: segment k + 1's slice is on its way into the other buffer (lds_asm_load_b32)
           q0 = lds_asm_load_b32(rs_off + (uint32_t)r * 4u);
           q1 = lds_asm_load_b32(rs_off + (uint32_t)r * 4u + 4u);
-          uint32_t vbits = lds_asm_load_b32(L.rowval + (uint32_t)r * 4u);
+          uint32_t vbits = lds_asm_load_b32(rowval_k + (uint32_t)r * 4u);
 #pragma unroll
           for (int q = 0; q < 4; ++q) sl[q] = lds_asm_load_b128(L.xmax + (uint32_t)(q * 4) * 4u);
           lds_asm_wait(q0, q1, vbits, sl[0], sl[1], sl[2], sl[3]);
@@ -1634,14 +1649,14 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
           uint32_t c1 = (q1 - 1u) / T;
           c1 = c1 < (uint32_t)(PK_MAX_NW * 64) ? c1 : (uint32_t)(PK_MAX_NW * 64 - 1);  // a column index, whatever was read
           for (uint32_t c = c0; c < c1; ++c) {
-            uint32_t ce = lds_asm_load_b32(L.colend + c * 4u);
+            uint32_t ce = lds_asm_load_b32(colend_k + c * 4u);
             lds_asm_wait(ce);
             v += __uint_as_float(ce);
           }
         } else {
           const uint32_t* rs = reinterpret_cast<const uint32_t*>(smem_raw + rs_off);
-          const float* rowval = reinterpret_cast<const float*>(smem_raw + L.rowval);
-          const float* colend = reinterpret_cast<const float*>(smem_raw + L.colend);
+          const float* rowval = reinterpret_cast<const float*>(smem_raw + rowval_k);
+          const float* colend = reinterpret_cast<const float*>(smem_raw + colend_k);
           q0 = rs[r];
           q1 = rs[r + 1];
           const uint32_t c0 = q0 / T, c1 = (q1 - 1u) / T;
@@ -1688,12 +1703,12 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
       if (defer_k && (wave << 6) < nrows) __builtin_amdgcn_s_waitcnt(3 | (7 << 4) | (15 << 8));
       else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
     }
-    __builtin_amdgcn_s_barrier();                          // F_k
+    if constexpr (!ONEB) __builtin_amdgcn_s_barrier();    // F_k (single-barrier form: the other table set is written next)
   }
   settle_pending();
 }
 
-static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max_rg, int& nwc, int& dma_waves) {
+static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max_rg, int& nwc, int& dma_waves, uint32_t& xwin, bool& oneb) {
   max_rg = 0;
   nwc = 0;
   for (int k = 0; k < n; ++k) {
@@ -1705,7 +1720,9 @@ static bool pipe_eligible(const PackedLayout* Ls, int n, int in_groups, int& max
   dma_waves = nwc + PP_DMA_WAVES <= PK_MAX_NW ? PP_DMA_WAVES : 0;
   if (tuning().packed_pipe == 2) dma_waves = 0;  // experiments: self-service DMA for every shape
   if (tuning().packed_pipe == 3 && dma_waves == 0) return false;  // experiments: round-3 first cut (DMA waves only)
-  return pipe_lds(max_rg).total <= 160u * 1024u;
+  xwin = (uint32_t)(in_groups + 1) * PK_VB <= PP_XWIN_SMALL ? PP_XWIN_SMALL : PP_XWIN;
+  oneb = dma_waves != 0 && tuning().packed_pipe != 5 && pipe_lds(max_rg, xwin, true).total <= 160u * 1024u;  // 5: two barriers always
+  return pipe_lds(max_rg, xwin, oneb).total <= 160u * 1024u;
 }
 
 // ---------------------------------------------------------------------------------------------- host launch helpers
@@ -2397,7 +2414,9 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
     PackedLayout Ls[AQLM_HIP_MAX_SEGMENTS];
     for (int k = 0; k < num_segments; ++k) desc_layout(descs[k], Ls[k]);
     int prg = 0, nwc = 0, dmaw = 0;
-    if (pipe_eligible(Ls, num_segments, mp.in_groups, prg, nwc, dmaw)) {
+    uint32_t xwin = PP_XWIN;
+    bool oneb = false;
+    if (pipe_eligible(Ls, num_segments, mp.in_groups, prg, nwc, dmaw, xwin, oneb)) {
       PipeParams pp{};
       pp.x = mp.x;
       pp.in_groups = mp.in_groups;
@@ -2407,14 +2426,21 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
       pp.dma_waves = dmaw;
       pp.defer = tuning().packed_pipe == 4 ? 0 : 1;
       for (int k = 0; k < num_segments; ++k) pp.seg[k] = mp.seg[k];
-      const size_t lds = pipe_lds(prg).total;
+      const size_t lds = pipe_lds(prg, xwin, oneb).total;
       auto go = [&](auto kern) -> int {
         if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
         hipLaunchKernelGGL(kern, dim3(PK_NST), dim3((nwc + dmaw) * 64), lds, stream, pp);
         return check_hip(hipGetLastError(), "gemv_1x16_packed_pipe launch");
       };
-      if (dmaw == 0) return dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16, true>) : go(gemv_1x16_packed_pipe_kernel<BF16, true>);
-      return dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16, false>) : go(gemv_1x16_packed_pipe_kernel<BF16, false>);
+#define AQLM_PP_GO(SELF, XWV, OB) \
+  (dtype == AQLM_HIP_F16 ? go(gemv_1x16_packed_pipe_kernel<F16, SELF, XWV, OB>) : go(gemv_1x16_packed_pipe_kernel<BF16, SELF, XWV, OB>))
+      if (xwin == PP_XWIN_SMALL) {
+        if (dmaw == 0) return AQLM_PP_GO(true, PP_XWIN_SMALL, false);
+        return oneb ? AQLM_PP_GO(false, PP_XWIN_SMALL, true) : AQLM_PP_GO(false, PP_XWIN_SMALL, false);
+      }
+      if (dmaw == 0) return AQLM_PP_GO(true, PP_XWIN, false);
+      return oneb ? AQLM_PP_GO(false, PP_XWIN, true) : AQLM_PP_GO(false, PP_XWIN, false);
+#undef AQLM_PP_GO
     }
   }
   auto launch = [&](auto kern, auto lds_map) -> int {

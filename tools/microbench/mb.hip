@@ -845,6 +845,9 @@ static void bench_multi() {
       printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "one launch, pipelined segments", pipe, ab / pipe * 1e-3);
     }
     {  // every compute wave requests its share of the next slice itself (the mode of 15- / 16-wave layers) for every shape
+      aqlm_hip_set_tuning("packed_pipe", 5);
+      const double twob = time_it(true);
+      printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "pipelined, two barriers / segment", twob, ab / twob * 1e-3);
       aqlm_hip_set_tuning("packed_pipe", 2);
       const double selfdma = time_it(true);
       printf("%-22s %-34s %9.2f %9.0f\n", gr.name, "pipelined, no DMA waves", selfdma, ab / selfdma * 1e-3);
