@@ -1462,6 +1462,95 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
   uint32_t mask = PK_HMASK;
   asm volatile("" : "+v"(mask));  // SDWA operand in a VGPR
 
+  // Epilogue of segment k by the threads t0, t0 + nt, ... (single-barrier form): row sums -> fixed-point cells -> the last
+  // arrival writes y.  Two phases -- the atomics of up to four rows of a thread go out before the first answer is looked at --
+  // and asm LDS reads (the DMA waves run it with LDS-DMA in flight; see lds_asm_load_b32).
+  auto epilogue_rows = [&](int k, int t0, int nt) {
+    const PackedSegment s = segment(k);
+    int nrows = s.M - group * s.RG;
+    nrows = nrows < 0 ? 0 : (nrows < s.RG ? nrows : s.RG);
+    const uint32_t T = (uint32_t)s.T;
+    const int row_begin = group * s.RG;
+    const uint32_t rs_off = L.rs0 + (uint32_t)rs_buf(k) * L.rs_bytes;
+    const uint32_t rowval_k = L.rowval + (ONEB ? (uint32_t)(k & 1) * L.rowval_bytes : 0u);
+    const uint32_t colend_k = L.colend + (ONEB ? (uint32_t)(k & 1) * L.colend_bytes : 0u);
+    if (t0 >= nrows) return;
+    uint32_t xm = 0u;
+    {
+      u32x4 sl0 = lds_asm_load_b128(L.xmax), sl1 = lds_asm_load_b128(L.xmax + 16u), sl2 = lds_asm_load_b128(L.xmax + 32u),
+            sl3 = lds_asm_load_b128(L.xmax + 48u);
+      uint32_t dummy0 = 0u, dummy1 = 0u, dummy2 = 0u;
+      lds_asm_wait(dummy0, dummy1, dummy2, sl0, sl1, sl2, sl3);
+      const u32x4 sl[4] = {sl0, sl1, sl2, sl3};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t a = sl[q].x > sl[q].y ? sl[q].x : sl[q].y, c = sl[q].z > sl[q].w ? sl[q].z : sl[q].w;
+        const uint32_t d = a > c ? a : c;
+        xm = d > xm ? d : xm;
+      }
+    }
+    const float bound = (float)mp.in_groups * (float)PK_G * s.cb_absmax * T_::to_float((uint16_t)xm);
+    int e = 0;
+    (void)frexpf(bound, &e);
+    const int sh = PK_FIX_BITS - e;
+    const uint16_t* bias_src = s.bias ? s.bias : s.scales;
+    for (int r0 = t0; r0 < nrows; r0 += 4 * nt) {
+      unsigned long long old[4], mine[4];
+      uint16_t sc[4], bi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + i * nt;
+        old[i] = mine[i] = 0ull;
+        sc[i] = bi[i] = 0;
+        if (r < nrows) {
+          uint32_t q0 = lds_asm_load_b32(rs_off + (uint32_t)r * 4u), q1 = lds_asm_load_b32(rs_off + (uint32_t)r * 4u + 4u);
+          uint32_t vbits = lds_asm_load_b32(rowval_k + (uint32_t)r * 4u);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(vbits));
+          float v = __uint_as_float(vbits);
+          const uint32_t c0 = q0 / T;
+          uint32_t c1 = (q1 - 1u) / T;
+          c1 = c1 < (uint32_t)(PK_MAX_NW * 64) ? c1 : (uint32_t)(PK_MAX_NW * 64 - 1);
+          for (uint32_t c = c0; c < c1; ++c) {
+            uint32_t ce = lds_asm_load_b32(colend_k + c * 4u);
+            lds_asm_wait(ce);
+            v += __uint_as_float(ce);
+          }
+          const bool finite = bound < __builtin_inff() && fabsf(v) <= 2.f * bound;
+          const long long qv = finite ? __float2ll_rn(ldexpf(v, sh)) : 0ll;
+          mine[i] = ((unsigned long long)qv << PK_VAL_SHIFT) + (finite ? 1ull : 1ull + (1ull << PK_CNT_BITS));
+          const int row = row_begin + r;
+          old[i] = __hip_atomic_fetch_add(s.acc + row, mine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sc[i] = s.scales[row];
+          bi[i] = bias_src[row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + i * nt;
+        if (r < nrows && (old[i] & PK_CNT_MASK) == (unsigned long long)(PK_S - 1)) {
+          const int row = row_begin + r;
+          const unsigned long long cell = old[i] + mine[i];
+          const long long sum = (long long)cell >> PK_VAL_SHIFT;
+          float sv = (float)ldexp((double)sum, -sh);
+          if ((cell >> PK_CNT_BITS) & PK_CNT_MASK) sv = __builtin_nanf("");
+          s.y[row] = T_::from_float(__builtin_fmaf(sv, T_::to_float(sc[i]), s.bias ? T_::to_float(bi[i]) : 0.f));
+          __hip_atomic_store(s.acc + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  };
+
+  // Single-barrier form: who runs segment k's epilogue?  The two DMA waves, during loop k + 1, when that costs the compute
+  // waves nothing -- at most two rows per DMA thread and a next loop at least as long as this one (measured: with the short
+  // k / v loops behind q, or 688-row groups, the DMA waves become the critical path); else the compute waves, right after M_k.
+  auto epi_on_dma = [&](int k) -> bool {
+    if (!ONEB || k + 1 >= mp.nseg) return false;
+    const PackedSegment a = segment(k), b = segment(k + 1);
+    int nrows = a.M - group * a.RG;
+    nrows = nrows < 0 ? 0 : (nrows < a.RG ? nrows : a.RG);
+    return nrows <= 2 * PP_DMA_WAVES * 64 && b.NW * b.T >= a.NW * a.T;
+  };
+
   if (dma_wave) {
     // ============================================ DMA waves ================================================================
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));  // vmcnt(0) lgkmcnt(0): my share of the first fill has landed
@@ -1473,6 +1562,7 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
         dma_rowstart(sn, rs_buf(k + 1), dw, PP_DMA_WAVES);
       }
       if constexpr (ONEB) {
+        if (k >= 1 && epi_on_dma(k - 1)) epilogue_rows(k - 1, dw * 64 + lane, PP_DMA_WAVES * 64);  // while the compute waves run loop k
         __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));  // slice k + 1 is in LDS when the compute waves leave M_k
         __builtin_amdgcn_s_barrier();                        // M_k
       } else {
@@ -1626,7 +1716,8 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_pipe_kernel(const PipeP
     asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");  // the asm LDS stores are invisible to the compiler's counters
     __builtin_amdgcn_s_barrier();                          // M_k
     // ---- epilogue of segment k (compute waves): row sums -> fixed-point cell -> last arrival writes y ---------------------
-    {
+    // (single-barrier form: where epi_on_dma(k) says so the DMA waves do it while this wave is already in loop k + 1)
+    if (!epi_on_dma(k)) {
       const uint32_t rs_off = L.rs0 + (uint32_t)rs_buf(k) * L.rs_bytes;
       const uint32_t T = (uint32_t)s.T;
       const int row_begin = group * s.RG;
