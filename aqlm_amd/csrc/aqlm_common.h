@@ -156,7 +156,7 @@ struct Tuning {
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
   int packed_fused_finalize = 1;  // 0 = two-kernel finalize even when the descriptor carries the codebook range (A/B runs)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
-  int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel), 0 = ascending j
+  int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel + pk_improve_kernel), 2 = greedy deal only, 0 = ascending j
   int packed_xcopies = 0;        // prepack: rotated copies of x the batch-1 kernel keeps in LDS (1..4, capped by what fits); 0 = 1
   int packed_entry_bytes = 0;    // prepack: 0 / 4 = 32-bit entries; 3 = 24-bit entries (wave ranges of <= 32 steps)
   int packed_debug = 0;          // profiling builds (-DAQLM_PACKED_TRACE) only: 1 = no LDS reads / dots, 2 = no entry stream

@@ -425,6 +425,190 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
   }
 }
 
+// K3c: local search on the greedy deal.  The greedy order is good in a wave range's early slots and poor in its last ones
+// (the pools run dry: whatever is left must be taken).  This pass walks the slots again; an entry that shares its codebook
+// or x bank group with another lane of its service group looks at every other position of its row's pool and swaps with
+// the one that lowers
+//     cost(slot, service group) = 8 * (max_b count_c[b] + max_b count_x[b]) + sum_b count_c[b]^2 + sum_b count_x[b]^2
+// (the max terms are the LDS cycles of the two reads, the squares break ties towards flatter histograms) the most, summed
+// over the two (slot, service group) cells the swap touches; swaps that leave the cost unchanged are taken too (they walk
+// plateaus), PK_IMPROVE_SWEEPS passes.  tools/arrangement_bound.py: LDS cycles per service group and read 2.18 + 1.70 ->
+// 1.6 + 1.5 (lower bound of any order 1.27 + 1.26, simulated annealing 1.57 + 1.43).  Same launch shape and the same fixed
+// order of decisions as K3b -> deterministic.  Entries are still plain here (parity, flags and row numbers are stamped
+// later), null entries of a cell read one address (two with 32-byte vectors: one per lane parity) and count once.
+constexpr int PK_IMPROVE_SWEEPS = 6;  // most of the gain comes in the first three; the prepack runs once per layer
+
+struct PkHist {
+  uint32_t w[4];  // 16 counts of 8 bits
+  __device__ __forceinline__ void add(uint32_t bank, uint32_t delta) {  // delta = +1 or -1 (as uint32_t)
+    const uint32_t v = delta << ((bank & 3u) * 8u);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) w[i] += (bank >> 2) == i ? v : 0u;
+  }
+  __device__ __forceinline__ uint32_t count(uint32_t bank) const {
+    uint32_t v = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) v = (bank >> 2) == i ? w[i] : v;
+    return (v >> ((bank & 3u) * 8u)) & 255u;
+  }
+  __device__ __forceinline__ int cost() const {
+    int mx = 0, sq = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = (int)((w[i >> 2] >> ((i & 3) * 8)) & 255u);
+      mx = c > mx ? c : mx;
+      sq += c * c;
+    }
+    return 8 * mx + sq;
+  }
+};
+
+__device__ __forceinline__ int pk_lane_group(int lane) {  // LDS service group of a lane (inverse of pk_group_lane)
+  const int h = lane & 31;
+  const int g1 = (h >= 4 && h < 12) || (h >= 16 && h < 20) || h >= 28;
+  return (lane >> 5) * 2 + g1;
+}
+
+__global__ __launch_bounds__(64) void pk_improve_kernel(const uint32_t* a, uint32_t* ent, int M, int in_groups, int RG, int NW,
+                                                        int T) {
+  extern __shared__ uint32_t arr_sm[];
+  uint32_t* e = arr_sm;                                                       // [64 * T * 4] entries in (lane, t, k) order: a row's pool is contiguous
+  PkHist* hc = reinterpret_cast<PkHist*>(e + (size_t)T * 256);               // [4 T slots][4 service groups]
+  PkHist* hx = hc + (size_t)T * 16;
+  uint16_t* rowa = reinterpret_cast<uint16_t*>(hx + (size_t)T * 16);         // [64 * T] the pool of the lane-step's row: lane-steps [rowa, rowb)
+  uint16_t* rowb = rowa + (size_t)T * 64;
+  uint8_t* nulls = reinterpret_cast<uint8_t*>(rowb + (size_t)T * 64);        // [4 T][4][2] null entries per cell and lane parity
+  const size_t st = blockIdx.x;
+  const int w = blockIdx.y, l = threadIdx.x;
+  const int g = (int)(st / PK_S);
+  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  const uint32_t* starts = a + st * (RG + 1);
+  const uint32_t total = starts[nrows];
+  uint32_t* wave_ent = ent + (((size_t)st * NW + w) * T) * 256;
+  const uint32_t w0 = (uint32_t)w * 64u * (uint32_t)T;
+  if (w0 >= total) return;  // nothing but null entries
+  const uint32_t q0 = w0 + (uint32_t)l * (uint32_t)T;
+  for (int t = 0; t < T; ++t)
+    *reinterpret_cast<u32x4*>(e + ((size_t)l * T + t) * 4) = *reinterpret_cast<const u32x4*>(wave_ent + ((size_t)t * 64 + l) * 4);
+  for (int i = l; i < T * 16 * 2 * 4; i += 64) reinterpret_cast<uint32_t*>(hc)[i] = 0u;  // hc and hx
+  for (int i = l; i < T * 32; i += 64) nulls[i] = 0;
+  {
+    int r = nrows;
+    if (q0 < total) {
+      int lo = 0, hi = nrows;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= q0) lo = mid; else hi = mid;
+      }
+      r = lo;
+    }
+    for (int t = 0; t < T; ++t) {
+      const uint32_t q = q0 + (uint32_t)t;
+      uint32_t ra = q - w0, rb = ra + 1;
+      if (q < total) {
+        while (starts[r + 1] <= q) ++r;
+        const uint32_t rs = starts[r], re = starts[r + 1];
+        ra = rs > w0 ? rs - w0 : 0u;
+        rb = re < w0 + 64u * (uint32_t)T ? re - w0 : 64u * (uint32_t)T;
+      }
+      rowa[l * T + t] = (uint16_t)ra;
+      rowb[l * T + t] = (uint16_t)rb;
+    }
+  }
+  __syncthreads();
+  const uint32_t null_j = (uint32_t)in_groups;
+  // bank groups of an entry read by a lane of parity `par`; null entries: the zero vector's slot and x slot `in_groups`
+  auto bank_c = [&](uint32_t v, uint32_t par) { return (v >> (16 + PK_VSH)) == null_j ? par : (((v >> 4) & 15u) ^ par); };
+  auto bank_x = [&](uint32_t v, uint32_t par) { return (((v >> (16 + PK_VSH)) << (PK_VSH - 4)) & 15u) ^ par; };
+  auto lane_par = [](int lane) { return PK_G == 16 ? (uint32_t)(lane & 1) : 0u; };
+  // the cell's histograms after `v` joined (sign = +1) or left (-1) at lane parity `par`; `nz` = the cell's null count there
+  auto apply = [&](PkHist& c, PkHist& x, uint32_t v, uint32_t par, uint32_t sign, uint32_t& nz) {
+    if ((v >> (16 + PK_VSH)) == null_j) {
+      const bool counts = sign == 1u ? nz == 0u : nz == 1u;  // the first null in, the last null out
+      nz += sign;
+      if (!counts) return;
+    }
+    c.add(bank_c(v, par), sign);
+    x.add(bank_x(v, par), sign);
+  };
+  if (l == 0) {  // histograms of the greedy deal (sequential: pack time, 256 T entries)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int t = 0; t < T; ++t)
+        for (int k = 0; k < 4; ++k) {
+          const int cell = (t * 4 + k) * 4 + pk_lane_group(lane);
+          const uint32_t par = lane_par(lane);
+          uint32_t nz = nulls[cell * 2 + par];
+          apply(hc[cell], hx[cell], e[(lane * T + t) * 4 + k], par, 1u, nz);
+          nulls[cell * 2 + par] = (uint8_t)nz;
+        }
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < PK_IMPROVE_SWEEPS; ++sweep) {
+    for (int s = 0; s < 4 * T; ++s) {
+      const int t = s >> 2, k = s & 3;
+      for (int lane = 0; lane < 64; ++lane) {  // wave-uniform: the entry under repair
+        const int p = (lane * T + t) * 4 + k;
+        const uint32_t v = e[p];
+        if ((v >> (16 + PK_VSH)) == null_j) continue;
+        const uint32_t par = lane_par(lane);
+        const int cell = s * 4 + pk_lane_group(lane);
+        const PkHist c0 = hc[cell], x0 = hx[cell];
+        if (c0.count(bank_c(v, par)) <= 1u && x0.count(bank_x(v, par)) <= 1u) continue;  // alone in both bank groups
+        const int cost0 = c0.cost() + x0.cost();
+        const uint32_t nz0 = nulls[cell * 2 + par];
+        const int base = (int)rowa[lane * T + t] * 4, n = ((int)rowb[lane * T + t] - (int)rowa[lane * T + t]) * 4;
+        uint32_t key = ~0u;  // (cost change + 2^14) << 16 | pool index: the minimum is the best, lowest-index partner
+        for (int i = l; i < n; i += 64) {
+          const int p2 = base + i, q2 = p2 >> 2, k2 = p2 & 3, lane2 = q2 / T, t2 = q2 - lane2 * T;
+          const int cell2 = (t2 * 4 + k2) * 4 + pk_lane_group(lane2);
+          if (cell2 == cell) continue;
+          const uint32_t v2 = e[p2], par2 = lane_par(lane2);
+          PkHist c1 = c0, x1 = x0, c2 = hc[cell2], x2 = hx[cell2];
+          const int cost2 = c2.cost() + x2.cost();
+          uint32_t nz1 = nz0, nz2 = nulls[cell2 * 2 + par2];
+          apply(c1, x1, v, par, ~0u, nz1);
+          apply(c1, x1, v2, par, 1u, nz1);
+          apply(c2, x2, v2, par2, ~0u, nz2);
+          apply(c2, x2, v, par2, 1u, nz2);
+          int cost_a = c1.cost() + x1.cost(), cost_b = c2.cost() + x2.cost();
+          // hipcc 7.2 / gfx950 -O3 miscompiles the four-cost difference when it may fold it (every change came out positive: no
+          // swap was ever taken; found with tools/microbench/arr_dbg.hip): keep the new costs as opaque values
+          asm volatile("" : "+v"(cost_a), "+v"(cost_b));
+          const int d = cost_a + cost_b - cost0 - cost2;
+          const uint32_t kk = ((uint32_t)(d + (1 << 14)) << 16) | (uint32_t)i;
+          key = kk < key ? kk : key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)key, o, WAVE);
+          key = other < key ? other : key;
+        }
+        if ((key >> 16) > (1u << 14)) continue;  // every partner makes it worse (or there is none)
+        __syncthreads();  // everybody has read the cells
+        if (l == 0) {
+          const int p2 = base + (int)(key & 0xffffu), q2 = p2 >> 2, k2 = p2 & 3, lane2 = q2 / T, t2 = q2 - lane2 * T;
+          const int cell2 = (t2 * 4 + k2) * 4 + pk_lane_group(lane2);
+          const uint32_t v2 = e[p2], par2 = lane_par(lane2);
+          PkHist c1 = hc[cell], x1 = hx[cell], c2 = hc[cell2], x2 = hx[cell2];
+          uint32_t nz1 = nulls[cell * 2 + par], nz2 = nulls[cell2 * 2 + par2];
+          apply(c1, x1, v, par, ~0u, nz1);
+          apply(c1, x1, v2, par, 1u, nz1);
+          apply(c2, x2, v2, par2, ~0u, nz2);
+          apply(c2, x2, v, par2, 1u, nz2);
+          hc[cell] = c1; hx[cell] = x1; hc[cell2] = c2; hx[cell2] = x2;
+          nulls[cell * 2 + par] = (uint8_t)nz1;
+          nulls[cell2 * 2 + par2] = (uint8_t)nz2;
+          e[p] = v2;
+          e[p2] = v;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (int t = 0; t < T; ++t)
+    *reinterpret_cast<u32x4*>(wave_ent + ((size_t)t * 64 + l) * 4) = *reinterpret_cast<const u32x4*>(e + ((size_t)l * T + t) * 4);
+}
+
 // K4: bookkeeping bits.  Thread (st, r): flag on the row's last lane-step.
 __global__ __launch_bounds__(256) void pk_flag_kernel(const uint32_t* a, uint32_t* ent, int M, int RG, int NW, int T) {
   const size_t st = blockIdx.y;
@@ -2028,6 +2212,9 @@ extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features,
   if (arrange)
     hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 256, stream, a,
                        ent, M, in_groups, RG, NW, T, XC);
+  if (arrange && tuning().packed_arrange == 1)  // 2 = the greedy deal alone (A/B runs)
+    hipLaunchKernelGGL(pk_improve_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * (1024 + 512 + 256 + 32), stream, a, ent, M,
+                       in_groups, RG, NW, T);
   if (PK_PARITY_BITS) hipLaunchKernelGGL(pk_parity_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4);
   hipLaunchKernelGGL(pk_flag_kernel, dim3((RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, M, RG, NW, T);
   hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, M, RG, NW, T);

@@ -453,6 +453,34 @@ def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
     assert hk.prepack_1x16(torch.zeros(8, 4095, 1, dtype=torch.int16, device=DEV)) is None  # 32760 features: j needs 13 bits
 
 
+def test_prepack_local_search_lowers_bank_conflicts(hk):
+    """The prepack's second ordering pass (pk_improve_kernel) changes no result and no parity test can see it -- and a
+    miscompiled cost difference once made it a silent no-op.  Measure what it is for on the device layout: LDS cycles per
+    16-lane service group and read (tests/packed_model.py), greedy deal alone vs greedy + local search."""
+    from aqlm_amd import _native
+    from tests import packed_model as pm
+
+    fin, fout = 4096, 2048
+    g = torch.Generator().manual_seed(11)
+    cu = torch.randint(0, 65536, (fout, fin // 8, 1), generator=g, dtype=torch.int32)
+    codes = (cu - (cu >= 32768) * 65536).to(torch.int16).to(DEV)
+    cycles = {}
+    try:
+        for arrange in (2, 1):
+            _native.set_tuning("packed_arrange", arrange)
+            packed = hk.prepack_1x16(codes)
+            d = packed.desc
+            G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), int(d.entry_bytes))
+            P = dict(ent=((G["slot"].astype(np.int64) + pm.XB) << 16) | G["code"], in_groups=fin // 8, NW=int(d.waves), winfo=G["winfo"])
+            cycles[arrange] = pm.conflict_cycles(P, max_streams=4)
+            assert torch.equal(hk.unpack_1x16(packed), codes)
+    finally:
+        _native.set_tuning("packed_arrange", 1)
+    print(f"LDS cycles per service group and read: greedy {cycles[2]:.3f}, greedy + local search {cycles[1]:.3f}")
+    assert cycles[2] < 2.1 and cycles[1] < 0.86 * cycles[2], cycles
+
+
+
 PACKED_SHAPES = [
     (4096, 4096, "float16", True),
     (4096, 1000, "float16", False),      # ragged row groups

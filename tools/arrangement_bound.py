@@ -15,7 +15,9 @@ measures on the device layout.  Result (T = steps per wave; 512 / 1024 input gro
     T = 6  (4096 -> 11008):  no order 2.99 + 2.91 | greedy 2.18 + 1.70 | annealed 1.57 + 1.43 | bound 1.28 + 1.29
     T = 29 (8192 -> 28672):  no order 3.07 + 2.96 | greedy 2.07 + 1.53 |                      | bound 1.13 + 1.12
 
-i.e. the shipped order has collected 60 % (T = 6) of what an ideal order could, and an expensive search another 25 %.
+i.e. the greedy deal collects 60 % (T = 6) of what an ideal order could and a search another 25 %.  That search is built
+into the prepack since round 3 (pk_improve_kernel: best-swap local search with plateau moves, 6 sweeps); on the device
+layout it reaches codebook 1.53 + x 1.47 (tools/conflict_report.py).
 
     python tools/arrangement_bound.py [T] [in_groups] [anneal iterations]
 """

@@ -44,6 +44,6 @@ def report(fin, fout, arrange=1, xcopies=0):
 
 
 if __name__ == "__main__":
-    for fin, fout in ((4096, 4096), (8192, 4096)):
-        for arr, xc in ((0, 0), (1, 0), (1, 4)):
+    for fin, fout in ((4096, 4096), (4096, 11008), (8192, 4096)):
+        for arr, xc in ((0, 0), (2, 0), (1, 0), (1, 4)):  # ascending j | greedy deal only | greedy + local search (default) | + 4 copies of x
             report(fin, fout, arr, xc)

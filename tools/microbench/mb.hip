@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/aqlm_hip.h"
@@ -497,6 +498,8 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"two-kernel finalize", "packed_fused_finalize", 0}});
       if (getenv("MB_W67")) {  // focused A/B: small layers, 5 / 6 / 7 waves, three alternations
         for (int r = 0; r < 3; ++r) { variants.push_back({{"waves=6", "packed_waves", 6}}); variants.push_back({{"waves=7", "packed_waves", 7}}); variants.push_back({{"waves=5", "packed_waves", 5}}); }
+      } else if (getenv("MB_ARR")) {  // focused A/B: greedy deal alone (2) vs greedy + local search (1), two alternations, B = 1 and 4
+        for (int r = 0; r < 2; ++r) { variants.push_back({{"arrange=2 (greedy only)", "packed_arrange", 2}}); variants.push_back({{"arrange=1", "packed_arrange", 1}}); }
       } else if (getenv("MB_PD")) {  // focused A/B on the default packing: ring depth 3 vs 4, three alternations
         for (int r = 0; r < 3; ++r) { variants.push_back({{"prefetch=4", "packed_prefetch", 4}}); variants.push_back({{"prefetch=3", "packed_prefetch", 3}}); }
       } else if (getenv("MB_AB12")) {  // focused A/B: 12 vs 16 waves, three alternations
@@ -570,17 +573,19 @@ static void bench_gemv(int argc, char** argv) {
       if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_fused_finalize") || !strcmp(var[0].key, "mb_chain") || !strcmp(var[0].key, "packed_fill_rotate"))) check_packed(c.s, layers[0], c.in, c.out, &layers[1]);
       if (c.s.packed && !var.empty() && (!strcmp(var[0].key, "packed_waves") || !strcmp(var[0].key, "packed_arrange") || !strcmp(var[0].key, "packed_entry_bytes") || !strcmp(var[0].key, "packed_xcopies"))) {  // a format parameter: repack
         const size_t pb = aqlm_hip_prepack_1x16_bytes(c.out, c.in, c.s.g);
+        const auto pk_t0 = std::chrono::steady_clock::now();
         for (auto& L : layers) {
           if (int rc = aqlm_hip_prepack_1x16(L.codes, c.out, c.in, c.s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
           L.desc.codebook_absmax = 1.0f;
         }
         one[0] = layers[0];
         for (auto& w : warm) w = layers[0];
-        printf("# repacked: waves %d steps %d entry bytes %d x copies %d, %.3f B per code\n", layers[0].desc.waves, layers[0].desc.steps,
-               layers[0].desc.entry_bytes, (int)layers[0].desc.x_copies, (double)layers[0].desc.used_bytes / ((double)c.out * (c.in / c.s.g)));
+        printf("# repacked: waves %d steps %d entry bytes %d x copies %d, %.3f B per code, %.2f ms per layer\n", layers[0].desc.waves, layers[0].desc.steps,
+               layers[0].desc.entry_bytes, (int)layers[0].desc.x_copies, (double)layers[0].desc.used_bytes / ((double)c.out * (c.in / c.s.g)),
+               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pk_t0).count() / (double)layers.size());
       }
       for (int batch : {1, 2, 4, 8}) {
-        if (batch > 1 && (!var.empty() || quick)) continue;
+        if (batch > 1 && (!var.empty() || quick) && !(getenv("MB_ARR") && batch == 4)) continue;
         const size_t ab = algo_bytes(c.in, c.out, c.s, batch);
         const double cold = time_graph(c.s, layers, c.in, c.out, batch, 4);
         const double w = time_graph(c.s, warm, c.in, c.out, batch, 20);
