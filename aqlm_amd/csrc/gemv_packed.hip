@@ -432,11 +432,12 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
 //     cost(slot, service group) = 8 * (max_b count_c[b] + max_b count_x[b]) + sum_b count_c[b]^2 + sum_b count_x[b]^2
 // (the max terms are the LDS cycles of the two reads, the squares break ties towards flatter histograms) the most, summed
 // over the two (slot, service group) cells the swap touches; swaps that leave the cost unchanged are taken too (they walk
-// plateaus), PK_IMPROVE_SWEEPS passes.  tools/arrangement_bound.py: LDS cycles per service group and read 2.18 + 1.70 ->
+// plateaus), PK_IMPROVE_SWEEPS passes (3 for long wave ranges).  tools/arrangement_bound.py: LDS cycles per service group and read 2.18 + 1.70 ->
 // 1.6 + 1.5 (lower bound of any order 1.27 + 1.26, simulated annealing 1.57 + 1.43).  Same launch shape and the same fixed
 // order of decisions as K3b -> deterministic.  Entries are still plain here (parity, flags and row numbers are stamped
 // later), null entries of a cell read one address (two with 32-byte vectors: one per lane parity) and count once.
-constexpr int PK_IMPROVE_SWEEPS = 6;  // most of the gain comes in the first three; the prepack runs once per layer
+constexpr int PK_IMPROVE_SWEEPS = 6;       // most of the gain comes in the first three (3.88 -> 3.34 / 3.23 / 3.16 ... 3.07 cycles)
+constexpr int PK_IMPROVE_SWEEPS_LONG = 3;  // wave ranges of more than 12 steps: the 70B layers, bound by their entry stream anyway
 
 struct PkHist {
   uint32_t w[4];  // 16 counts of 8 bits
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(64) void pk_improve_kernel(const uint32_t* a, uint3
         }
   }
   __syncthreads();
-  for (int sweep = 0; sweep < PK_IMPROVE_SWEEPS; ++sweep) {
+  const int sweeps = T <= 12 ? PK_IMPROVE_SWEEPS : PK_IMPROVE_SWEEPS_LONG;
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
     for (int s = 0; s < 4 * T; ++s) {
       const int t = s >> 2, k = s & 3;
       for (int lane = 0; lane < 64; ++lane) {  // wave-uniform: the entry under repair

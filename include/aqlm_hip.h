@@ -192,7 +192,11 @@ typedef struct aqlm_hip_packed_desc {
                             codebook; 0 = unknown).  > 0 enables the fused finalize of aqlm_hip_gemv_1x16_packed[_multi]:
                             it bounds the slice sums, from which the kernel derives an overflow-free fixed-point scale.
                             Must be >= the true maximum (update it when the codebook is retrained); any finite value
-                            that is too large only costs resolution (the sums keep ~47 bits below the bound). */
+                            that is too large only costs resolution (the sums keep ~47 bits below the bound).
+                            The value travels as a kernel argument: a hipGraph that captured the launch replays with
+                            the bound it was captured with -- re-capture (or capture with a generous bound) if the
+                            codebook's range can grow afterwards.  A sum beyond the bound is not wrapped silently:
+                            the row's result is NaN (the kernel checks |sum| <= 2 * bound). */
 } aqlm_hip_packed_desc;
 
 size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size);
