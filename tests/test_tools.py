@@ -39,3 +39,24 @@ def test_make_pmc_traffic_applies_the_gfx950_correction(tmp_path):
     assert not any("pk_" in name for name in t["per_kernel"])
     per_matvec = (2 * k["hbm_bytes"] + 2 * (2 * 10.0 * 1024 + 4.0 * 1024)) / 2     # main + finalize per matvec
     assert abs(t["gemv_1x16_hbm_bytes_per_launch"] - per_matvec) < 1e-6
+
+
+def test_arrangement_bound_orders_and_bound_are_consistent():
+    """tools/arrangement_bound.py: the restated greedy deal beats the ascending order, a short annealing run does not make it
+    worse, every order is a permutation inside the rows' pools, and nothing beats the degree bound."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import arrangement_bound as ab
+    finally:
+        sys.path.pop(0)
+    c, x, row = ab.make_wave(3, 512, np.random.default_rng(7))
+    gc, gx = ab.greedy(c, x, row)
+    ac, ax = ab.anneal(gc, gx, row, 20000)
+    base, g, a, lb = ab.cost(c, x).sum(), ab.cost(gc, gx).sum(), ab.cost(ac, ax).sum(), ab.degree_bound(c, x).sum()
+    assert lb <= a <= g + 0.05 and g < 0.8 * base and lb >= 2.0, (base, g, a, lb)
+    for r in np.unique(row):  # the entries of a row stay in the row (as multisets of (codebook slot, x slot) pairs)
+        sel = row == r
+        want = sorted(zip(c[sel].ravel().tolist(), x[sel].ravel().tolist()))
+        assert sorted(zip(gc[sel].ravel().tolist(), gx[sel].ravel().tolist())) == want
+        assert sorted(zip(ac[sel].ravel().tolist(), ax[sel].ravel().tolist())) == want
