@@ -149,7 +149,78 @@ void sweep_rows_plain(const float* lut, const uint8_t* codes, float* acc, int r0
   }
 }
 
+// Scalar look-ups, two input groups per pass over the rows (halves the traffic of the accumulators): no gather instruction --
+// on cores with three or four load ports (Zen 5) plain loads outrun the microcoded gathers.  K <= 2.
+template <int K>
+void sweep_rows_scalar(const float* lut, const uint8_t* codes, float* acc, int r0, int r1, int in_groups, int out_features) {
+  for (int i = r0; i < r1; ++i) acc[i] = 0.f;
+  int j = 0;
+  for (; j + 2 <= in_groups; j += 2) {
+    const float* l0 = lut + (size_t)j * K * 256;
+    const float* l1 = l0 + (size_t)K * 256;
+    const uint8_t* c0 = codes + ((size_t)j * out_features) * K;
+    const uint8_t* c1 = c0 + (size_t)out_features * K;
+#pragma GCC unroll 4
+    for (int i = r0; i < r1; ++i) {
+      const uint8_t* p0 = c0 + (size_t)i * K;
+      const uint8_t* p1 = c1 + (size_t)i * K;
+      float a = l0[p0[0]], b = l1[p1[0]];
+      if (K == 2) {
+        a += l0[256 + p0[1]];
+        b += l1[256 + p1[1]];
+      }
+      acc[i] += a + b;
+    }
+  }
+  for (; j < in_groups; ++j) {
+    const float* l0 = lut + (size_t)j * K * 256;
+    const uint8_t* c0 = codes + ((size_t)j * out_features) * K;
+    for (int i = r0; i < r1; ++i) {
+      const uint8_t* p0 = c0 + (size_t)i * K;
+      float a = l0[p0[0]];
+      if (K == 2) a += l0[256 + p0[1]];
+      acc[i] += a;
+    }
+  }
+}
+
+// The same for 4 / 8 codebooks: one input group per pass, the K look-ups of a row summed as a tree (a chain of K dependent
+// adds would be the critical path).
+template <int K>
+void sweep_rows_scalar_tree(const float* lut, const uint8_t* codes, float* acc, int r0, int r1, int in_groups, int out_features) {
+  static_assert(K == 4 || K == 8, "tree written out for 4 and 8");
+  for (int i = r0; i < r1; ++i) acc[i] = 0.f;
+  for (int j = 0; j < in_groups; ++j) {
+    const float* l = lut + (size_t)j * K * 256;
+    const uint8_t* c = codes + ((size_t)j * out_features) * K;
+#pragma GCC unroll 2
+    for (int i = r0; i < r1; ++i) {
+      const uint8_t* p = c + (size_t)i * K;
+      float t = (l[p[0]] + l[256 + p[1]]) + (l[512 + p[2]] + l[768 + p[3]]);
+      if (K == 8) t += (l[1024 + p[4]] + l[1280 + p[5]]) + (l[1536 + p[6]] + l[1792 + p[7]]);
+      acc[i] += t;
+    }
+  }
+}
+
 void sweep_rows(const float* lut, const uint8_t* codes, float* acc, int r0, int r1, int in_groups, int out_features, int K) {
+  // Which sweep: measured on the GPU box's EPYC 9575F (Zen 5, 1 thread, 2x8g8 4096 -> 11008): scalar look-ups 2.41 ms, AVX-512
+  // gathers 3.05 ms; on a Sapphire Rapids Xeon the other way round (4.9 vs 3.8 ms) -- so AMD cores take the scalar sweep.
+  // AQLM_CPU_SWEEP=scalar|gather overrides (experiments).
+  static const char* const sweep_env = getenv("AQLM_CPU_SWEEP");
+#if defined(__x86_64__)
+  static const bool amd = __builtin_cpu_is("amd");
+#else
+  static const bool amd = false;
+#endif
+  const bool scalar = sweep_env ? !strcmp(sweep_env, "scalar") : (amd || K >= 4);  // 8 codebooks: the tree of scalar look-ups wins on both (Xeon: 5.8 vs 7.4 ms)
+  if (scalar) {
+    if (K == 1) return sweep_rows_scalar<1>(lut, codes, acc, r0, r1, in_groups, out_features);
+    if (K == 2) return sweep_rows_scalar<2>(lut, codes, acc, r0, r1, in_groups, out_features);
+    if (K == 4) return sweep_rows_scalar_tree<4>(lut, codes, acc, r0, r1, in_groups, out_features);
+    if (K == 8) return sweep_rows_scalar_tree<8>(lut, codes, acc, r0, r1, in_groups, out_features);
+    return sweep_rows_plain(lut, codes, acc, r0, r1, in_groups, out_features, K);
+  }
 #if defined(__x86_64__)
   static const bool has_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
   static const bool has_avx512 = has_avx2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
@@ -158,6 +229,95 @@ void sweep_rows(const float* lut, const uint8_t* codes, float* acc, int r0, int 
   if (has_avx2) return sweep_rows_impl<true>(lut, codes, acc, r0, r1, in_groups, out_features, K);
 #endif
   sweep_rows_plain(lut, codes, acc, r0, r1, in_groups, out_features, K);
+}
+
+// One output row of the direct 1 x n kernel: per code one gather of g floats and g multiply-adds.  Four independent
+// accumulator sets -- with one, every code waits for the previous code's add (FMA latency per code: measured 2x the time) --
+// and the codebook vectors of the codes 16 ahead are prefetched (the 2 MiB fp32 table of a 16-bit codebook lives in L2 / L3).
+template <class CodeAt>
+static inline void row_1xn_plain(const float* x, const float* codebook, CodeAt code_at, const float* scales, const float* bias, float* y,
+                                 int batch, long xs, long ys, int in_groups, int g, int i) {
+  constexpr int U = 4;
+  for (int b = 0; b < batch; ++b) {
+    const float* xb = x + (size_t)b * xs;
+    float acc[U][16];
+    for (int u = 0; u < U; ++u)
+      for (int k = 0; k < g; ++k) acc[u][k] = 0.f;
+    int j = 0;
+    for (; j + U <= in_groups; j += U)
+      for (int u = 0; u < U; ++u) {
+        const float* v = codebook + (size_t)code_at(j + u) * g;
+        const float* xj = xb + (size_t)(j + u) * g;
+        for (int k = 0; k < g; ++k) acc[u][k] += v[k] * xj[k];
+      }
+    for (; j < in_groups; ++j) {
+      const float* v = codebook + (size_t)code_at(j) * g;
+      const float* xj = xb + (size_t)j * g;
+      for (int k = 0; k < g; ++k) acc[0][k] += v[k] * xj[k];
+    }
+    float s = 0.f;
+    for (int k = 0; k < g; ++k) s += (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
+    y[(size_t)b * ys + i] = s * scales[i] + (bias ? bias[i] : 0.f);
+  }
+}
+
+#if defined(__x86_64__)
+template <int G, class CodeAt>
+__attribute__((target("avx2,fma"))) static inline void row_1xn_avx2(const float* x, const float* codebook, CodeAt code_at, const float* scales,
+                                                                   const float* bias, float* y, int batch, long xs, long ys,
+                                                                   int in_groups, int i) {
+  constexpr int U = 4, AHEAD = 16, V = G / 8;  // V 256-bit vectors per code
+  for (int b = 0; b < batch; ++b) {
+    const float* xb = x + (size_t)b * xs;
+    __m256 acc[U][V];
+    for (int u = 0; u < U; ++u)
+      for (int h = 0; h < V; ++h) acc[u][h] = _mm256_setzero_ps();
+    int j = 0;
+    for (; j + U <= in_groups; j += U) {
+      if (j + AHEAD + U <= in_groups)
+        for (int u = 0; u < U; ++u) _mm_prefetch((const char*)(codebook + (size_t)code_at(j + AHEAD + u) * G), _MM_HINT_T0);
+      for (int u = 0; u < U; ++u) {
+        const float* v = codebook + (size_t)code_at(j + u) * G;
+        const float* xj = xb + (size_t)(j + u) * G;
+        for (int h = 0; h < V; ++h) acc[u][h] = _mm256_fmadd_ps(_mm256_loadu_ps(v + 8 * h), _mm256_loadu_ps(xj + 8 * h), acc[u][h]);
+      }
+    }
+    for (; j < in_groups; ++j) {
+      const float* v = codebook + (size_t)code_at(j) * G;
+      const float* xj = xb + (size_t)j * G;
+      for (int h = 0; h < V; ++h) acc[0][h] = _mm256_fmadd_ps(_mm256_loadu_ps(v + 8 * h), _mm256_loadu_ps(xj + 8 * h), acc[0][h]);
+    }
+    __m256 t = _mm256_add_ps(_mm256_add_ps(acc[0][0], acc[1][0]), _mm256_add_ps(acc[2][0], acc[3][0]));
+    for (int h = 1; h < V; ++h) t = _mm256_add_ps(t, _mm256_add_ps(_mm256_add_ps(acc[0][h], acc[1][h]), _mm256_add_ps(acc[2][h], acc[3][h])));
+    float lanes[8];
+    _mm256_storeu_ps(lanes, t);
+    float s = 0.f;
+    for (int k = 0; k < 8; ++k) s += lanes[k];
+    y[(size_t)b * ys + i] = s * scales[i] + (bias ? bias[i] : 0.f);
+  }
+}
+#endif
+
+static void row_1xn(const float* x, const float* codebook, const void* codes, int code_bytes, uint32_t mask, const float* scales,
+                    const float* bias, float* y, int batch, long xs, long ys, int in_groups, int g, int i) {
+  const size_t row_at = (size_t)i * in_groups;
+  const uint16_t* c16 = (const uint16_t*)codes + row_at;
+  const uint8_t* c8 = (const uint8_t*)codes + row_at;
+  auto at16 = [=](int j) -> uint32_t { return (uint32_t)c16[j] & mask; };
+  auto at8 = [=](int j) -> uint32_t { return (uint32_t)c8[j] & mask; };
+#if defined(__x86_64__)
+  static const bool has_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  if (has_avx2) {
+    if (code_bytes == 2) {
+      if (g == 8) return row_1xn_avx2<8>(x, codebook, at16, scales, bias, y, batch, xs, ys, in_groups, i);
+      return row_1xn_avx2<16>(x, codebook, at16, scales, bias, y, batch, xs, ys, in_groups, i);
+    }
+    if (g == 8) return row_1xn_avx2<8>(x, codebook, at8, scales, bias, y, batch, xs, ys, in_groups, i);
+    return row_1xn_avx2<16>(x, codebook, at8, scales, bias, y, batch, xs, ys, in_groups, i);
+  }
+#endif
+  if (code_bytes == 2) return row_1xn_plain(x, codebook, at16, scales, bias, y, batch, xs, ys, in_groups, g, i);
+  row_1xn_plain(x, codebook, at8, scales, bias, y, batch, xs, ys, in_groups, g, i);
 }
 
 }  // namespace
@@ -208,23 +368,7 @@ extern "C" int aqlm_cpu_gemv_1xn(const float* x, const float* codebook, const vo
   const uint32_t mask = (1u << nbits) - 1u;
   const int nt = resolve_threads(nthreads);
 #pragma omp parallel for num_threads(nt) schedule(static)
-  for (int i = 0; i < out_features; ++i) {
-    for (int b = 0; b < batch; ++b) {
-      const float* xb = x + (size_t)b * x_row_stride;
-      float acc[16];
-      for (int k = 0; k < g; ++k) acc[k] = 0.f;
-      for (int j = 0; j < in_groups; ++j) {
-        const size_t at = (size_t)i * in_groups + j;
-        const uint32_t code = (code_bytes == 2 ? (uint32_t)((const uint16_t*)codes)[at] : (uint32_t)((const uint8_t*)codes)[at]) & mask;
-        const float* v = codebook + (size_t)code * g;
-        const float* xj = xb + (size_t)j * g;
-#pragma omp simd
-        for (int k = 0; k < g; ++k) acc[k] += v[k] * xj[k];
-      }
-      float s = 0.f;
-      for (int k = 0; k < g; ++k) s += acc[k];
-      y[(size_t)b * y_row_stride + i] = s * scales[i] + (bias ? bias[i] : 0.f);
-    }
-  }
+  for (int i = 0; i < out_features; ++i)
+    row_1xn(x, codebook, codes, code_bytes, mask, scales, bias, y, batch, x_row_stride, y_row_stride, in_groups, g, i);
   return 0;
 }
