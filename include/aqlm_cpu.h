@@ -26,7 +26,8 @@ int aqlm_cpu_max_threads(void); /* OpenMP's default team size on this host */
  *           benchmark/matmul_benchmark_cpu.py:100-111).
  * codebooks [K][256][in_group_size] fp32; codes_alt [in_features/in_group_size][out_features][K] uint8 -- the layout the
  * reference permutes `codes` to for this kernel (inference.py:78-83); scales [out], bias [out] or NULL; x / y row strides
- * in elements.  scratch: aqlm_cpu_lut_scratch_floats(...) floats.  nthreads <= 0: OpenMP default.
+ * in elements.  scratch: aqlm_cpu_lut_scratch_floats(...) floats (the per-token table and a transposed copy of the
+ * codebooks; contents are undefined between calls).  nthreads <= 0: OpenMP default.
  */
 size_t aqlm_cpu_lut_scratch_floats(int in_features, int num_codebooks, int in_group_size);
 int aqlm_cpu_gemv_lut_kx8(const float* x, const float* codebooks, const uint8_t* codes_alt, const float* scales,
