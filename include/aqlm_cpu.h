@@ -2,6 +2,9 @@
  * aqlm_cpu.h -- C ABI of libaqlm_cpu.so: native CPU kernels of the AQLM QuantizedLinear matvec (host-side companion
  * of libaqlm_hip.so).  fp32 activations / outputs, caller-owned buffers, no allocation.
  * Return 0 on success, AQLM_CPU_E_* otherwise.  Paths cited are relative to the reference tree (inference_lib/src/aqlm/).
+ * Instruction sets are chosen at run time (SSE2 baseline; AVX2 + FMA, AVX-512 where the CPU has them).  Experiment switches,
+ * read once per process: AQLM_CPU_SWEEP=scalar|gather (the look-up sweep of the LUT kernel; default: scalar on AMD cores and
+ * for 4 / 8 codebooks, gathers otherwise), AQLM_CPU_NO_AVX512=1, AQLM_CPU_NO_AVX2_LUT=1 (scalar table build).
  */
 #ifndef AQLM_CPU_H_
 #define AQLM_CPU_H_
