@@ -10,13 +10,14 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import Optional
 
 import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libaqlm_cpu.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -36,6 +37,8 @@ def lib():
         L.aqlm_cpu_gemv_lut_kx8.argtypes = [vp, vp, vp, vp, vp, vp, ci, cl, cl, ci, ci, ci, ci, vp, ci]
         L.aqlm_cpu_gemv_1xn.restype = ci
         L.aqlm_cpu_gemv_1xn.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, cl, cl, ci, ci, ci, ci, ci]
+        L.aqlm_cpu_gemv_1xn_f16.restype = ci
+        L.aqlm_cpu_gemv_1xn_f16.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, cl, cl, ci, ci, ci, ci, ci]
         if L.aqlm_cpu_abi_version() != ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.aqlm_cpu_abi_version()}, expected {ABI_VERSION}; rebuild it")
         _lib = L
@@ -88,6 +91,31 @@ def cpu_gemm_lut(input: torch.Tensor, codes_alt: torch.Tensor, codebooks: torch.
     return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))
 
 
+# fp16 copies of the codebooks for the direct kernel, one per codebook tensor (keyed by id with a weak reference that drops the
+# entry when the tensor dies -- a WeakKeyDictionary would compare tensors with ==), rebuilt when the tensor was written.  None = the values are not fp16-representable (or the CPU lacks F16C): fp32 table.
+HALF_TABLE = True
+_HALF_TABLES = {}
+
+
+def _half_table(codebooks: torch.Tensor) -> Optional[torch.Tensor]:
+    if not HALF_TABLE:
+        return None
+    try:
+        version = codebooks._version
+    except RuntimeError:  # inference tensors carry no version counter: do not cache what cannot be invalidated
+        return None
+    key = (codebooks.data_ptr(), version, codebooks.dtype, tuple(codebooks.shape))
+    ident = id(codebooks)
+    hit = _HALF_TABLES.get(ident)
+    if hit is not None and hit[0]() is codebooks and hit[1] == key:
+        return hit[2]
+    half = codebooks.detach().to(torch.float16).contiguous()
+    if not torch.equal(half.to(torch.float32), codebooks.detach().to(torch.float32)):
+        half = None  # a retrained fp32 codebook, bf16 values outside fp16's range, ...
+    _HALF_TABLES[ident] = (weakref.ref(codebooks, lambda _, ident=ident: _HALF_TABLES.pop(ident, None)), key, half)
+    return half
+
+
 def cpu_gemv_1xn(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
                  bias: Optional[torch.Tensor], nthreads: int = 0) -> torch.Tensor:
     """One codebook of up to 65536 entries, g = 8 | 16, canonical codes [out, in_groups, 1] (int8 / int16 containers)."""
@@ -100,12 +128,20 @@ def cpu_gemv_1xn(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tens
     if input.shape[-1] != in_features:
         raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
     x = _f32(input.reshape(-1, in_features))
-    cb, sc, bi = _f32(codebooks), _f32(scales.reshape(-1)), _f32(bias)
+    sc, bi = _f32(scales.reshape(-1)), _f32(bias)
     c = codes.contiguous()
     y = torch.empty((x.shape[0], out_features), dtype=torch.float32)
-    rc = lib().aqlm_cpu_gemv_1xn(x.data_ptr(), cb.data_ptr(), c.data_ptr(), c.element_size(), sc.data_ptr(), _ptr(bi),
-                                 y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, nbits, g,
-                                 _threads(nthreads))
+    rc = -2
+    half = _half_table(codebooks)
+    if half is not None:  # same values from half the bytes (exactness checked when the copy was made); -2: no F16C here
+        rc = lib().aqlm_cpu_gemv_1xn_f16(x.data_ptr(), half.data_ptr(), c.data_ptr(), c.element_size(), sc.data_ptr(), _ptr(bi),
+                                         y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, nbits, g,
+                                         _threads(nthreads))
+    if rc == -2:
+        cb = _f32(codebooks)
+        rc = lib().aqlm_cpu_gemv_1xn(x.data_ptr(), cb.data_ptr(), c.data_ptr(), c.element_size(), sc.data_ptr(), _ptr(bi),
+                                     y.data_ptr(), x.shape[0], x.stride(0), out_features, in_features, out_features, nbits, g,
+                                     _threads(nthreads))
     if rc:
         raise RuntimeError(f"aqlm_cpu_gemv_1xn failed with {rc}")
     return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))

@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define AQLM_CPU_ABI_VERSION 1
+#define AQLM_CPU_ABI_VERSION 2
 #define AQLM_CPU_E_INVALID (-1)
 #define AQLM_CPU_E_UNSUPPORTED (-2)
 
@@ -46,6 +46,15 @@ int aqlm_cpu_gemv_lut_kx8(const float* x, const float* codebooks, const uint8_t*
 int aqlm_cpu_gemv_1xn(const float* x, const float* codebook, const void* codes, int code_bytes, const float* scales,
                       const float* bias, float* y, int batch, long x_row_stride, long y_row_stride, int in_features,
                       int out_features, int nbits, int in_group_size, int nthreads);
+
+/*
+ * The same with the codebook stored as IEEE fp16 (converted with F16C on the fly): half the table, which keeps a 16-bit
+ * codebook in L2 -- exact whenever the fp32 codebook values are fp16-representable (AQLM checkpoints store fp16 codebooks), and
+ * that is the caller's check.  AQLM_CPU_E_UNSUPPORTED on a CPU without AVX2 + FMA + F16C: use aqlm_cpu_gemv_1xn.  (ABI 2.)
+ */
+int aqlm_cpu_gemv_1xn_f16(const float* x, const uint16_t* codebook_f16, const void* codes, int code_bytes, const float* scales,
+                          const float* bias, float* y, int batch, long x_row_stride, long y_row_stride, int in_features,
+                          int out_features, int nbits, int in_group_size, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,8 @@ def main():
     parser.add_argument("--log_error", action="store_true")
     parser.add_argument("--nbits_per_codebook", type=int, default=8)
     parser.add_argument("--num_codebooks", type=int, default=2)
+    parser.add_argument("--fp16_codebooks", action="store_true",
+                        help="codebook values rounded to fp16 as in a checkpoint (the reference protocol draws fp32 randn): lets the 1 x n kernel use its fp16 table")
     parser.add_argument("--in_group_size", type=int, default=8)
     parser.add_argument("--nthreads", type=int, default=1)
     parser.add_argument("--max_seconds", type=float, default=20.0, help="cap of the timed loop per side and shape (0 = none)")
@@ -64,6 +66,8 @@ def main():
             x = torch.randn((1, fin), generator=gen, dtype=torch.float32)
             codes = pack_int_data(torch.randint(2 ** nbits, (fout, fin // g, K), generator=gen), nbits)   # canonical [out, in/g, K]
             codebooks = torch.randn((K, 2 ** nbits, 1, g), generator=gen, dtype=torch.float32)
+            if args.fp16_codebooks:
+                codebooks = codebooks.half().float()
             scales = torch.randn((fout, 1, 1, 1), generator=gen, dtype=torch.float32)
             weight = _dequantize_weight(unpack_int_data(codes, nbits), codebooks, scales).contiguous()
             y_ref = F.linear(x, weight)
