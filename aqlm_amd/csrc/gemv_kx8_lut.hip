@@ -11,6 +11,7 @@
 // add instead of g/8 ds_read_b128 and g/2 v_dot2c.  Arithmetic is the same fp32 accumulation of exact fp16/bf16
 // products, in a different association order.
 #include <algorithm>
+#include <type_traits>
 
 #include "aqlm_common.h"
 
@@ -57,57 +58,93 @@ __device__ __forceinline__ void lut_absmax(lut_us2& m, const u32x4& v) {
   m = __builtin_elementwise_max(m, __builtin_bit_cast(lut_us2, v.w & 0x7fff7fffu));
 }
 
+// LDS image of a slab (round 4).  Entry (group jl, codebook c = 4 ch + k, value v) lives at byte
+//     v * 256 + (k & 1) * 128 + (jl * 2 + ch) * 4 + (k >> 1) * 65536 :
+// the bank of an entry is a function of (jl, ch) alone, and (jl, ch) is the LANE of the row walk (32 lanes = the 128 code
+// bytes of one row's slab chunk, one dword = 4 codebooks each), so a wave-wide ds_read_b32 never has a bank conflict
+// whatever the codes are.  Round 3's image was lut[jl][c][v]: bank = v mod 32 -- random for the reads, and 16 equal banks
+// for the 16 lanes of every table write (79 % of the LDS cycles were conflict cycles, profiles/r03_8x8_lut_kernel_pmc.json).
+__device__ __forceinline__ uint32_t lut_perm(uint32_t cw, uint32_t base, uint32_t sel) { return __builtin_amdgcn_perm(cw, base, sel); }
+
+// row_shr:1 with the old value kept where the source lane does not exist: lane 0 of every DPP row takes `in`, the
+// others take their left neighbour's `chain` -- a 16-deep shift register per row in ONE VALU op
+__device__ __forceinline__ float lut_shift_in(float in, float chain) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, in), __builtin_bit_cast(int, chain),
+                                                                0x111, 0xf, 0xf, false));
+}
+
 // `block` = the workgroup's index within its own layer (== blockIdx.x for a single-layer launch)
 template <class T, int G>
 __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* const lut = reinterpret_cast<float*>(smem_raw);  // [16 groups][8 codebooks][256]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l16 = lane & 15, quarter = lane >> 4;
+#ifdef AQLM_LUT_TRACE  // profiling builds only (tools/microbench `make trace`): wall-clock stamps (100 MHz) per wave behind the cells
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LUT_TRACE(i) do { __builtin_amdgcn_sched_barrier(0); tr[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LUT_TRACE(i)
+#endif
+  LUT_TRACE(0);
   const int slab = block % p.nslabs, range = block / p.nslabs;
   const int j0 = slab * LUT_JS;
   const int row_begin = range * p.rows_per_range;
   int nrows = p.M - row_begin;
   nrows = nrows < 0 ? 0 : (nrows < p.rows_per_range ? nrows : p.rows_per_range);
 
-  // code bytes of this quarter-wave's first rows go in flight before the table is built (clamped, unconditional)
-  const int jmine = j0 + l16 < p.in_groups ? j0 + l16 : p.in_groups - 1;
-  const bool group_ok = j0 + l16 < p.in_groups;
-  const int r0 = wave * 4 + quarter;  // rows r0, r0 + 64, ...
-  auto load_codes = [&](int r) -> u32x2 {
-    const int rc = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
-    return __builtin_nontemporal_load(
-        reinterpret_cast<const u32x2*>(p.codes + (((long)row_begin + rc) * p.in_groups + jmine) * 8));
+  // ---- row walk geometry: half-wave = one row, lane s of the half = (group jl = s / 2, codebooks 4 ch .. 4 ch + 3) =
+  // dword s of the row's 128-byte slab chunk: the 32 lanes read it with one coalesced load
+  const int s32 = lane & 31, half = lane >> 5;
+  const int jl = s32 >> 1, ch = s32 & 1;
+  const bool group_ok = j0 + jl < p.in_groups;
+  const int jmine = group_ok ? j0 + jl : p.in_groups - 1;
+  const int rfirst = wave * 2 + half;  // rows rfirst, rfirst + 32, ...
+  const int nsteps = (nrows + 31) >> 5;
+  // code words: raw buffer loads over the row range (rows past its end answer zeros and touch no memory: all loads are
+  // unconditional); per step one 32-bit add forms the offset
+  const uint32_t cstride = (uint32_t)p.in_groups * 8u;
+  const __amdgpu_buffer_rsrc_t rs_codes = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.codes + (size_t)row_begin * cstride), 0, (uint32_t)nrows * cstride, 0x00020000);
+  const uint32_t coff = (uint32_t)rfirst * cstride + (uint32_t)jmine * 8u + (uint32_t)ch * 4u;
+  auto load_codes = [&](int step) -> uint32_t {
+    return __builtin_amdgcn_raw_buffer_load_b32(rs_codes, coff + (uint32_t)step * (32u * cstride), 0, AUX_NT);
   };
-  u32x2 cq[4];
+  constexpr int RING = 8;  // steps of code words in flight per wave
+  uint32_t cq[RING];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) cq[k] = load_codes(r0 + 64 * k);
+  for (int k = 0; k < RING; ++k) cq[k] = load_codes(k);
 
-  // ---- table on the matrix cores: lut[jl][cv] = sum_k cb[cv][k] * x[j0+jl][k] is a [2048 x g] x [g x 16] product.
-  // v_mfma_f32_16x16x32: A = 16 (c,v) rows x 32 k (lane l: row l%16, 8 k of piece l/16), B = x of the 16 groups
-  // (lane l: group l%16, same piece), D[row (l/16)*4 + r][group l%16] -> 4 consecutive table entries = one 16-B LDS
-  // write.  g < 32 pads k with zero pieces.  128 tiles per workgroup, 8 per wave (the VALU version of this build cost
-  // 3.4 us per workgroup).
+  // ---- table on the matrix cores: lut[(c, v)][jl] = sum_k cb[c][v][k] * x[j0 + jl][k] is a [2048 x g] x [g x 16] product.
+  // v_mfma_f32_16x16x32: A = 16 codebook rows x 32 k (lane l: row l % 16, 8 k of piece l / 16), B = x of the 16 groups
+  // (lane l: group l % 16, same piece), D[row (l / 16) * 4 + r][group l % 16].  A tile's 16 rows are
+  // row q * 4 + vs * 2 + ch  =  codebook 4 ch + k, value v0 + 2 q + vs   (k, v0 per tile: 4 x 32 tiles),
+  // so the 4 D registers of lane l are (v, ch = 0 / 1) and (v + 1, ch = 0 / 1) of group l % 16: two 8-byte LDS writes
+  // whose 16 lanes cover 128 contiguous bytes (conflict-free).  g < 32 pads k with zero pieces.  8 tiles per wave.
   {
     constexpr int P = G / 8;  // pieces of 8 k per vector: 1, 2 or 4
     const int col = lane & 15, kg = lane >> 4;
     const u32x4 zero = {0u, 0u, 0u, 0u};
     const int jb = j0 + col < p.in_groups ? j0 + col : p.in_groups - 1;
     const u32x4 bfrag = kg < P ? reinterpret_cast<const u32x4*>(p.x + (size_t)jb * G)[kg] : zero;
+    const int arow_c = (col & 1) * 4, arow_v = (col >> 2) * 2 + ((col >> 1) & 1);  // this lane's A row within a tile
     u32x4 afrag[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int cv = (wave * 8 + t) * 16 + col;  // this lane's A row
+      const int tile = wave * 8 + t, k = tile >> 5, v0 = (tile & 31) * 8;
+      const int cv = (arow_c + k) * 256 + v0 + arow_v;
       afrag[t] = kg < P ? reinterpret_cast<const u32x4*>(p.codebooks + (size_t)cv * G)[kg] : zero;
     }
+    LUT_TRACE(1);  // loads issued
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const f32x4 d = lut_mfma16<T>(afrag[t], bfrag, f32x4{0.f, 0.f, 0.f, 0.f});
-      const int cv0 = (wave * 8 + t) * 16 + kg * 4;
-      *reinterpret_cast<f32x4*>(lut + col * (LUT_KC * 256) + cv0) = d;
+      const int tile = wave * 8 + t, k = tile >> 5, v0 = (tile & 31) * 8;
+      unsigned char* const dst = smem_raw + (v0 + kg * 2) * 256 + (k & 1) * 128 + (k >> 1) * 65536 + col * 8;
+      *reinterpret_cast<float2*>(dst) = float2{d[0], d[1]};
+      *reinterpret_cast<float2*>(dst + 256) = float2{d[2], d[3]};
     }
+    LUT_TRACE(2);  // table written
     if (p.cells != nullptr) {
       // Fused finalize needs a bound of the slab sums that every workgroup of the layer computes identically:
       // max|codebook| -- the 16 waves' A fragments are the whole codebook -- and max|x| over ALL input groups (an extra
@@ -126,7 +163,9 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
       }
     }
   }
+  LUT_TRACE(3);  // at the barrier
   __syncthreads();
+  LUT_TRACE(4);  // table complete
   // fixed-point unit of the fused finalize: |slab sum| <= 16 groups x 8 codebooks x g x max|cb| x max|x| < 2^e; with
   // sh = 41 - e - ceil(log2(nslabs)) the nslabs addends of a row stay below 2^42 (the sum field is bits 63..20)
   int sh = 0;
@@ -145,69 +184,101 @@ __device__ __forceinline__ void gemv_8x8_lut_body(const LutParams& p, const int 
     sh = 41 - e - (32 - __builtin_clz((unsigned)(p.nslabs > 1 ? p.nslabs - 1 : 1)));
   }
 
-  // ---- rows: lane = input group j0 + l16 (8 code bytes), quarter-wave = one row
-  const float* const my = lut + l16 * (LUT_KC * 256);
+  // ---- rows.  Per step and half-wave: 4 v_perm_b32 (LDS address = {0, base byte 2, code byte, base byte 0}), 4
+  // ds_read_b32, 3 adds, a 32-lane DPP sum (the total lands in the half's upper DPP row), and one DPP shift that files
+  // the total in a 16-deep per-row shift register: after a batch of <= 16 steps lane 16 + i of a half holds the total of
+  // the batch's step (count - 1 - i), and ONE vector pass hands all of them in (store, or fixed-point atomic + settle).
+  uint32_t base[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) base[k] = (uint32_t)((k & 1) * 128 + s32 * 4 + (k >> 1) * 65536);
   float* const out = p.partial + (size_t)slab * p.M + row_begin;
-  // Fused finalize: lane 0 of a quarter-wave adds the row's slab sum to the row's cell as a fixed-point integer (bits
-  // 63..20; +1 in the arrival counter, bits 9..0; +1 in bits 19..10 if the value is not finite) with ONE returning
-  // atomic -- integer adds commute, so the total is independent of the arrival order -- and whoever finds
-  // nslabs - 1 earlier arrivals applies scale and bias, rounds once, writes y and zeroes the cell.  The returned values
-  // of a round are looked at one round later, so the atomics' round trip hides behind the next rows' table reads.
-  unsigned long long pend_old[4], pend_mine[4];
-  uint16_t pend_scale[4] = {0, 0, 0, 0}, pend_bias[4] = {0, 0, 0, 0};  // requested with the atomic: behind the last-arrival test they
-  int pend_row[4] = {-1, -1, -1, -1};                                  // were a second round trip at the very end of the kernel
+  // Fused finalize: the owner lane adds the row's slab sum to the row's cell as a fixed-point integer (bits 63..20; +1
+  // in the arrival counter, bits 9..0; +1 in bits 19..10 if the value is not finite) with ONE returning atomic -- integer
+  // adds commute, so the total is independent of the arrival order -- and whoever finds nslabs - 1 earlier arrivals
+  // applies scale and bias, rounds once, writes y and zeroes the cell.  A batch's returned values are looked at behind
+  // the next batch's table reads.
+  unsigned long long pend_old = 0ull, pend_mine = 0ull;
+  uint16_t pend_scale = 0, pend_bias = 0;  // requested with the atomic: behind the last-arrival test they would be a second round trip
+  int pend_row = -1;
   const uint16_t* const bias_src = p.bias ? p.bias : p.scales;
-  auto settle = [&](int k) {
-    if (pend_row[k] >= 0 && (pend_old[k] & 1023ull) == (unsigned long long)(p.nslabs - 1)) {
-      const int row = pend_row[k];
-      const unsigned long long cell = pend_old[k] + pend_mine[k];
+  auto settle = [&]() {
+    if (pend_row >= 0 && (pend_old & 1023ull) == (unsigned long long)(p.nslabs - 1)) {
+      const unsigned long long cell = pend_old + pend_mine;
       float sv = (float)ldexp((double)((long long)cell >> 20), -sh);
       if ((cell >> 10) & 1023ull) sv = __builtin_nanf("");
-      const float scale = T::to_float(pend_scale[k]);
-      const float bias = p.bias ? T::to_float(pend_bias[k]) : 0.f;
-      p.y[row] = T::from_float(__builtin_fmaf(sv, scale, bias));
-      __hip_atomic_store(p.cells + row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float scale = T::to_float(pend_scale);
+      const float bias = p.bias ? T::to_float(pend_bias) : 0.f;
+      p.y[pend_row] = T::from_float(__builtin_fmaf(sv, scale, bias));
+      __hip_atomic_store(p.cells + pend_row, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    pend_row[k] = -1;
+    pend_row = -1;
   };
-  for (int rbase = r0; __any(rbase < nrows); rbase += 256) {
+  const bool owner = (lane & 16) != 0;  // the upper DPP row of each half holds the totals
+  typedef __attribute__((address_space(3))) const float* lds_f32_ptr;
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();  // LDS map above starts at 0
+  float chain = 0.f;
+  int filed = 0;  // steps in the shift register
+  // four steps, straight-line (ring slots S .. S + 3); steps past the end read zeros and are never handed in
+  auto quad = [&](auto slot0, int sb) {
+    constexpr int S = decltype(slot0)::value;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = rbase + 64 * k;
-      const u32x2 cw = cq[k];
-      cq[k] = load_codes(r + 256);  // next round's codes for this slot
-      float acc = 0.f;
-      if (group_ok) {
-        acc += my[0 * 256 + (cw.x & 0xffu)];
-        acc += my[1 * 256 + ((cw.x >> 8) & 0xffu)];
-        acc += my[2 * 256 + ((cw.x >> 16) & 0xffu)];
-        acc += my[3 * 256 + (cw.x >> 24)];
-        acc += my[4 * 256 + (cw.y & 0xffu)];
-        acc += my[5 * 256 + ((cw.y >> 8) & 0xffu)];
-        acc += my[6 * 256 + ((cw.y >> 16) & 0xffu)];
-        acc += my[7 * 256 + (cw.y >> 24)];
-      }
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t cw = cq[S + t];
+      cq[S + t] = load_codes(sb + t + RING);
+      const float a0 = *(lds_f32_ptr)(uintptr_t)lut_perm(cw, base[0], 0x0c020400u);
+      const float a1 = *(lds_f32_ptr)(uintptr_t)lut_perm(cw, base[1], 0x0c020500u);
+      const float a2 = *(lds_f32_ptr)(uintptr_t)lut_perm(cw, base[2], 0x0c020600u);
+      const float a3 = *(lds_f32_ptr)(uintptr_t)lut_perm(cw, base[3], 0x0c020700u);
+      float acc = (a0 + a1) + (a2 + a3);
+      acc = group_ok ? acc : 0.f;
       acc = row16_sum(acc);
-      if (p.cells == nullptr) {
-        if (l16 == 0 && r < nrows) out[r] = acc;
-      } else {
-        settle(k);  // the previous round's atomic of this slot
-        if (l16 == 0 && r < nrows) {
-          const bool finite = bound < __builtin_inff() && fabsf(acc) <= 2.f * bound;  // false for NaN / Inf anywhere
-          const long long q = finite ? __float2ll_rn(ldexpf(acc, sh)) : 0ll;
-          pend_mine[k] = ((unsigned long long)q << 20) + (finite ? 1ull : 1025ull);
-          pend_row[k] = row_begin + r;
-          pend_old[k] = __hip_atomic_fetch_add(p.cells + pend_row[k], pend_mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          pend_scale[k] = p.scales[pend_row[k]];
-          pend_bias[k] = bias_src[pend_row[k]];
-        }
+      acc += dpp_f32<0x142>(acc);  // row_bcast:15 -- the upper row of each half now holds the 32-lane total
+      chain = lut_shift_in(acc, chain);
+    }
+  };
+  // lane 16 + i (48 + i) of the wave holds the row of step `done` - 1 - i, i < filed
+  auto hand_in = [&](int done) {
+    const int i = lane & 15;
+    const int r = rfirst + 32 * (done - 1 - i);
+    const bool mine = owner && i < filed && r < nrows;
+    if (p.cells == nullptr) {
+      if (mine) out[r] = chain;
+    } else {
+      settle();  // the previous batch's atomics
+      if (mine) {
+        const bool finite = bound < __builtin_inff() && fabsf(chain) <= 2.f * bound;  // false for NaN / Inf anywhere
+        const long long q = finite ? __float2ll_rn(ldexpf(chain, sh)) : 0ll;
+        pend_mine = ((unsigned long long)q << 20) + (finite ? 1ull : 1025ull);
+        pend_row = row_begin + r;
+        pend_old = __hip_atomic_fetch_add(p.cells + pend_row, pend_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_scale = p.scales[pend_row];
+        pend_bias = bias_src[pend_row];
       }
     }
+    filed = 0;
+  };
+  LUT_TRACE(5);  // walk starts
+  for (int sb = 0; sb < nsteps;) {
+    quad(std::integral_constant<int, 0>{}, sb);
+    sb += 4;
+    filed += 4;
+    if (filed == 16 || sb >= nsteps) hand_in(sb);
+    if (sb >= nsteps) break;
+    quad(std::integral_constant<int, 4>{}, sb);
+    sb += 4;
+    filed += 4;
+    if (filed == 16 || sb >= nsteps) hand_in(sb);
   }
-  if (p.cells != nullptr) {
+  LUT_TRACE(6);  // rows handed in (atomics in flight)
+  if (p.cells != nullptr) settle();
+#ifdef AQLM_LUT_TRACE
+  tr[7] = wall_clock64();
+  if (lane == 0 && p.cells != nullptr) {
+    unsigned long long* const out_tr = p.cells + ((p.M + 1023) & ~1023) + ((size_t)block * 16 + wave) * 8;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) settle(k);
+    for (int i = 0; i < 8; ++i) out_tr[i] = tr[i];
   }
+#endif
 }
 
 // scalar arguments (13 dwords): preloaded into SGPRs at wave launch, no kernel-argument fetch at the head of the kernel

@@ -63,6 +63,13 @@ class SharedInputGroup:
         self._fast_group = None      # compiled launch of the group (csrc_front FastGroup), valid for exactly these lanes:
         self._fast_group_of = None   # ids of the members' FastLinear objects it was built from
 
+    def __getstate__(self):
+        """Copies and pickles carry the membership only: parked outputs and the compiled group launch (a pybind11 object) are
+        rebuilt by the copy at its first call."""
+        state = dict(self.__dict__)
+        state.update({"_input": None, "_version": -1, "_pending": {}, "_fast_group": None, "_fast_group_of": None})
+        return state
+
     def applicable(self, input: torch.Tensor) -> bool:
         if not input.is_cuda or math.prod(input.shape[:-1]) > GEMV_MAX_ROWS:
             return False

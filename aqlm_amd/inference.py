@@ -75,6 +75,23 @@ class QuantizedLinear(nn.Module):
         self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
         self._fast = None  # compiled fast lane of the decode call (aqlm_amd/_front.py); derived, rebuilt with the kernel choice
 
+    # Everything the module derives from its parameters (kernel choice, autograd ops, prepacked / permuted codes, the compiled
+    # fast lane -- a pybind11 object that cannot be pickled) is left out of copies and pickles: `copy.deepcopy(model)`,
+    # `torch.save(model)` and `pickle` work at any time (EMA copies, PEFT `modules_to_save`, draft-model clones), and the copy
+    # rebuilds its derived state at its first forward.  A module whose canonical codes were dropped hands them back to the copy.
+    _DERIVED_DEFAULTS = {"gemv_op": None, "gemm_op": None, "use_gemv_rule": None, "_fast": None, "_packed_codes": None,
+                         "_packed_fingerprint": None, "_cpu_codes_alt": None, "_prepack_deferred": False}
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        if self._codes_dropped:
+            params = state["_parameters"].copy()
+            params["codes"] = nn.Parameter(self._canonical_codes(), requires_grad=False)
+            state["_parameters"] = params
+            state["_codes_dropped"] = False
+        state.update(self._DERIVED_DEFAULTS)
+        return state
+
     def extra_repr(self) -> str:
         return (f"in_features={self.in_features}, out_features={self.out_features}, scheme="
                 f"{self.num_codebooks}x{self.nbits_per_codebook}g{self.in_group_size}, bias={self.bias is not None}")

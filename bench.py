@@ -46,6 +46,10 @@ def algorithmic_bytes(fin, fout, K=1, nbits=16, g=8, batch=1, bias=False):
     return n
 
 
+# load-time price of the prepacked path over every layer built so far (reset by main() around the timed workload)
+PREPACK_STATS = {"seconds": 0.0, "layers": 0, "packed_bytes": 0, "canonical_code_bytes": 0, "weights": 0}
+
+
 class Layer:
     """One synthetic QuantizedLinear instance resident in HBM (mirrors benchmark/matmul_benchmark.py:83-97:
     uniform random codes, randn codebooks, scales = 1, no bias)."""
@@ -75,8 +79,16 @@ class Layer:
         """One-off load-time repack for the slice-bucketed decode kernel (layers with >= PACK_MIN_OUT codes)."""
         from aqlm_amd.inference_kernels import hip_kernel as hk
 
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         self.packed = hk.prepack_1x16(self.codes, self.g, codebooks=self.codebooks)  # + the codebook range: single-kernel matvecs
+        torch.cuda.synchronize()
+        PREPACK_STATS["seconds"] += time.perf_counter() - t0
         if self.packed is not None:
+            PREPACK_STATS["layers"] += 1
+            PREPACK_STATS["packed_bytes"] += int(self.packed.buf.numel() * self.packed.buf.element_size())
+            PREPACK_STATS["canonical_code_bytes"] += int(self.codes.numel() * self.codes.element_size())
+            PREPACK_STATS["weights"] += self.fin * self.fout
             nb = self.x.shape[0]
             self.ws = torch.empty((self.packed.slices * nb * self.fout,), dtype=torch.float32, device=self.codes.device)
 
@@ -501,6 +513,34 @@ def sharded_70b(lib, dev, rank, world, steps):
     return out
 
 
+def launcher_command(gpus, argv, port=None):
+    """The command `python bench.py --gpus N` re-executes itself as when it was not started by torch.distributed.run
+    (the driver's own form: one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    import socket
+
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_probe(world, rank):
+    """AQLM_BENCH_LAUNCH_PROBE=1: exercise only the launcher path (self-launch, rendezvous, one collective) on the gloo backend --
+    the CPU test of `python bench.py --gpus N` (tests/test_tools.py); no GPU, no kernels."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_probe": True, "world": dist.get_world_size(), "sum_of_ranks_plus_1": float(t)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -514,9 +554,19 @@ def main():
     if args.no_packed:
         PACK_MIN_OUT = 0
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one process per GPU over RCCL); the driver's
+        # `python -m torch.distributed.run ... bench.py --gpus N` arrives with WORLD_SIZE set and skips this
+        cmd = launcher_command(args.gpus, sys.argv[1:])
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched by torch.distributed.run with another --nproc-per-node?)")
+    if os.environ.get("AQLM_BENCH_LAUNCH_PROBE") == "1":
+        return launch_probe(world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback path")
     torch.cuda.set_device(local_rank)
@@ -527,7 +577,6 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from aqlm_amd import _native  # raises if libaqlm_hip.so is missing
 
@@ -541,6 +590,7 @@ def main():
         layers.append(Layer(4096, 11008, 1, 16, 8, rank * 10000 + 2 * i + 1, dev))
     step = GraphedPass(layers, lib)
     torch.cuda.synchronize()
+    prepack = dict(PREPACK_STATS)  # the 64 layers of the timed workload only
 
     # ---- W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides
     with torch.cuda.stream(step.stream):
@@ -606,21 +656,38 @@ def main():
                    "scheme": "1x16g8", "batch": 1, "layers_per_step": step.n, "algorithmic_bytes_per_step": step.bytes,
                    "kernels": ("prepacked slice-bucketed gemv (layers of >= 0.5 M codes: both shapes); the direct L2-gather gemv "
                                "serves smaller layers and --no-packed" if PACK_MIN_OUT else "direct L2-gather gemv"),
-                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+                   # the load-time and memory price of the prepacked path for these 64 layers (outside the timed region)
+                   "prepack_s_total": prepack["seconds"], "prepack_ms_per_layer": prepack["seconds"] * 1e3 / max(1, prepack["layers"]),
+                   "packed_bytes": prepack["packed_bytes"], "canonical_code_bytes": prepack["canonical_code_bytes"],
+                   "bits_per_weight_resident": {
+                       "packed_only": 8.0 * prepack["packed_bytes"] / max(1, prepack["weights"]),
+                       "packed_plus_canonical": 8.0 * (prepack["packed_bytes"] + prepack["canonical_code_bytes"]) / max(1, prepack["weights"]),
+                       "canonical_only": 8.0 * prepack["canonical_code_bytes"] / max(1, prepack["weights"])} if prepack["layers"] else None},
         "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
         "roofline": roofline,
     }
 
-    # ---- outside the timed region: every output of the step against the generic kernel (a different code path) ----
+    # ---- outside the timed region: the step's outputs against the CPU ORACLE (oracle/aqlm_oracle.c, the restated reference
+    # path -- checker only) on one layer of each shape, and against the generic HIP kernel (a different code path) as well ----
     from aqlm_amd.inference_kernels import hip_kernel as hk
 
-    parity = {}
+    parity, parity_oracle = {}, {}
     for L in (layers[0], layers[1]):
         ref = hk.generic_matmat(L.x[:1], L.codes, L.codebooks, L.scales.reshape(-1, 1, 1, 1), None).float()
         got = L.y[:1].float()
         parity[f"{L.fin}x{L.fout}"] = float((got - ref).abs().mean() / ref.abs().mean())
+        if rank == 0:
+            from oracle import c_oracle
+
+            k = c_oracle.DequantGemv(L.codebooks.float().cpu().numpy(), L.codes.cpu().numpy(), L.scales.float().cpu().numpy(), None, 16,
+                                     nthreads=c_oracle.max_threads())
+            y_or = torch.from_numpy(np.array(k(L.x[0].float().cpu().numpy()), copy=True))
+            parity_oracle[f"{L.fin}x{L.fout}"] = float((got[0].cpu() - y_or).abs().mean() / y_or.abs().mean())
     result["parity_mean_rel_vs_generic_kernel"] = parity
+    result["parity_mean_rel_vs_cpu_oracle"] = parity_oracle
     assert all(v < 1e-3 for v in parity.values()), f"bench outputs are off: {parity}"
+    assert all(v < 1e-3 for v in parity_oracle.values()), f"bench outputs differ from the CPU oracle: {parity_oracle}"
 
     # ---- untimed breakdown (rank 0 prints; every rank runs the collectives inside)
     if not args.no_detail:
@@ -752,10 +819,8 @@ def main():
         result["detail"] = detail
         result["sharded_70b"] = sharded_70b(lib, dev, rank, world, args.steps)
 
-    if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline()
-    elif rank == 0:
-        result["cpu_baseline"] = None
+    if rank == 0:  # rank 0 at every N (the other ranks wait at the barrier below; outside every timed region)
+        result["cpu_baseline"] = None if args.no_cpu else cpu_baseline()
 
     if rank == 0:
         print(json.dumps(result))

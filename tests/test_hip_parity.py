@@ -1856,3 +1856,50 @@ def test_pipelined_shared_input_launch(hk, outs, fin, dt, waves):
     torch.cuda.synchronize()
     for k in range(len(outs)):
         assert torch.equal(captured[k], singles[k])
+
+
+def test_gpu_modules_copy_and_pickle_after_a_forward(hk):
+    """ADVICE round 3: a module that has run on the GPU holds a pybind11 fast lane (and a fused group a compiled launch);
+    deepcopy / pickle / torch.save must work at any time, the copy must not share derived state with the original, and a
+    module whose canonical codes were dropped must hand them to the copy."""
+    import copy
+    import io
+    import pickle
+
+    import aqlm
+    from aqlm.checkpoint import prepack_model
+
+    fin = 2048
+    holder = torch.nn.Module()
+    Ls = {}
+    for k, (n, fo) in enumerate([("q_proj", 1536), ("k_proj", 512), ("v_proj", 512)]):
+        Ls[n] = orc.make_layer(4300 + k, fin, fo, 1, 16, 8, batch=2, bias=(k == 0))
+        m, T = _module_from(Ls[n], 1, 16, 8, fin, fo, torch.float16)
+        setattr(holder, n, m)
+    x = to_dev(Ls["q_proj"], torch.float16)["x"][:1].contiguous()
+    prepack_model(holder, min_codes=100_000)
+    aqlm.fuse_shared_input_linears(holder)
+    with torch.no_grad():
+        want = {n: getattr(holder, n)(x) for n in Ls}
+        assert holder.q_proj._packed_codes is not None
+        clones = [copy.deepcopy(holder), pickle.loads(pickle.dumps(holder))]
+        buf = io.BytesIO()
+        torch.save(holder, buf)
+        buf.seek(0)
+        clones.append(torch.load(buf, weights_only=False))
+        for c in clones:
+            assert c.q_proj._fast is None and c.q_proj._packed_codes is None and c.q_proj.gemv_op is None
+            g = c.q_proj._shared_input_group
+            assert g is not None and g.members[0] is c.q_proj and g.members[1] is c.k_proj and g._fast_group is None
+            assert c.q_proj.codes.data_ptr() != holder.q_proj.codes.data_ptr()
+            for n in Ls:
+                assert torch.equal(getattr(c, n)(x), want[n]), n
+        # dropped canonical codes travel with the copy
+        prepack_model(holder, min_codes=100_000, drop_canonical=True)
+        assert holder.q_proj._codes_dropped
+        c = copy.deepcopy(holder)
+        assert not c.q_proj._codes_dropped and tuple(c.q_proj.codes.shape) == (1536, fin // 8, 1)
+        assert torch.equal(c.q_proj.codes, to_dev(Ls["q_proj"], torch.float16)["codes"])
+        for n in Ls:
+            assert torch.equal(getattr(c, n)(x), want[n]), n
+            assert torch.equal(getattr(holder, n)(x), want[n]), n

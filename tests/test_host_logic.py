@@ -241,3 +241,30 @@ def test_checkpoint_tooling_validates_and_upgrades_configs():
     assert rep["quantized_linears"] == 1 and rep["codes"] == 32 * 8 * 2 and rep["prepacked"] == 0
     with pytest.raises(NotImplementedError):
         prepack_model(torch.nn.Sequential(m))
+
+
+@pytest.mark.parametrize("K,nbits,g", [(2, 8, 8), (1, 16, 8)])
+def test_module_copies_and_pickles_after_a_forward_cpu(K, nbits, g):
+    """after the first forward the module holds derived state (autograd ops, a lambda, permuted codes and, on
+    the GPU, a pybind11 fast lane); `copy.deepcopy`, `pickle` and `torch.save(module)` must still work and the copy must compute
+    the same thing."""
+    import copy
+    import io
+    import pickle
+
+    m = aqlm.QuantizedLinear(256, 64, g, 1, K, nbits, bias=True, dtype=torch.float32)
+    L = orc.make_layer(5, 256, 64, K, nbits, g, float_dtype=np.float32)
+    m.load_state_dict({"codes": torch.from_numpy(L["codes"]), "codebooks": torch.from_numpy(L["codebooks"]),
+                       "scales": torch.from_numpy(L["scales"]), "bias": torch.from_numpy(L["bias"])})
+    x = torch.from_numpy(L["x"])
+    y = m(x)
+    assert m.gemv_op is not None
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone.gemv_op is None and clone._fast is None and clone._cpu_codes_alt is None
+        assert torch.equal(clone.codes, m.codes)
+        assert torch.equal(clone(x), y)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    assert torch.equal(torch.load(buf, weights_only=False)(x), y)
+    assert m.gemv_op is not None  # the original keeps its derived state

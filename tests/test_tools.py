@@ -60,3 +60,29 @@ def test_arrangement_bound_orders_and_bound_are_consistent():
         want = sorted(zip(c[sel].ravel().tolist(), x[sel].ravel().tolist()))
         assert sorted(zip(gc[sel].ravel().tolist(), gx[sel].ravel().tolist())) == want
         assert sorted(zip(ac[sel].ravel().tolist(), ax[sel].ravel().tolist())) == want
+
+
+def test_bench_self_launches_under_torch_distributed_run():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must re-execute itself under torch.distributed.run with one
+    rank per GPU; AQLM_BENCH_LAUNCH_PROBE=1 stops each rank after the rendezvous and one gloo collective, so the launcher path is
+    covered without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AQLM_BENCH_LAUNCH_PROBE"] = "1"
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                                  cwd=ROOT, env=env, timeout=300, stderr=subprocess.DEVNULL)
+    res = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
+    assert res == {"launch_probe": True, "world": 2, "sum_of_ranks_plus_1": 3.0}
+
+
+def test_bench_launcher_command_is_the_drivers_form():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "5"], port=29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    # a mismatch between --gpus and the launcher's world size is reported, not asserted
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, timeout=300)
+    assert p.returncode != 0 and b"WORLD_SIZE=3" in p.stderr

@@ -602,6 +602,44 @@ static void bench_gemv(int argc, char** argv) {
   }
 }
 
+// ---------------------------------------------------------------- phase trace of the look-up-table kernel (trace build only)
+// Needs the library built with -DAQLM_LUT_TRACE (make trace): every wave stamps wall_clock64 (100 MHz) behind the cells.
+static void bench_lut_trace(int in, int out, int g) {
+  g_ws_bytes = (size_t)64 << 20;
+  CK(hipMalloc(&g_ws, g_ws_bytes));
+  CK(hipMemset(g_ws, 0, g_ws_bytes));
+  const Scheme s{"8x8LUT", 8, 8, g, false, false, true};
+  const size_t ab1 = algo_bytes(in, out, s, 1);
+  int n = (int)((600u << 20) / ab1) + 1;
+  if (n > 160) n = 160;
+  auto layers = make_layers(s, in, out, 1, n);
+  unsigned long long* tr = (unsigned long long*)g_ws + ((out + 1023) & ~1023);
+  const int in_groups = in / g, nslabs = (in_groups + 15) / 16, nranges = std::max(1, 256 / nslabs), nblocks = nslabs * nranges;
+  std::vector<unsigned long long> h((size_t)nblocks * 16 * 8);
+  const char* names[8] = {"entry", "loads issued", "table written", "at the barrier", "table complete", "walk starts", "rows handed in", "end"};
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipMemset(tr, 0, h.size() * 8));
+    CK(hipDeviceSynchronize());
+    for (int i = 1; i < n; ++i) launch_layer(s, layers[i], in, out, 1, nullptr);
+    launch_layer(s, layers[0], in, out, 1, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < h.size(); i += 8) if (h[i]) t0 = std::min(t0, h[i]);
+    printf("# 8x8g%d look-up-table kernel %d->%d cold, run %d (%d workgroups x 16 waves): us since the first wave's entry (min / mean / max)\n", g, in, out, rep, nblocks);
+    for (int k = 0; k < 8; ++k) {
+      double mn = 1e9, mx = 0, sum = 0; size_t cnt = 0;
+      for (size_t i = 0; i < h.size(); i += 8) {
+        if (!h[i]) continue;
+        const double v = (double)(h[i + k] - t0) * 0.01;
+        mn = std::min(mn, v); mx = std::max(mx, v); sum += v; ++cnt;
+      }
+      printf("  %-16s %7.2f %7.2f %7.2f\n", names[k], mn, cnt ? sum / cnt : 0.0, mx);
+    }
+  }
+  free_layers(layers);
+}
+
 // ---------------------------------------------------------------- phase trace of the packed kernel (trace build only)
 // Needs the library built with -DAQLM_PACKED_TRACE (make trace): the kernel then stamps wall_clock64 (100 MHz) at
 // entry / loads issued / LDS filled / first row done / loop done / end into the workspace tail.
@@ -911,6 +949,7 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "stream") || !strcmp(what, "all")) bench_stream();
   if (!strcmp(what, "rates") || !strcmp(what, "all")) bench_rates();
   if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
+  if (!strcmp(what, "lut_trace")) bench_lut_trace(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 4096, argc > 4 ? atoi(argv[4]) : 32);
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
   if (!strcmp(what, "multi")) bench_multi();
   if (!strcmp(what, "trace")) {
