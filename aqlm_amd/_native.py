@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQLM_AMD_HIP_LIB: another build of the same library (same-box A/B runs of two commits, tools/gpu/r3_ab*.sh); default: in-tree
 LIB_PATH = os.environ.get("AQLM_AMD_HIP_LIB") or os.path.join(_HERE, "libaqlm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
@@ -99,6 +99,11 @@ SIGNATURES = {
     "aqlm_hip_gemv_8x8_lut_multi": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_8x8_lut_fused": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemv_8x8_lut_multi_fused": (_ci, [_segp, _ci, _vp, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_8x8_planar_bytes": (_sz, [_ci, _ci, _ci]),
+    "aqlm_hip_8x8_planar_pack": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_8x8_planar_unpack": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
+    "aqlm_hip_gemv_8x8_lut_planar": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_float, _vp, _sz, _ci, _vp]),
+    "aqlm_hip_gemv_8x8_lut_planar_multi": (_ci, [_segp, ctypes.POINTER(ctypes.c_float), _ci, _vp, _ci, _ci, _ci, _vp, _sz, _ci, _vp]),
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_dequant_1x16": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_dequant_kx8": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]),

@@ -125,18 +125,32 @@ def memory_report(model: torch.nn.Module) -> Dict[str, float]:
     return rep
 
 
-def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_canonical: bool = False) -> Dict[str, float]:
+def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_canonical: bool = False, compact: bool = False,
+                  thorough: bool = False) -> Dict[str, float]:
     """Resolve the kernels and run the load-time repack of every eligible QuantizedLinear now (GPU-resident modules
     only) instead of at its first forward; ``min_codes`` overrides ``inference.PREPACK_MIN_CODES`` for this call.
     ``drop_canonical=True`` (inference-only deployments) frees the checkpoint-layout ``codes`` of every repacked layer:
     the packed buffer is lossless, ``state_dict()`` / large-batch / backward rebuild them on demand.
-    Returns ``memory_report(model)``."""
-    from . import inference
+    ``compact=True`` packs 1x16 g8 layers with 24-bit entries (3.5 instead of 4.5 bytes per code: a 70B model holds 30 GB of
+    packed codes instead of 39; measured 1-5 % slower matvecs).  ``thorough=True`` runs the local search of the entry order on
+    every layer, not only on those of <= 8 Mi codes (1-3 % faster matvecs on the big layers for ~5x their prepack time).
+    Returns ``memory_report(model)`` plus ``prepack_seconds``."""
+    import time
+
+    from . import _native, inference
     from .inference import QuantizedLinear
 
     old = inference.PREPACK_MIN_CODES
     if min_codes is not None:
         inference.PREPACK_MIN_CODES = int(min_codes)
+    old_eb, old_arr = _native.get_tuning("packed_entry_bytes"), _native.get_tuning("packed_arrange")
+    if compact:
+        _native.set_tuning("packed_entry_bytes", 3)
+    if thorough:
+        _native.set_tuning("packed_arrange", 3)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
     try:
         for m in model.modules():
             if isinstance(m, QuantizedLinear):
@@ -147,4 +161,10 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_
                     m.drop_canonical_codes()
     finally:
         inference.PREPACK_MIN_CODES = old
-    return memory_report(model)
+        _native.set_tuning("packed_entry_bytes", old_eb)
+        _native.set_tuning("packed_arrange", old_arr)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    rep = memory_report(model)
+    rep["prepack_seconds"] = time.perf_counter() - t0
+    return rep

@@ -67,6 +67,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "packed_fill_rotate")) return &t.packed_fill_rotate;
   if (!strcmp(key, "packed_pipe")) return &t.packed_pipe;
   if (!strcmp(key, "packed_prefetch_waves")) return &t.packed_prefetch_waves;
+  if (!strcmp(key, "lut_waves")) return &t.lut_waves;
   return nullptr;
 }
 

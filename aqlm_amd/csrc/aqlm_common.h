@@ -156,13 +156,14 @@ struct Tuning {
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)
   int packed_fused_finalize = 1;  // 0 = two-kernel finalize even when the descriptor carries the codebook range (A/B runs)
   int packed_waves = 0;          // prepack: waves per workgroup of the packed 1x16 kernel (4 / 8 / 16); 0 = heuristic
-  int packed_arrange = 1;        // prepack: 1 = bank-aware order of the entries (pk_arrange_kernel + pk_improve_kernel), 2 = greedy deal only, 0 = ascending j
+  int packed_arrange = 1;        // prepack: bank-aware order of the entries: 1 = greedy deal + local search for layers of <= 8 Mi codes, greedy deal alone above; 3 = local search always; 2 = greedy deal only; 0 = ascending j
   int packed_xcopies = 0;        // prepack: rotated copies of x the batch-1 kernel keeps in LDS (1..4, capped by what fits); 0 = 1
   int packed_entry_bytes = 0;    // prepack: 0 / 4 = 32-bit entries; 3 = 24-bit entries (wave ranges of <= 32 steps)
   int packed_debug = 0;          // profiling builds (-DAQLM_PACKED_TRACE) only: 1 = no LDS reads / dots, 2 = no entry stream
   int packed_prefetch = 0;       // packed 1x16 kernel: steps of the entry stream in flight per wave (4 / 8); 0 = heuristic
   int packed_pipe = 1;           // shared-input launches of batch 1: 1 = one workgroup per CU walks the segments with double-buffered slices
   int packed_fill_rotate = 1;    // packed 1x16 kernel: 1 = the workgroups that share a codebook slice start their LDS fill at different pieces
+  int lut_waves = 0;             // 8 x 8 look-up-table matvec: waves per workgroup (8 / 16); 0 = default
   int packed_prefetch_waves = 0; // chain prefetch: extra waves per workgroup that pull the next layer towards L2 (0 = 2, -1 = off)
 };
 Tuning& tuning();

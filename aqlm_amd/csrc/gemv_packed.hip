@@ -437,6 +437,7 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
 // order of decisions as K3b -> deterministic.  Entries are still plain here (parity, flags and row numbers are stamped
 // later), null entries of a cell read one address (two with 32-byte vectors: one per lane parity) and count once.
 constexpr int PK_IMPROVE_SWEEPS = 6;       // most of the gain comes in the first three (3.88 -> 3.34 / 3.23 / 3.16 ... 3.07 cycles)
+constexpr long PK_IMPROVE_MAX_CODES = 8L << 20;  // packed_arrange = 1 (default): layers above this keep the greedy deal alone
 constexpr int PK_IMPROVE_SWEEPS_LONG = 3;  // wave ranges of more than 12 steps: the 70B layers, bound by their entry stream anyway
 
 struct PkHist {
@@ -2214,7 +2215,10 @@ extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features,
   if (arrange)
     hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 256, stream, a,
                        ent, M, in_groups, RG, NW, T, XC);
-  if (arrange && tuning().packed_arrange == 1)  // 2 = the greedy deal alone (A/B runs)
+  // the local search on the greedy deal (1-3 % faster matvec) takes ~10x the greedy deal's time (27 -> 120 ms for a 29 M-code
+  // layer): by default (1) only layers of <= 8 Mi codes get it -- a 70B model then prepacks in ~13 s instead of ~1 min --,
+  // 3 = always, 2 = never
+  if (arrange && (tuning().packed_arrange == 3 || (tuning().packed_arrange == 1 && (long)M * in_groups <= PK_IMPROVE_MAX_CODES)))
     hipLaunchKernelGGL(pk_improve_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * (1024 + 512 + 256 + 32), stream, a, ent, M,
                        in_groups, RG, NW, T);
   if (PK_PARITY_BITS) hipLaunchKernelGGL(pk_parity_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4);

@@ -124,14 +124,16 @@ class SharedInputGroup:
                 return list(res)
         # every member runs on the kernel it would use alone (so outputs stay bit-identical to the unfused modules):
         # prepacked members share one packed launch, the others one direct launch
-        packed_idx = [i for i, m in enumerate(ms) if m._packed_codes is not None and input.dtype == m.codebooks.dtype]
+        single_row = input.numel() == input.shape[-1]
+        packed_idx = [i for i, m in enumerate(ms) if m._packed_codes is not None and input.dtype == m.codebooks.dtype
+                      and (isinstance(m._packed_codes, hip_kernel.PackedCodes) or single_row)]
         direct_idx = [i for i in range(len(ms)) if i not in packed_idx]
         outs: List[Optional[torch.Tensor]] = [None] * len(ms)
         if packed_idx:
             sub = [ms[i] for i in packed_idx]
-            res = hip_kernel.code1x16_matmat_packed_multi(
-                input, [m._packed_codes for m in sub], [m.codebooks for m in sub], [m.scales for m in sub],
-                [m.bias for m in sub])
+            planar = isinstance(sub[0]._packed_codes, hip_kernel.PlanarCodes)  # a group has one scheme: all 1x16 or all 8x8
+            op = hip_kernel.code8x8_matmat_planar_multi if planar else hip_kernel.code1x16_matmat_packed_multi
+            res = op(input, [m._packed_codes for m in sub], [m.codebooks for m in sub], [m.scales for m in sub], [m.bias for m in sub])
             for i, o in zip(packed_idx, res):
                 outs[i] = o
         if direct_idx:

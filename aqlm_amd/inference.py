@@ -114,10 +114,15 @@ class QuantizedLinear(nn.Module):
                 and math.prod(input.shape[:-1]) <= GEMV_MAX_ROWS and not (torch.is_grad_enabled() and input.requires_grad)):
             from .inference_kernels import hip_kernel
 
-            if torch.compiler.is_compiling():  # traced: go through the dispatcher op (it has a fake implementation)
+            if isinstance(packed, hip_kernel.PlanarCodes):
+                # 8x8 on planar codes: the look-up-table matvec takes one row; anything else goes through the ordinary ops below
+                if input.numel() == input.shape[-1] and not torch.compiler.is_compiling():
+                    return hip_kernel.code8x8_matmat_planar(input, packed, self.codebooks, self.scales, self.bias)
+            elif torch.compiler.is_compiling():  # traced: go through the dispatcher op (it has a fake implementation)
                 return torch.ops.aqlm.code1x16_matmat_packed(input, packed.buf, self.codebooks, self.scales, self.bias,
                                                              packed._ints)
-            return hip_kernel.code1x16_matmat_packed(input, packed, self.codebooks, self.scales, self.bias)
+            else:
+                return hip_kernel.code1x16_matmat_packed(input, packed, self.codebooks, self.scales, self.bias)
         op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
         return op.apply(input, self._canonical_codes(), self.codebooks, self.scales, self.bias)
 
@@ -143,9 +148,7 @@ class QuantizedLinear(nn.Module):
         """``codes`` in the checkpoint layout; rebuilt from the prepacked buffer (lossless) when they were dropped."""
         if not self._codes_dropped:
             return self.codes
-        from .inference_kernels import hip_kernel
-
-        return hip_kernel.unpack_1x16(self._packed_codes)
+        return self._packed_codes.unpack()  # lossless inverse of the load-time re-layout (1x16 slices / 8x8 planes)
 
     def drop_canonical_codes(self) -> bool:
         """Inference-only memory saver: free ``codes`` of a prepacked layer (the packed buffer holds the same
@@ -235,6 +238,17 @@ class QuantizedLinear(nn.Module):
 
             self._packed_codes = hip_kernel.prepack_1x16(self.codes, self.in_group_size, codebooks=self.codebooks)
             self._packed_fingerprint = self._codes_fingerprint()
+        elif (PREPACK_MIN_CODES and self.out_features * (self.in_features // self.in_group_size) * 8 >= PREPACK_MIN_CODES
+                and self.num_codebooks == 8 and self.nbits_per_codebook == 8 and self.in_group_size in (8, 16, 32) and self.out_group_size == 1
+                and self.codes.is_cuda and self.codebooks.dtype in (torch.float16, torch.bfloat16)):
+            # 8 x 8-bit schemes: planar copy of the codes for the look-up-table matvec (same size as `codes`, lossless)
+            if torch.cuda.is_current_stream_capturing():
+                self._prepack_deferred = True  # the codebook bound is a host read-back: first forward outside a capture
+                return
+            from .inference_kernels import hip_kernel
+
+            self._packed_codes = hip_kernel.planar_8x8_pack(self.codes, self.in_group_size, codebooks=self.codebooks)
+            self._packed_fingerprint = self._codes_fingerprint()
         self._build_fast_lane()
 
     def _build_fast_lane(self) -> None:
@@ -253,6 +267,8 @@ class QuantizedLinear(nn.Module):
 
         packed = self._packed_codes
         scheme = (self.num_codebooks, self.nbits_per_codebook, self.in_group_size)
+        if packed is not None and not isinstance(packed, hip_kernel.PackedCodes):
+            return  # planar 8x8 codes: Python path (one launch, no compiled lane yet)
         if packed is not None:
             if not (hip_kernel.FUSED_FINALIZE and packed.desc.codebook_absmax > 0.0 and packed.range_is_current(self.codebooks)):
                 return  # two-kernel finalize (needs a workspace): Python path

@@ -91,20 +91,38 @@ def cpu_gemm_lut(input: torch.Tensor, codes_alt: torch.Tensor, codebooks: torch.
     return y.to(input.dtype).reshape(input.shape[:-1] + (out_features,))
 
 
-# fp16 copies of the codebooks for the direct kernel, one per codebook tensor (keyed by id with a weak reference that drops the
-# entry when the tensor dies -- a WeakKeyDictionary would compare tensors with ==), rebuilt when the tensor was written.  None = the values are not fp16-representable (or the CPU lacks F16C): fp32 table.
+# fp16 view of the codebooks for the direct kernel (half the bytes the 65536-entry gathers touch).
+#   * an fp16 parameter (what checkpoints store) is used AS IS: no copy, nothing to go stale;
+#   * any other dtype gets a converted copy, kept per codebook tensor (keyed by id with a weak reference that drops the entry
+#     when the tensor dies -- a WeakKeyDictionary would compare tensors with ==) and used only while it is provably current:
+#     same storage, same version counter AND the same checksum of the source, recomputed on every call (two reductions over
+#     <= 2 MiB, ~2 % of the kernel's time) -- writes through `.data` (older optimizer / loader code: `p.data.copy_()`) do not
+#     bump the version counter, the checksum sees them.  `invalidate_half_tables()` drops every copy.
+#   None = the values are not fp16-representable (or the CPU lacks F16C): fp32 table.
 HALF_TABLE = True
 _HALF_TABLES = {}
+
+
+def invalidate_half_tables() -> None:
+    """Forget every cached fp16 codebook copy (they are rebuilt from the live tensors at the next call)."""
+    _HALF_TABLES.clear()
+
+
+def _checksum(t: torch.Tensor):
+    f = t.detach().reshape(-1).to(torch.float32)
+    return (float(f.sum()), float(f.abs().sum()))
 
 
 def _half_table(codebooks: torch.Tensor) -> Optional[torch.Tensor]:
     if not HALF_TABLE:
         return None
+    if codebooks.dtype == torch.float16:
+        return codebooks.detach().contiguous()  # the live storage itself (contiguous parameters: no copy)
     try:
         version = codebooks._version
     except RuntimeError:  # inference tensors carry no version counter: do not cache what cannot be invalidated
         return None
-    key = (codebooks.data_ptr(), version, codebooks.dtype, tuple(codebooks.shape))
+    key = (codebooks.data_ptr(), version, codebooks.dtype, tuple(codebooks.shape), _checksum(codebooks))
     ident = id(codebooks)
     hit = _HALF_TABLES.get(ident)
     if hit is not None and hit[0]() is codebooks and hit[1] == key:

@@ -159,6 +159,9 @@ class PackedCodes:
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
 
+    def unpack(self) -> torch.Tensor:
+        return unpack_1x16(self)
+
     @property
     def device(self):
         return self.buf.device
@@ -525,13 +528,13 @@ def code1x16_matmat_packed_multi(input, packed, codebooks, scales, bias):
 # keeps that derived buffer itself; callers of the raw op -- the reference's own benchmark/matmul_benchmark.py:103, vLLM-style
 # integrations -- get it from this cache: keyed by the identity of the `codes` tensor object (a weak reference drops the
 # entry when the tensor dies, so an address reused by a new tensor can never alias it), validated on every hit against
-# (data_ptr, _version, shape), bounded in bytes.  A caller that passes a fresh view object on every call never hits: after
+# (data_ptr, _version, shape), bounded in bytes (RAW_OP_PREPACK_MAX_BYTES, 1 GiB, least recently used evicted).  A caller that passes a fresh view object on every call never hits: after
 # RAW_OP_PREPACK_MAX_MISSES packs without a single hit the cache switches itself off.  Nothing is packed while a hipGraph is
 # being captured (the pack synchronises); outputs equal the direct kernel's up to fp32 summation order.
 MATMAT_GEMM_MIN_ROWS = 7              # rows (batch x sequence) from which aqlm::code1x16_matmat runs the MFMA kernel (= the module's gemv rule + 1)
 RAW_OP_PREPACK = True                 # set False to keep the raw op on the direct kernel
 RAW_OP_PREPACK_MIN_CODES = 500_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
-RAW_OP_PREPACK_MAX_BYTES = 4 << 30  # of packed buffers held for callers of the raw op (modules keep their own)
+RAW_OP_PREPACK_MAX_BYTES = 1 << 30  # of packed buffers held for callers of the raw op (modules keep their own); least recently used go first
 RAW_OP_PREPACK_MAX_MISSES = 8
 _RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None)
 _RAW_STATS = {"bytes": 0, "packs_without_hit": 0, "hits": 0, "packs": 0}
@@ -570,6 +573,7 @@ def _raw_packed_for(codes, codebooks, input):
             if entry[2] is not None:
                 _RAW_STATS["hits"] += 1
                 _RAW_STATS["packs_without_hit"] = 0
+                _RAW_PACKED[key] = _RAW_PACKED.pop(key)  # most recently used last (dicts keep insertion order)
             return entry[2]
         _raw_drop(key)  # the tensor was modified in place / rebound: pack again
     if (_RAW_STATS["packs_without_hit"] >= RAW_OP_PREPACK_MAX_MISSES or torch.cuda.is_current_stream_capturing()
@@ -580,7 +584,14 @@ def _raw_packed_for(codes, codebooks, input):
     packed = None
     g = int(codebooks.shape[3])
     cap = _lib.aqlm_hip_prepack_1x16_bytes(codes.shape[0], codes.shape[1] * g, g)
-    if cap and _RAW_STATS["bytes"] + cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
+    if cap and cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
+        # bounded: the least recently used packed buffers make room (a caller cycling through more layers than fit keeps
+        # repacking -- `packs_without_hit` then switches the cache off -- and should hold PackedCodes itself, like the module)
+        for old in list(_RAW_PACKED):
+            if _RAW_STATS["bytes"] + cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
+                break
+            if _RAW_PACKED[old][2] is not None:
+                _raw_drop(old)
         packed = prepack_1x16(codes, g)
     try:
         ref = weakref.ref(codes, lambda _r, k=key: _raw_drop(k))
@@ -659,6 +670,178 @@ def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
     if rc:
         _native.check(rc, "aqlm gemv_8x8_lut")
     return y.reshape(input.shape[:-1] + (out_features,))
+
+
+# ------------------------------------------------------------------------------------------------------
+# planar 8 x 8-bit codes (aqlm_hip_8x8_planar_pack): [8][out][in_groups rounded up to 4] bytes, the checkpoint's
+# [out][in_groups][8] transposed.  A workgroup of the look-up-table matvec then serves ONE codebook x 128 input groups: 16 KiB
+# of codebook instead of 128 KiB through its L1, its codes as 128 contiguous bytes per row.  Same size as the canonical codes,
+# lossless; derived at load time like the prepacked 1x16 buffer (the reference permutes its codes for the CPU look-up kernel
+# in the same place, inference.py:78-83).
+# ------------------------------------------------------------------------------------------------------
+PLANAR_8X8_MIN_GROUPS = 64  # input groups below which a 128-group slab would be mostly empty: canonical layout
+
+
+class PlanarCodes:
+    """8x8 codes in the planar layout + the codebook bound the single-kernel finalize needs."""
+
+    __slots__ = ("buf", "out_features", "in_features", "in_group_size", "codebook_absmax", "_range_of")
+
+    def __init__(self, buf: torch.Tensor, out_features: int, in_features: int, in_group_size: int):
+        self.buf = buf
+        self.out_features, self.in_features, self.in_group_size = out_features, in_features, in_group_size
+        self.codebook_absmax = 0.0
+        self._range_of = None
+
+    def set_codebook_range(self, codebooks: torch.Tensor) -> None:
+        absmax = float(codebooks.detach().abs().max().float().item())
+        self.codebook_absmax = absmax if absmax == absmax and absmax != float("inf") else 0.0
+        self._range_of = (codebooks.data_ptr(), _version(codebooks))
+
+    def range_is_current(self, codebooks: torch.Tensor) -> bool:
+        return self._range_of == (codebooks.data_ptr(), _version(codebooks))
+
+    def numel(self) -> int:  # bytes held
+        return self.buf.numel()
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def unpack(self) -> torch.Tensor:
+        return planar_8x8_unpack(self)
+
+
+def planar_8x8_pack(codes: torch.Tensor, in_group_size: int, codebooks: Optional[torch.Tensor] = None) -> Optional[PlanarCodes]:
+    """Planar copy of 8x8 codes [out, in/g, 8] (int8); None when the layout does not pay (few input groups)."""
+    if codes.dim() != 3 or codes.shape[2] != 8 or codes.dtype != torch.int8 or not codes.is_cuda:
+        return None
+    out_features, in_groups = codes.shape[0], codes.shape[1]
+    if in_groups < PLANAR_8X8_MIN_GROUPS:
+        return None
+    in_features = in_groups * in_group_size
+    nbytes = _lib.aqlm_hip_8x8_planar_bytes(out_features, in_features, in_group_size)
+    if nbytes == 0:
+        return None
+    codes = _c(codes)
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=codes.device)
+    with torch.cuda.device(codes.device):
+        rc = _lib.aqlm_hip_8x8_planar_pack(codes.data_ptr(), out_features, in_features, in_group_size, buf.data_ptr(), nbytes,
+                                           _stream_ptr(codes.device))
+    if rc:
+        _native.check(rc, "aqlm 8x8_planar_pack")
+    planar = PlanarCodes(buf, out_features, in_features, in_group_size)
+    if codebooks is not None and not torch.cuda.is_current_stream_capturing():
+        planar.set_codebook_range(codebooks)
+    return planar
+
+
+def planar_8x8_unpack(planar: PlanarCodes) -> torch.Tensor:
+    """The canonical codes [out, in/g, 8] (int8) of a planar buffer (aqlm_hip_8x8_planar_unpack; lossless)."""
+    codes = torch.empty((planar.out_features, planar.in_features // planar.in_group_size, 8), dtype=torch.int8, device=planar.device)
+    with torch.cuda.device(planar.device):
+        rc = _lib.aqlm_hip_8x8_planar_unpack(planar.data_ptr(), planar.out_features, planar.in_features, planar.in_group_size,
+                                             codes.data_ptr(), _stream_ptr(planar.device))
+    if rc:
+        _native.check(rc, "aqlm 8x8_planar_unpack")
+    return codes
+
+
+def _planar_refresh(planar: PlanarCodes, codebooks: torch.Tensor) -> None:
+    """Keep the codebook bound in step with the tensor the op is called with; nothing can be read back while a hipGraph is being
+    captured: an unknown bound then means the two-kernel form for that call."""
+    if planar.range_is_current(codebooks):
+        return
+    if torch.cuda.is_current_stream_capturing() or torch.compiler.is_compiling():
+        planar.codebook_absmax, planar._range_of = 0.0, None
+        return
+    planar.set_codebook_range(codebooks)
+
+
+def _check_planar_args(input, planar, codebooks, scales):
+    if codebooks.dtype != input.dtype or scales.dtype != input.dtype:
+        raise NotImplementedError(f"input dtype {input.dtype} must match codebooks/scales dtype {codebooks.dtype}")
+    if tuple(codebooks.shape) != (8, 256, 1, planar.in_group_size):
+        raise NotImplementedError(f"planar codes of an 8x8 g{planar.in_group_size} layer need codebooks [8, 256, 1, {planar.in_group_size}], got {tuple(codebooks.shape)}")
+    if input.shape[-1] != planar.in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {planar.in_features}")
+    if input.device != planar.device or codebooks.device != input.device:
+        raise ValueError(f"input on {input.device}, layer on {planar.device}")
+    if input.numel() != input.shape[-1]:
+        raise NotImplementedError("the look-up-table matvec takes one input row")
+    return _dtype_id(input)
+
+
+def code8x8_matmat_planar(input, planar: PlanarCodes, codebooks, scales, bias=None):
+    """Single-row 8x8 matvec on planar codes (aqlm_hip_gemv_8x8_lut_planar); same contract as codekx8_matmat."""
+    dt = _check_planar_args(input, planar, codebooks, scales)
+    x = _flat_rows(input)
+    codebooks, scales = _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    out_features, in_features, g = planar.out_features, planar.in_features, planar.in_group_size
+    y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
+    stream = _stream_ptr(input.device)
+    _planar_refresh(planar, codebooks)
+    cells = _lut_cells(input.device, stream, out_features) if planar.codebook_absmax > 0.0 else None
+    with _device_guard(input.device):
+        if cells is not None:
+            rc = _lib.aqlm_hip_gemv_8x8_lut_planar(planar.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(),
+                                                   y.data_ptr(), out_features, in_features, g, dt, planar.codebook_absmax,
+                                                   cells.data_ptr(), cells.numel() * 8, 1, stream)
+        else:
+            ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, out_features, in_features)
+            ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
+            rc = _lib.aqlm_hip_gemv_8x8_lut_planar(planar.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(),
+                                                   y.data_ptr(), out_features, in_features, g, dt, 0.0, ws.data_ptr(), ws_bytes, 0, stream)
+    if rc:
+        _native.check(rc, "aqlm gemv_8x8_lut_planar")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
+def code8x8_matmat_planar_multi(input, planar, codebooks, scales, bias):
+    """Several planar 8x8 layers times one input row in ONE launch (aqlm_hip_gemv_8x8_lut_planar_multi); bit-identical to
+    code8x8_matmat_planar per layer."""
+    n = len(planar)
+    if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == n):
+        raise ValueError(f"code8x8_matmat_planar_multi takes 1..{_native.MAX_SEGMENTS} layers with one entry per list")
+    x = _flat_rows(input)
+    segs = (_native.Segment * n)()
+    absmax = (ctypes.c_float * n)()
+    keep, outs = [], []
+    dt, ws_bytes = None, 0
+    g, in_features = planar[0].in_group_size, planar[0].in_features
+    for k in range(n):
+        dt = _check_planar_args(input, planar[k], codebooks[k], scales[k])
+        if planar[k].in_group_size != g or planar[k].in_features != in_features:
+            raise ValueError("all layers of a shared-input launch must have the same scheme and in_features")
+        _planar_refresh(planar[k], codebooks[k])
+        cb, sc = _c(codebooks[k]), _c(scales[k])
+        bi = None if bias[k] is None else _c(bias[k])
+        of = planar[k].out_features
+        y = torch.empty((1, of), dtype=input.dtype, device=input.device)
+        keep += [cb, sc, bi]
+        outs.append(y)
+        segs[k].codes, segs[k].codebook, segs[k].scales, segs[k].bias = planar[k].data_ptr(), cb.data_ptr(), sc.data_ptr(), _ptr(bi)
+        segs[k].y, segs[k].y_row_stride, segs[k].out_features = y.data_ptr(), of, of
+        absmax[k] = planar[k].codebook_absmax
+        ws_bytes += _lib.aqlm_hip_workspace_bytes(_native.OP_GEMV_8X8_LUT, g, of, in_features)
+    stream = _stream_ptr(input.device)
+    cells = _lut_cells(input.device, stream, sum(y.shape[1] for y in outs)) if all(a > 0.0 for a in absmax) else None
+    with _device_guard(input.device):
+        if cells is not None:
+            rc = _lib.aqlm_hip_gemv_8x8_lut_planar_multi(segs, absmax, n, x.data_ptr(), in_features, g, dt, cells.data_ptr(),
+                                                         cells.numel() * 8, 1, stream)
+        else:
+            ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
+            rc = _lib.aqlm_hip_gemv_8x8_lut_planar_multi(segs, absmax, n, x.data_ptr(), in_features, g, dt, ws.data_ptr(), ws_bytes, 0,
+                                                         stream)
+    if rc:
+        _native.check(rc, "aqlm gemv_8x8_lut_planar_multi")
+    return [y.reshape(input.shape[:-1] + (y.shape[1],)) for y in outs]
 
 
 def codekx8_matmat(input, codes, codebooks, scales, bias=None):

@@ -61,8 +61,9 @@ class ShardedQuantizedLinear(nn.Module):
     def __init__(self, codes, codebooks, scales, bias, *, mode: str, in_group_size: int, in_lo: int, in_hi: int,
                  out_lo: int, out_hi: int, out_features: int, group=None, gather_output: bool = True,
                  kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = torch.float32,
-                 collective: str = "rccl", bias_all: Optional[torch.Tensor] = None):
+                 collective: str = "rccl", bias_all: Optional[torch.Tensor] = None, input_is_sharded: bool = False):
         super().__init__()
+        self.input_is_sharded = input_is_sharded  # in-split only: x arrives as this rank's slice (the paired out-split layer's output)
         assert collective in ("rccl", "xgmi")
         self.collective = collective
         self._bias_all = bias_all      # the full bias on every rank (the fused finalize writes the full y everywhere)
@@ -85,6 +86,8 @@ class ShardedQuantizedLinear(nn.Module):
         self._packed_tried = False
         self._packed_fingerprint = None  # identity / storage / version of `codes` at pack time (as QuantizedLinear does)
         self._selector_kernel = None
+        self._gather_sizes = None
+        self._cpu_codes_alt = None  # (fingerprint, codes permuted for the host LUT kernel); derived
 
     def _codes_fingerprint(self):
         c = self.codes
@@ -107,26 +110,29 @@ class ShardedQuantizedLinear(nn.Module):
         self._packed, self._packed_tried, self._packed_fingerprint = None, False, None
         self._xgmi, self._xgmi_ok = None, None
         self._selector_kernel = None
+        self._cpu_codes_alt = None
         return out
 
     @classmethod
     def from_full(cls, codes, codebooks, scales, bias, *, mode: str = "in", group=None, gather_output: bool = True,
                   kernel: Optional[Callable] = None, reduce_dtype: Optional[torch.dtype] = torch.float32,
-                  collective: str = "rccl"):
+                  collective: str = "rccl", bounds=None, input_is_sharded: bool = False):
+        """``bounds`` = this rank's [lo, hi) -- input groups for ``mode="in"``, output rows for ``mode="out"`` -- when the
+        caller fixes the partition itself (paired layers must cut at the same places: :func:`shard_mlp`)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         out_groups, in_groups, _ = codes.shape
         g = codebooks.shape[3]
         if mode == "in":
             # multiples of 8 groups keep each shard on the tuned (16-B code word) kernels
-            j0, j1 = shard_bounds(in_groups, world, rank, multiple=8)
+            j0, j1 = bounds if bounds is not None else shard_bounds(in_groups, world, rank, multiple=8)
             c = codes[:, j0:j1, :].contiguous()
             b = bias if (bias is not None and rank == 0) else None
             return cls(c, codebooks, scales, b, mode=mode, in_group_size=g, in_lo=j0 * g, in_hi=j1 * g, out_lo=0,
                        out_hi=out_groups, out_features=out_groups, group=group, gather_output=gather_output,
                        kernel=kernel, reduce_dtype=reduce_dtype, collective=collective,
-                       bias_all=bias if collective == "xgmi" else None)
-        i0, i1 = shard_bounds(out_groups, world, rank)
+                       bias_all=bias if collective == "xgmi" else None, input_is_sharded=input_is_sharded)
+        i0, i1 = bounds if bounds is not None else shard_bounds(out_groups, world, rank)
         return cls(codes[i0:i1].contiguous(), codebooks, scales[i0:i1].contiguous(),
                    None if bias is None else bias[i0:i1].contiguous(), mode=mode, in_group_size=g, in_lo=0,
                    in_hi=in_groups * g, out_lo=i0, out_hi=i1, out_features=out_groups, group=group,
@@ -159,6 +165,18 @@ class ShardedQuantizedLinear(nn.Module):
             from .inference_kernels import hip_kernel
 
             return hip_kernel.code1x16_matmat_packed(x, self._packed, self.codebooks, self.scales, bias)
+        if self._kernel is None and not self.codes.is_cuda:
+            from .inference_kernels.kernel_selector import cpu_kernel_takes_permuted_codes
+
+            if cpu_kernel_takes_permuted_codes(self.codebooks):
+                # host shards with 8-bit codebooks: the native LUT kernel reads codes permuted to [in_groups, out, K]; a derived
+                # copy, as in QuantizedLinear.prepare_matmul_op (the reference permutes the parameter in place, inference.py:78-83)
+                fp = self._codes_fingerprint()
+                if self._cpu_codes_alt is None or self._cpu_codes_alt[0] != fp:
+                    from .inference_kernels.cpu_kernel import permute_codes_for_lut
+
+                    self._cpu_codes_alt = (fp, permute_codes_for_lut(self.codes))
+                return self._k()(x, self._cpu_codes_alt[1], self.codebooks, self.scales, bias)
         return self._k()(x, self.codes, self.codebooks, self.scales, bias)
 
     def _xgmi_forward(self, xs: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
@@ -213,12 +231,14 @@ class ShardedQuantizedLinear(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if self.mode == "in" and self.input_is_sharded and x.shape[-1] != self.in_hi - self.in_lo:
+            raise ValueError(f"this in-split shard expects its own slice of the input ({self.in_hi - self.in_lo} features), got {x.shape[-1]}")
         if self.mode == "in" and self.collective == "xgmi" and x.is_cuda and self._kernel is None:
-            y = self._xgmi_forward(x[..., self.in_lo:self.in_hi], x.numel() // x.shape[-1])
+            y = self._xgmi_forward(x if self.input_is_sharded else x[..., self.in_lo:self.in_hi], x.numel() // x.shape[-1])
             if y is not None:
                 return y
         if self.mode == "in":
-            xs = x[..., self.in_lo:self.in_hi]
+            xs = x if self.input_is_sharded else x[..., self.in_lo:self.in_hi]
             if self.codes.shape[1] == 0:  # more ranks than 8-group blocks: this rank contributes nothing
                 y = torch.zeros(x.shape[:-1] + (self.out_features,), dtype=x.dtype, device=x.device)
             else:
@@ -234,10 +254,131 @@ class ShardedQuantizedLinear(nn.Module):
         y = self._shard_matvec(x, self.bias)
         if world == 1 or not self.gather_output:
             return y
-        sizes = [shard_bounds(self.out_features, world, r)[1] - shard_bounds(self.out_features, world, r)[0]
-                 for r in range(world)]
+        if self._gather_sizes is None:  # the ranks' row counts (explicit bounds need not be the default split): agreed once
+            mine_n = torch.tensor([self.out_hi - self.out_lo], dtype=torch.int64, device=y.device)
+            alln = [torch.empty_like(mine_n) for _ in range(world)]
+            dist.all_gather(alln, mine_n, group=self.group)
+            self._gather_sizes = [int(t) for t in alln]
+        sizes = self._gather_sizes
         width = max(sizes)  # all_gather needs equal shapes: pad ragged shards, trim after
         mine = y if y.shape[-1] == width else torch.nn.functional.pad(y, (0, width - y.shape[-1]))
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine.contiguous(), group=self.group)
         return torch.cat([p[..., :s] for p, s in zip(parts, sizes)], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Megatron pairing: an out-split layer whose output stays sharded feeds an in-split layer that
+# takes its own slice -- gate/up -> act * mul -> down needs ONE collective per MLP (the in-split's all-reduce), q/k/v ->
+# attention over the rank's heads -> o_proj one per attention block; an "in-split everywhere" plan pays one per layer
+# (7 per decoder block instead of 2).  The modules replace the QuantizedLinear children in place, so Hugging Face's modeling
+# code (`down_proj(act_fn(gate_proj(x)) * up_proj(x))`, `o_proj(attn(q_proj(x), k_proj(x), v_proj(x)))`) runs unchanged on
+# per-rank slices.
+# ---------------------------------------------------------------------------------------------------------------------
+def _layer_tensors(m):
+    codes = m._canonical_codes() if hasattr(m, "_canonical_codes") else m.codes
+    return codes.detach(), m.codebooks.detach(), m.scales.detach(), (None if m.bias is None else m.bias.detach())
+
+
+def _world_rank(group):
+    if dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_pair(first_layers, second, *, unit: int = 1, group=None, kernel: Optional[Callable] = None,
+               reduce_dtype: Optional[torch.dtype] = torch.float32, collective: str = "rccl"):
+    """Column-parallel ``first_layers`` (their outputs stay sharded) feeding row-parallel ``second``: the shared dimension
+    (rows of the first layers = input features of the second) is cut ONCE, in blocks of ``unit`` features (rounded up to whole
+    8-group code words of ``second``; ``unit`` = head_dim x heads-per-kv-head for attention so that heads stay whole).
+    Returns ``([sharded first layers], sharded second)``."""
+    world, rank = _world_rank(group)
+    codes2, cb2, sc2, b2 = _layer_tensors(second)
+    g2 = int(cb2.shape[3])
+    inner = codes2.shape[1] * g2
+    for m in first_layers:
+        if _layer_tensors(m)[0].shape[0] * int(m.codebooks.shape[2]) != inner:
+            raise ValueError(f"paired layers must share the inner dimension ({inner} input features of the second layer)")
+    block = unit * 8 * g2 // _gcd(unit, 8 * g2)  # lcm: whole units AND whole 8-group code words of the second layer
+    if inner % block:
+        block = unit * g2 // _gcd(unit, g2)      # ragged inner dimension: whole groups at least
+    lo, hi = shard_bounds(inner, world, rank, multiple=block)
+    firsts = []
+    for m in first_layers:
+        c, cb, sc, b = _layer_tensors(m)
+        firsts.append(ShardedQuantizedLinear.from_full(c, cb, sc, b, mode="out", group=group, gather_output=False, kernel=kernel,
+                                                       bounds=(lo, hi)))
+    sec = ShardedQuantizedLinear.from_full(codes2, cb2, sc2, b2, mode="in", group=group, kernel=kernel, reduce_dtype=reduce_dtype,
+                                           collective=collective, bounds=(lo // g2, hi // g2), input_is_sharded=True)
+    return firsts, sec
+
+
+def _gcd(a: int, b: int) -> int:
+    while b:
+        a, b = b, a % b
+    return a
+
+
+def shard_mlp(mlp: nn.Module, *, names=("gate_proj", "up_proj", "down_proj"), group=None, kernel: Optional[Callable] = None,
+              reduce_dtype: Optional[torch.dtype] = torch.float32, collective: str = "rccl") -> nn.Module:
+    """Replace ``mlp.gate_proj`` / ``up_proj`` (out-split, outputs left sharded) and ``down_proj`` (in-split on the same cut,
+    one all-reduce) in place.  No collective for gate / up; the activation and the product act on the rank's slice."""
+    *first_names, second_name = names
+    firsts, sec = shard_pair([getattr(mlp, n) for n in first_names], getattr(mlp, second_name), group=group, kernel=kernel,
+                             reduce_dtype=reduce_dtype, collective=collective)
+    for n, m in zip(first_names, firsts):
+        setattr(mlp, n, m)
+    setattr(mlp, second_name, sec)
+    return mlp
+
+
+def shard_attention(attn: nn.Module, *, head_dim: int, num_heads: int, num_kv_heads: int,
+                    names=("q_proj", "k_proj", "v_proj", "o_proj"), group=None, kernel: Optional[Callable] = None,
+                    reduce_dtype: Optional[torch.dtype] = torch.float32, collective: str = "rccl") -> nn.Module:
+    """q / k / v out-split by whole heads (a rank keeps the query heads of its key / value heads), o_proj in-split on the
+    same cut.  Needs ``num_kv_heads`` divisible by the world size (Llama-3-70B: 8 kv heads, 8 GPUs)."""
+    world, rank = _world_rank(group)
+    if num_kv_heads % world or num_heads % num_kv_heads:
+        raise ValueError(f"{num_kv_heads} key/value heads do not split over {world} ranks")
+    qn, kn, vn, on = names
+    rep = num_heads // num_kv_heads
+    (q,), o = shard_pair([getattr(attn, qn)], getattr(attn, on), unit=head_dim * rep * (num_kv_heads // world), group=group,
+                         kernel=kernel, reduce_dtype=reduce_dtype, collective=collective)
+    kv_lo, kv_hi = shard_bounds(num_kv_heads * head_dim, world, rank, multiple=head_dim * (num_kv_heads // world))
+    for n in (kn, vn):
+        c, cb, sc, b = _layer_tensors(getattr(attn, n))
+        setattr(attn, n, ShardedQuantizedLinear.from_full(c, cb, sc, b, mode="out", group=group, gather_output=False, kernel=kernel,
+                                                          bounds=(kv_lo, kv_hi)))
+    setattr(attn, qn, q)
+    setattr(attn, on, o)
+    for attr, val in (("num_heads", num_heads // world), ("num_key_value_heads", num_kv_heads // world)):
+        if hasattr(attn, attr):  # older Hugging Face attention modules reshape with these
+            setattr(attn, attr, val)
+    return attn
+
+
+def shard_model(model: nn.Module, *, group=None, attention: bool = True, kernel: Optional[Callable] = None,
+                reduce_dtype: Optional[torch.dtype] = torch.float32, collective: str = "rccl") -> dict:
+    """Apply the pairing to every decoder block of a Hugging Face style model whose linears are ``QuantizedLinear``: MLPs
+    always; attention blocks when the head counts allow it (``model.config`` gives them).  Returns a summary
+    ``{"mlp": n, "attention": n, "collectives_per_block": ...}``.  Everything else (norms, embeddings, lm_head) stays replicated."""
+    from .inference import QuantizedLinear
+
+    cfg = getattr(model, "config", None)
+    done = {"mlp": 0, "attention": 0}
+    for mod in list(model.modules()):
+        kids = dict(mod.named_children())
+        if all(isinstance(kids.get(n), QuantizedLinear) for n in ("gate_proj", "up_proj", "down_proj")):
+            shard_mlp(mod, group=group, kernel=kernel, reduce_dtype=reduce_dtype, collective=collective)
+            done["mlp"] += 1
+        if attention and cfg is not None and all(isinstance(kids.get(n), QuantizedLinear) for n in ("q_proj", "k_proj", "v_proj", "o_proj")):
+            heads = int(cfg.num_attention_heads)
+            kv = int(getattr(cfg, "num_key_value_heads", heads) or heads)
+            hd = int(getattr(cfg, "head_dim", None) or cfg.hidden_size // heads)
+            world, _ = _world_rank(group)
+            if kv % world == 0:
+                shard_attention(mod, head_dim=hd, num_heads=heads, num_kv_heads=kv, group=group, kernel=kernel,
+                                reduce_dtype=reduce_dtype, collective=collective)
+                done["attention"] += 1
+    done["collectives_per_block"] = (1 if done["mlp"] else 0) + (1 if done["attention"] else 0)
+    return done

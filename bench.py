@@ -67,6 +67,11 @@ class Layer:
         self.y = torch.empty((batch, fout), device=device, dtype=torch.float16)
         self.bytes = algorithmic_bytes(fin, fout, K, nbits, g, batch)
         self.packed = None
+        self.planar = None
+        if PACK_MIN_OUT and (K, nbits) == (8, 8):
+            from aqlm_amd.inference_kernels import hip_kernel as hk
+
+            self.planar = hk.planar_8x8_pack(self.codes, g, codebooks=self.codebooks)  # load-time re-layout (same size, lossless)
         if PACK_MIN_OUT and (K, nbits) == (1, 16) and g in (8, 16) and fout * (fin // g) >= PACK_MIN_OUT:
             from aqlm_amd import _native
 
@@ -105,6 +110,14 @@ class Layer:
         elif batch == 1 and self.K == 8 and self.nbits == 8:
             if getattr(self, "lut_cells", None) is None:  # zero-at-rest accumulator cells of the single-kernel form
                 self.lut_cells = torch.zeros((self.fout,), dtype=torch.int64, device=self.codes.device)
+            if self.planar is not None:
+                rc = lib.aqlm_hip_gemv_8x8_lut_planar(self.planar.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
+                                                      self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, _native.F16,
+                                                      self.planar.codebook_absmax, self.lut_cells.data_ptr(),
+                                                      self.lut_cells.numel() * 8, 1, stream)
+                if rc:
+                    _native.check(rc)
+                return
             rc = lib.aqlm_hip_gemv_8x8_lut_fused(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                                  self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, _native.F16,
                                                  self.lut_cells.data_ptr(), self.lut_cells.numel() * 8, stream)
@@ -157,6 +170,21 @@ class FusedLayers:
             m0 = self.members[0]
             if getattr(self, "lut_cells", None) is None:  # zero-at-rest accumulator cells of the single-kernel form
                 self.lut_cells = torch.zeros((sum(m.fout for m in self.members),), dtype=torch.int64, device=self.x.device)
+            if all(getattr(m, "planar", None) is not None for m in self.members):
+                import ctypes
+
+                if getattr(self, "planar_segs", None) is None:
+                    self.planar_segs = (_native.Segment * len(self.members))()
+                    for sg, src, m in zip(self.planar_segs, self.segs, self.members):
+                        sg.codes, sg.codebook, sg.scales, sg.bias = m.planar.data_ptr(), src.codebook, src.scales, None
+                        sg.y, sg.y_row_stride, sg.out_features = src.y, src.y_row_stride, src.out_features
+                    self.planar_absmax = (ctypes.c_float * len(self.members))(*[m.planar.codebook_absmax for m in self.members])
+                rc = lib.aqlm_hip_gemv_8x8_lut_planar_multi(self.planar_segs, self.planar_absmax, len(self.members), self.x.data_ptr(),
+                                                            self.fin, self.g, _native.F16, self.lut_cells.data_ptr(),
+                                                            self.lut_cells.numel() * 8, 1, stream)
+                if rc:
+                    _native.check(rc)
+                return
             rc = lib.aqlm_hip_gemv_8x8_lut_multi_fused(self.segs, len(self.members), self.x.data_ptr(), self.fin, self.g,
                                                        _native.F16, self.lut_cells.data_ptr(), self.lut_cells.numel() * 8, stream)
         elif self.members[0].nbits == 8:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 4
+#define AQLM_HIP_ABI_VERSION 5
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -164,13 +164,15 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
                             size_t workspace_bytes, void* stream);
 
 /*
- * Load-time repack of 1x16 g8 codes into the slice-bucketed format v6 consumed by aqlm_hip_gemv_1x16_packed (layout:
+ * Load-time repack of 1x16 codes (g 8 or 16) into the slice-bucketed format v6 consumed by aqlm_hip_gemv_1x16_packed (layout:
  * aqlm_amd/csrc/gemv_packed.hip, specification tests/packed_model.py; 4 bytes per code + ~6 bytes per (row, slice),
  * plus 64 bytes per output row of zero-at-rest accumulator cells for the fused finalize).
  * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
  * (inference.py:78-83).
- *   aqlm_hip_prepack_1x16_bytes  capacity the caller must provide (0: shape not covered -- in_group_size != 8 or
- *                                in_features / 8 > 4094); more than the result needs: the repack uses the tail as scratch.
+ *   aqlm_hip_prepack_1x16_bytes  capacity the caller must provide (0: shape not covered -- in_group_size not 8 or 16, more
+ *                                input groups than an entry's 12 / 11-bit slot field addresses, or rows whose tables fit no LDS
+ *                                image); more than the result needs: the repack uses the tail as scratch.
+ *                                in_group_size 16 = the second instantiation (32 slices of 2048 x 32 B).
  *   aqlm_hip_prepack_1x16        fills `packed` and `*desc`; desc->used_bytes <= capacity is what has to be kept (the
  *                                buffer may be trimmed / copied; the descriptor travels with it and is also stored in the
  *                                buffer's first bytes).  Synchronises `stream` (load-time call, not graph-capturable).
@@ -344,6 +346,37 @@ int aqlm_hip_gemv_8x8_lut_fused(const void* codes_i8, const void* codebooks, con
                                 void* cells, size_t cells_bytes, void* stream);
 int aqlm_hip_gemv_8x8_lut_multi_fused(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
                                       int in_group_size, int dtype, void* cells, size_t cells_bytes, void* stream);
+
+/*
+ * Planar layout of 8 x 8-bit codes (ABI 5): [8 codebooks][out_features][jp] bytes, jp = in_features / in_group_size rounded up
+ * to 4 (padding bytes zero) -- the checkpoint's [out][in_groups][8] transposed, same size, lossless.  With it a workgroup of the
+ * look-up-table matvec serves ONE codebook x 128 input groups: it fetches 16 KiB of codebook (g = 32) instead of all 128 KiB
+ * and reads its codes as 128 contiguous bytes per row.  Load-time re-layout, the counterpart of the reference's code
+ * permutation for its CPU look-up kernel (inference.py:78-83).  aqlm_hip_8x8_planar_bytes returns 0 for impossible sizes;
+ * buffers 8-byte aligned; pack / unpack are plain kernels on `stream` (no sync, capturable).
+ */
+size_t aqlm_hip_8x8_planar_bytes(int out_features, int in_features, int in_group_size);
+int aqlm_hip_8x8_planar_pack(const void* codes_i8, int out_features, int in_features, int in_group_size, void* planar,
+                             size_t planar_bytes, void* stream);
+int aqlm_hip_8x8_planar_unpack(const void* planar, int out_features, int in_features, int in_group_size, void* codes_i8,
+                               void* stream);
+
+/*
+ * aqlm_hip_gemv_8x8_lut[_fused] / _multi[_fused] on planar codes (replaces the same reference route, triton_kernel.py:30-125,
+ * reached through kernel_selector.py:91-94).  `fused` != 0: `workspace` = zero-at-rest cells as for the _fused entries, and
+ * `codebook_absmax` (> 0, a bound of max |codebook entry| over ALL 8 codebooks, e.g. taken at load time) replaces the in-kernel
+ * maximum -- a workgroup sees one codebook only, and every workgroup of a row must derive the same fixed-point unit; a bound
+ * that is too large only costs resolution, one that is too small gives NaN rows, never a wrong number.  `fused` == 0:
+ * `workspace` = aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMV_8X8_LUT, ...) bytes of fp32 partials, `codebook_absmax` ignored.
+ * _multi: segments[k].codes = the segment's planar buffer, codebook_absmax[k] its bound.  Results equal the canonical-layout
+ * entries up to fp32 summation order (other slab shape), and _multi equals the single-layer entry bit for bit.
+ */
+int aqlm_hip_gemv_8x8_lut_planar(const void* planar, const void* codebooks, const void* scales, const void* bias, const void* x,
+                                 void* y, int out_features, int in_features, int in_group_size, int dtype, float codebook_absmax,
+                                 void* workspace, size_t workspace_bytes, int fused, void* stream);
+int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const float* codebook_absmax, int num_segments,
+                                       const void* x, int in_features, int in_group_size, int dtype, void* workspace,
+                                       size_t workspace_bytes, int fused, void* stream);
 
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3

@@ -9,6 +9,7 @@ The reference ships pure Python and JIT-compiles its CUDA source at first use (i
 cuda_kernel.py:7-11); ahead-of-time libraries are what this package loads, so they are built here.  Set AQLM_SKIP_HIP_BUILD=1 to package the CPU library only (hosts without ROCm)."""
 import os
 import subprocess
+import sys
 
 from setuptools import setup
 from setuptools.command.build_py import build_py
@@ -21,7 +22,10 @@ def build_native():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc_cpu")])
     if os.environ.get("AQLM_SKIP_HIP_BUILD") != "1":
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc"), "-j", jobs])
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc_front")])  # compiled host glue (needs torch)
+        # compiled host glue (needs torch): built against the interpreter that is installing the package, not whatever
+        # `python3` is first on PATH (venv / conda installs), with the ROCm headers of this machine
+        rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME") or "/opt/rocm"
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "aqlm_amd", "csrc_front"), f"PYTHON={sys.executable}", f"ROCM_PATH={rocm}"])
 
 
 class BuildPyWithNative(build_py):

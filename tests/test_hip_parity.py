@@ -776,6 +776,19 @@ def test_raw_op_packs_large_layers_transparently(hk, monkeypatch):
         hk.code1x16_matmat(T3["x"], T3["codes"].view(fout, fin // 8, 1), T3["codebooks"], T3["scales"], None)
         gc.collect()
     assert stats["packs"] == p2 + 3
+    # bounded: with room for one packed layer only, a second layer evicts the first (least recently used), the byte count stays
+    # under the cap and the evicted layer is simply packed again when it comes back
+    monkeypatch.setattr(hk, "RAW_OP_PREPACK_MAX_MISSES", 100)
+    hk.clear_raw_op_prepack_cache()
+    T4 = to_dev(orc.make_layer(31340, fin, fout, 1, 16, 8, batch=1, bias=False), torch.float16)
+    y3 = hk.code1x16_matmat(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], None)
+    one = stats["bytes"]
+    monkeypatch.setattr(hk, "RAW_OP_PREPACK_MAX_BYTES", int(one * 1.7))
+    hk.code1x16_matmat(T4["x"], T4["codes"], T4["codebooks"], T4["scales"], None)
+    assert stats["bytes"] <= int(one * 1.7) and id(T3["codes"]) not in hk._RAW_PACKED and id(T4["codes"]) in hk._RAW_PACKED
+    assert torch.equal(hk.code1x16_matmat(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], None), y3)
+    assert id(T3["codes"]) in hk._RAW_PACKED and id(T4["codes"]) not in hk._RAW_PACKED
+    hk.clear_raw_op_prepack_cache()
 
 
 @pytest.mark.parametrize("dt", ["float16", "bfloat16"])
@@ -1102,6 +1115,120 @@ def test_gemv_8x8_lut_multi_is_bit_identical_to_separate_launches(hk, g, fin, fo
         assert torch.equal(y, hk.codekx8_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"]))
         y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
         check_close(y.float().cpu().numpy(), y64, dtype, f"lut multi 8x8g{g} {fin}->{L['codes'].shape[0]}")
+
+
+@pytest.mark.parametrize("g,fin,fout,dt,bias", [
+    (32, 4096, 4096, "float16", True),
+    (32, 11008, 1000, "float16", False),   # 344 groups: three 128-group slabs per codebook, the last one 88 wide; ragged rows
+    (32, 4096, 37, "bfloat16", True),
+    (8, 1024, 512, "float16", True),       # 128 groups of 8
+    (16, 2080, 300, "bfloat16", True),     # 130 groups: rows of the planes padded to 132 bytes
+    (32, 8192, 28672, "float16", False),   # 896 rows per workgroup: the hand-in pass covers several rows per thread
+])
+def test_gemv_8x8_lut_planar(hk, g, fin, fout, dt, bias):
+    """Planar code layout of the 8x8 look-up-table matvec: lossless re-layout, single-kernel and two-kernel forms vs the oracle and
+    vs the canonical-layout kernel, both workgroup sizes, repeatable bit for bit, zero input == bias."""
+    from aqlm_amd import _native
+
+    dtype = tdtype(dt)
+    L = orc.make_layer(4700 + fin + fout + g, fin, fout, 8, 8, g, batch=1, bias=bias,
+                       float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    planar = hk.planar_8x8_pack(T["codes"], g, codebooks=T["codebooks"])
+    assert planar is not None and planar.numel() == 8 * fout * ((fin // g + 3) // 4 * 4) and planar.codebook_absmax > 0
+    assert torch.equal(hk.planar_8x8_unpack(planar), T["codes"])
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    y_canon = hk._gemv_8x8_lut(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    outs = {}
+    for waves in (16, 8):
+        _native.set_tuning("lut_waves", waves)
+        try:
+            y = hk.code8x8_matmat_planar(T["x"], planar, T["codebooks"], T["scales"], T["bias"])
+            check_close(y.float().cpu().numpy(), y64, dtype, f"planar lut 8x8g{g} {fin}->{fout}, {waves} waves")
+            for _ in range(3):
+                assert torch.equal(hk.code8x8_matmat_planar(T["x"], planar, T["codebooks"], T["scales"], T["bias"]), y)
+            keep, planar.codebook_absmax = planar.codebook_absmax, 0.0   # unknown bound -> two-kernel form
+            try:
+                planar._range_of = (T["codebooks"].data_ptr(), hk._version(T["codebooks"]))
+                y2 = hk.code8x8_matmat_planar(T["x"], planar, T["codebooks"], T["scales"], T["bias"])
+            finally:
+                planar.codebook_absmax = keep
+            check_close(y.float().cpu().numpy(), y2.double().cpu().numpy(), dtype, "planar fused vs two-kernel")
+            yc = hk._gemv_8x8_lut(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+            check_close(yc.float().cpu().numpy(), y64, dtype, f"canonical lut, {waves} waves")
+            outs[waves] = y
+        finally:
+            _native.set_tuning("lut_waves", 0)
+    check_close(outs[16].float().cpu().numpy(), y_canon.double().cpu().numpy(), dtype, "planar vs canonical layout")
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    assert int(hk._LUT_CELLS[key].abs().max()) == 0, "cells must be zero when the kernels have finished"
+    if bias:
+        yz = hk.code8x8_matmat_planar(torch.zeros_like(T["x"]), planar, T["codebooks"], T["scales"], T["bias"])
+        assert torch.equal(yz[0], T["bias"])
+    xn = T["x"].clone()
+    xn[0, 3] = float("inf")
+    assert torch.isnan(hk.code8x8_matmat_planar(xn, planar, T["codebooks"], T["scales"], T["bias"])).all()
+    assert torch.equal(hk.code8x8_matmat_planar(T["x"], planar, T["codebooks"], T["scales"], T["bias"]), outs[16])
+
+
+@pytest.mark.parametrize("g,fin,fouts,dt", [(32, 4096, (4096, 1024, 1024), "float16"), (32, 11008, (300, 77), "bfloat16"),
+                                           (8, 1024, (256, 256, 256, 40), "float16")])
+def test_gemv_8x8_lut_planar_multi_is_bit_identical_to_separate_launches(hk, g, fin, fouts, dt):
+    dtype = tdtype(dt)
+    fd = np.float16 if dtype == torch.float16 else "bfloat16"
+    Ls = [orc.make_layer(6700 + fin + 7 * k, fin, fo, 8, 8, g, batch=1, bias=(k % 2 == 0), float_dtype=fd)
+          for k, fo in enumerate(fouts)]
+    Ts = [to_dev(L, dtype) for L in Ls]
+    x = Ts[0]["x"]
+    planars = [hk.planar_8x8_pack(T["codes"], g, codebooks=T["codebooks"]) for T in Ts]
+    outs = hk.code8x8_matmat_planar_multi(x, planars, [T["codebooks"] for T in Ts], [T["scales"] for T in Ts], [T["bias"] for T in Ts])
+    for L, T, pl, y in zip(Ls, Ts, planars, outs):
+        assert torch.equal(y, hk.code8x8_matmat_planar(x, pl, T["codebooks"], T["scales"], T["bias"]))
+        y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_close(y.float().cpu().numpy(), y64, dtype, f"planar lut multi 8x8g{g} {fin}->{L['codes'].shape[0]}")
+
+
+def test_8x8_module_uses_planar_codes_and_can_drop_the_canonical_ones(hk):
+    """QuantizedLinear of an 8x8 scheme: single-row calls run on the planar copy, 2..6 rows and backward on the canonical codes;
+    dropping the canonical codes keeps 2.0 bits per weight of codes resident and state_dict() lossless; fused q/k/v in one launch."""
+    import aqlm
+    from aqlm.checkpoint import prepack_model
+
+    fin = 4096
+    holder = torch.nn.Module()
+    Ls = {}
+    for k, (n, fo) in enumerate([("q_proj", 1024), ("k_proj", 256), ("v_proj", 256)]):
+        Ls[n] = orc.make_layer(4800 + k, fin, fo, 8, 8, 32, batch=3, bias=(k == 0))
+        m, _ = _module_from(Ls[n], 8, 8, 32, fin, fo, torch.float16)
+        setattr(holder, n, m)
+    T = to_dev(Ls["q_proj"], torch.float16)
+    x1, x3 = T["x"][:1].contiguous(), T["x"]
+    with torch.no_grad():
+        y1 = holder.q_proj(x1)
+        assert isinstance(holder.q_proj._packed_codes, hk.PlanarCodes)
+        assert torch.equal(y1, hk.code8x8_matmat_planar(x1, holder.q_proj._packed_codes, T["codebooks"], T["scales"], T["bias"]))
+        y64 = orc.dequantize_gemm(Ls["q_proj"]["x"], Ls["q_proj"]["codes"], Ls["q_proj"]["codebooks"], Ls["q_proj"]["scales"], Ls["q_proj"]["bias"])
+        check_close(y1.float().cpu().numpy(), y64[:1], torch.float16, "8x8 module, one row")
+        check_close(holder.q_proj(x3).float().cpu().numpy(), y64, torch.float16, "8x8 module, three rows")
+        sd = {k: v.clone() for k, v in holder.q_proj.state_dict().items()}
+        rep = prepack_model(holder, min_codes=100_000, drop_canonical=True)
+        assert holder.q_proj._codes_dropped and holder.v_proj._codes_dropped and rep["codes"] == 0 and abs(rep["code_bits_per_weight"] - 2.0) < 1e-9
+        assert torch.equal(holder.q_proj(x1), y1)
+        check_close(holder.q_proj(x3).float().cpu().numpy(), y64, torch.float16, "8x8 module, three rows, codes dropped")
+        sd2 = holder.q_proj.state_dict()
+        assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+        groups = aqlm.fuse_shared_input_linears(holder)
+        assert len(groups) == 1
+        want = {n: getattr(holder, n)._packed_codes for n in Ls}
+        outs = {n: getattr(holder, n)(x1) for n in Ls}
+        assert groups[0].launches == 1 and groups[0].served == 2
+        for n in Ls:
+            Tn = to_dev(Ls[n], torch.float16)
+            assert torch.equal(outs[n], hk.code8x8_matmat_planar(x1, want[n], Tn["codebooks"], Tn["scales"], Tn["bias"])), n
+    holder.q_proj.restore_canonical_codes()
+    xg = x1.clone().requires_grad_(True)
+    holder.q_proj(xg).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
 
 
 def test_gemv_kx8_multi_other_schemes_fall_back_per_segment(hk):

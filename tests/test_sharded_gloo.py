@@ -137,3 +137,119 @@ def test_one_shot_all_reduce_protocol_on_host_memory(world):
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert all(ok for _, ok, _ in res)
     assert len({d for _, _, d in res}) == 1   # bit-identical replicas
+
+
+# ------------------------------------------------------------------ Megatron pairing: out-split gate / up -> in-split down
+class _ToyMLP(torch.nn.Module):
+    """The shape of a Hugging Face Llama MLP: down_proj(act_fn(gate_proj(x)) * up_proj(x))."""
+
+    def __init__(self, hidden, inter, K, nbits, g, seed):
+        super().__init__()
+        from aqlm import QuantizedLinear
+
+        self.layers = {}
+        for k, (name, fi, fo) in enumerate((("gate_proj", hidden, inter), ("up_proj", hidden, inter), ("down_proj", inter, hidden))):
+            L = orc.make_layer(seed + k, fi, fo, K, nbits, g, batch=2, bias=(name == "down_proj"), float_dtype=np.float32)
+            m = QuantizedLinear(fi, fo, g, 1, K, nbits, bias=L["bias"] is not None, dtype=torch.float32)
+            with torch.no_grad():
+                m.codes.copy_(torch.from_numpy(L["codes"])); m.codebooks.copy_(torch.from_numpy(L["codebooks"]))
+                m.scales.copy_(torch.from_numpy(L["scales"]))
+                if L["bias"] is not None:
+                    m.bias.copy_(torch.from_numpy(L["bias"]))
+            setattr(self, name, m)
+            self.layers[name] = L
+        self.act_fn = torch.nn.SiLU()
+
+    def forward(self, x):
+        return self.down_proj(self.act_fn(self.gate_proj(x)) * self.up_proj(x))
+
+    def oracle(self, x64):
+        L = self.layers
+        f = lambda n, v: orc.dequantize_gemm(v, L[n]["codes"], L[n]["codebooks"], L[n]["scales"], L[n]["bias"])
+        gate, up = f("gate_proj", x64), f("up_proj", x64)
+        return f("down_proj", gate / (1.0 + np.exp(-gate)) * up)
+
+
+def _mlp_worker(rank, world, port, cfg, inject, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aqlm_amd.sharded import ShardedQuantizedLinear, shard_mlp
+
+        K, nbits, g, hidden, inter = cfg
+        mlp = _ToyMLP(hidden, inter, K, nbits, g, seed=77)
+        x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, hidden)).astype(np.float32))
+        want = mlp.oracle(x.double().numpy())
+        calls = {"n": 0}
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(*a, **kw):
+            calls["n"] += 1
+            return real_all_reduce(*a, **kw)
+
+        shard_mlp(mlp, kernel=_torch_kernel if inject else None)
+        assert all(isinstance(getattr(mlp, n), ShardedQuantizedLinear) for n in ("gate_proj", "up_proj", "down_proj"))
+        gp, dp = mlp.gate_proj, mlp.down_proj
+        assert gp.mode == "out" and not gp.gather_output and dp.mode == "in" and dp.input_is_sharded
+        assert (gp.out_lo, gp.out_hi) == (dp.in_lo, dp.in_hi) == (mlp.up_proj.out_lo, mlp.up_proj.out_hi)   # ONE cut
+        assert gp.out_lo % g == 0
+        dist.all_reduce = counting_all_reduce
+        try:
+            y = mlp(x)
+        finally:
+            dist.all_reduce = real_all_reduce
+        assert calls["n"] == 1, f"one collective per MLP expected, saw {calls['n']}"
+        assert gp(x).shape[-1] == gp.out_hi - gp.out_lo           # gate / up outputs stay sharded
+        widths = torch.tensor([gp.out_hi - gp.out_lo])
+        dist.all_reduce(widths)
+        err = float(np.abs(y.double().numpy() - want).max() / np.abs(want).mean())
+        q.put((rank, tuple(y.shape), err, int(widths)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("cfg,inject", [((2, 8, 8, 256, 704), False), ((1, 16, 8, 128, 320), True)])
+def test_megatron_paired_mlp_gloo(world, cfg, inject):
+    """shard_mlp: out-split gate / up (no collective, outputs sharded) feed the in-split down_proj on the same cut: one all-reduce
+    per MLP, result equal to the unsharded oracle (2x8g8 through the product's own CPU kernels, 1x16g8 with an fp64 shard kernel)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mlp_worker, args=(r, world, port, cfg, inject, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    for rank, shape, err, width_sum in sorted(q.get(timeout=10) for _ in range(world)):
+        assert shape == (2, cfg[3]) and width_sum == cfg[4]
+        assert err < (2e-5 if inject else 2e-4), f"rank {rank}: paired MLP differs from the unsharded oracle by {err}"
+
+
+def test_shard_model_pairs_attention_by_heads_world1():
+    """shard_model on a one-process 'world': the attention pairing keeps whole heads per rank and the summary counts the
+    collectives of a decoder block (2 paired vs 7 for in-split everywhere)."""
+    from types import SimpleNamespace
+
+    from aqlm import QuantizedLinear
+    from aqlm_amd.sharded import ShardedQuantizedLinear, shard_model
+
+    hidden, heads, kv, hd, inter = 256, 8, 2, 32, 512
+    blk = torch.nn.Module()
+    blk.self_attn = torch.nn.Module()
+    blk.mlp = torch.nn.Module()
+    mk = lambda fi, fo: QuantizedLinear(fi, fo, 8, 1, 2, 8, bias=False, dtype=torch.float32)
+    for n, (fi, fo) in {"q_proj": (hidden, heads * hd), "k_proj": (hidden, kv * hd), "v_proj": (hidden, kv * hd), "o_proj": (heads * hd, hidden)}.items():
+        setattr(blk.self_attn, n, mk(fi, fo))
+    for n, (fi, fo) in {"gate_proj": (hidden, inter), "up_proj": (hidden, inter), "down_proj": (inter, hidden)}.items():
+        setattr(blk.mlp, n, mk(fi, fo))
+    model = torch.nn.Module()
+    model.block = blk
+    model.config = SimpleNamespace(num_attention_heads=heads, num_key_value_heads=kv, hidden_size=hidden)
+    for p in model.parameters():
+        torch.nn.init.zeros_(p) if p.dtype.is_floating_point else p.zero_()
+    s = shard_model(model)
+    assert s == {"mlp": 1, "attention": 1, "collectives_per_block": 2}
+    assert all(isinstance(m, ShardedQuantizedLinear) for m in list(blk.self_attn.children()) + list(blk.mlp.children()))
+    assert blk.self_attn.o_proj.input_is_sharded and blk.self_attn.q_proj.mode == "out" and not blk.self_attn.k_proj.gather_output

@@ -355,6 +355,7 @@ struct Scheme {
   bool lds = false;  // (unused: the slice-scan experiment was removed)
   bool packed = false;  // route 1x16 through aqlm_hip_gemv_1x16_packed
   bool lut = false;     // route 8x8 through aqlm_hip_gemv_8x8_lut
+  bool planar = false;  // ... on planar codes (aqlm_hip_gemv_8x8_lut_planar)
 };
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -372,6 +373,8 @@ static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int ba
   if (s.nbits == 16 && s.packed && g_chain && next)
     return aqlm_hip_gemv_1x16_packed_chain(&L.desc, L.packed, L.cb, L.scales, nullptr, L.x, L.y, batch, in, out, AQLM_HIP_F16, g_ws, g_ws_bytes,
                                            &next->desc, next->packed, next->cb, st);
+  if (s.lut && s.planar)
+    return aqlm_hip_gemv_8x8_lut_planar(L.packed, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, 1.0f, g_ws, g_ws_bytes, g_lut_fused ? 1 : 0, st);
   if (s.lut && g_lut_fused)  // g_ws is zero-filled before every variant and left zero by every fused call
     return aqlm_hip_gemv_8x8_lut_fused(L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, g_ws, g_ws_bytes, st);
   if (s.lut)
@@ -434,6 +437,14 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     hipLaunchKernelGGL(fill_one_half, dim3(64), dim3(256), 0, 0, (uint16_t*)L.scales, (size_t)out);
   }
   CK(hipDeviceSynchronize());
+  if (s.planar) {
+    const size_t pb = aqlm_hip_8x8_planar_bytes(out, in, s.g);
+    for (auto& L : v) {
+      CK(hipMalloc(&L.packed, pb));
+      if (int rc = aqlm_hip_8x8_planar_pack(L.codes, out, in, s.g, L.packed, pb, nullptr)) { fprintf(stderr, "planar pack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+    }
+    CK(hipDeviceSynchronize());
+  }
   if (s.packed) {
     const size_t pb = aqlm_hip_prepack_1x16_bytes(out, in, s.g);
     for (auto& L : v) {
@@ -459,13 +470,15 @@ static void bench_gemv(int argc, char** argv) {
   const Scheme S1x16P{"1x16g8P", 1, 16, 8, false, true};
   const Scheme S1x16g16P{"1x16g16P", 1, 16, 16, false, true};
   const Scheme S8x8L{"8x8g32LUT", 8, 8, 32, false, false, true};
+  const Scheme S8x8LP{"8x8g32LUTP", 8, 8, 32, false, false, true, true};  // planar codes
   const Scheme S1x16{"1x16g8", 1, 16, 8}, S2x8{"2x8g8", 2, 8, 8}, S1x8{"1x8g8", 1, 8, 8}, S8x8{"8x8g32", 8, 8, 32}, S1x16g16{"1x16g16", 1, 16, 16};
   struct Case { Scheme s; int in, out; };
   std::vector<Case> cases = {{S1x16P, 4096, 4096}, {S1x16P, 4096, 11008}, {S1x16P, 4096, 14336}, {S1x16P, 14336, 4096}, {S1x16P, 4096, 1024}, {S1x16P, 8192, 28672}, {S1x16P, 1024, 28672}, {S1x16P, 2048, 28672}, {S1x16P, 8192, 8192}, {S1x16P, 28672, 8192}, {S1x16P, 8192, 1024},
                              {S1x16, 4096, 4096}, {S1x16, 4096, 11008}, {S1x16, 4096, 14336}, {S1x16, 14336, 4096}, {S1x16, 4096, 1024},
                              {S1x16, 8192, 28672}, {S1x16, 1024, 28672}, {S1x16g16, 4096, 4096}, {S1x16g16, 4096, 11008}, {S1x16g16, 8192, 28672},
                              {S1x16g16P, 4096, 4096}, {S1x16g16P, 4096, 11008}, {S1x16g16P, 11008, 4096}, {S1x16g16P, 4096, 14336}, {S1x16g16P, 8192, 8192}, {S1x16g16P, 8192, 28672}, {S1x16g16P, 28672, 8192}, {S2x8, 4096, 4096}, {S2x8, 4096, 11008}, {S2x8, 11008, 4096},
-                             {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}, {S8x8L, 4096, 4096}, {S8x8L, 4096, 11008}, {S8x8L, 11008, 4096}};
+                             {S1x8, 4096, 4096}, {S8x8, 4096, 4096}, {S8x8, 4096, 11008}, {S8x8L, 4096, 4096}, {S8x8L, 4096, 11008}, {S8x8L, 11008, 4096},
+                             {S8x8LP, 4096, 4096}, {S8x8LP, 4096, 11008}, {S8x8LP, 11008, 4096}};
   const bool quick = argc > 2 && !strcmp(argv[2], "quick");
   const char* only = argc > 3 ? argv[3] : nullptr;  // run only schemes whose name contains this
   const int only_out = argc > 4 ? atoi(argv[4]) : 0;
@@ -534,7 +547,10 @@ static void bench_gemv(int argc, char** argv) {
       variants.push_back({{"prefetch=8", "packed_prefetch", 8}});
       variants.push_back({{"default again", "packed_fill_rotate", 1}});
     } else if (c.s.lut) {
+      variants.push_back({{"waves=8", "lut_waves", 8}});
       variants.push_back({{"two-kernel finalize", "mb_lut_two_kernel", 1}});
+      variants.push_back({{"waves=16", "lut_waves", 16}});
+      variants.push_back({{"waves=8", "lut_waves", 8}});
     } else if (c.s.nbits == 8 && c.s.g == 8) {
       variants.push_back({{"replicas=off", "kx8_replicas", 0}});
       variants.push_back({{"replicas=force", "kx8_replicas", 2}});
@@ -604,19 +620,21 @@ static void bench_gemv(int argc, char** argv) {
 
 // ---------------------------------------------------------------- phase trace of the look-up-table kernel (trace build only)
 // Needs the library built with -DAQLM_LUT_TRACE (make trace): every wave stamps wall_clock64 (100 MHz) behind the cells.
-static void bench_lut_trace(int in, int out, int g) {
+static void bench_lut_trace(int in, int out, int g, bool planar) {
   g_ws_bytes = (size_t)64 << 20;
   CK(hipMalloc(&g_ws, g_ws_bytes));
   CK(hipMemset(g_ws, 0, g_ws_bytes));
-  const Scheme s{"8x8LUT", 8, 8, g, false, false, true};
+  const Scheme s{"8x8LUT", 8, 8, g, false, false, true, planar};
   const size_t ab1 = algo_bytes(in, out, s, 1);
   int n = (int)((600u << 20) / ab1) + 1;
   if (n > 160) n = 160;
   auto layers = make_layers(s, in, out, 1, n);
+  if (const char* w = getenv("MB_LUT_WAVES")) aqlm_hip_set_tuning("lut_waves", atoi(w));
   unsigned long long* tr = (unsigned long long*)g_ws + ((out + 1023) & ~1023);
-  const int in_groups = in / g, nslabs = (in_groups + 15) / 16, nranges = std::max(1, 256 / nslabs), nblocks = nslabs * nranges;
-  std::vector<unsigned long long> h((size_t)nblocks * 16 * 8);
-  const char* names[8] = {"entry", "loads issued", "table written", "at the barrier", "table complete", "walk starts", "rows handed in", "end"};
+  const int in_groups = in / g, nslabs = planar ? 8 * ((in_groups + 127) / 128) : (in_groups + 15) / 16, nranges = std::max(1, 256 / nslabs), nblocks = nslabs * nranges;
+  std::vector<unsigned long long> h((size_t)nblocks * 16 * 12);
+  const char* names[12] = {"entry", "loads issued", "table written", "at the barrier", "table complete", "walk starts", "rows handed in", "end", "walked + staged", "all walked", "", ""};
+  const int order[10] = {0, 1, 2, 3, 4, 5, 8, 9, 6, 7};
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipMemset(tr, 0, h.size() * 8));
     CK(hipDeviceSynchronize());
@@ -625,12 +643,13 @@ static void bench_lut_trace(int in, int out, int g) {
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
-    for (size_t i = 0; i < h.size(); i += 8) if (h[i]) t0 = std::min(t0, h[i]);
-    printf("# 8x8g%d look-up-table kernel %d->%d cold, run %d (%d workgroups x 16 waves): us since the first wave's entry (min / mean / max)\n", g, in, out, rep, nblocks);
-    for (int k = 0; k < 8; ++k) {
+    for (size_t i = 0; i < h.size(); i += 12) if (h[i]) t0 = std::min(t0, h[i]);
+    printf("# 8x8g%d look-up-table kernel%s %d->%d cold, run %d (%d workgroups): us since the first wave's entry (min / mean / max)\n", g, planar ? " (planar codes)" : "", in, out, rep, nblocks);
+    for (int kk = 0; kk < 10; ++kk) {
+      const int k = order[kk];
       double mn = 1e9, mx = 0, sum = 0; size_t cnt = 0;
-      for (size_t i = 0; i < h.size(); i += 8) {
-        if (!h[i]) continue;
+      for (size_t i = 0; i < h.size(); i += 12) {
+        if (!h[i] || !h[i + k]) continue;
         const double v = (double)(h[i + k] - t0) * 0.01;
         mn = std::min(mn, v); mx = std::max(mx, v); sum += v; ++cnt;
       }
@@ -949,7 +968,7 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "stream") || !strcmp(what, "all")) bench_stream();
   if (!strcmp(what, "rates") || !strcmp(what, "all")) bench_rates();
   if (!strcmp(what, "gemv") || !strcmp(what, "all")) bench_gemv(argc, argv);
-  if (!strcmp(what, "lut_trace")) bench_lut_trace(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 4096, argc > 4 ? atoi(argv[4]) : 32);
+  if (!strcmp(what, "lut_trace")) bench_lut_trace(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 4096, argc > 4 ? atoi(argv[4]) : 32, argc > 5 && !strcmp(argv[5], "planar"));
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
   if (!strcmp(what, "multi")) bench_multi();
   if (!strcmp(what, "trace")) {
