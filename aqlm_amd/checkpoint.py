@@ -168,3 +168,20 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_
     rep = memory_report(model)
     rep["prepack_seconds"] = time.perf_counter() - t0
     return rep
+
+
+def enable_dense_below_rows(model: torch.nn.Module, rows: int) -> int:
+    """Opt-in escape hatch: calls with 7 .. rows - 1 input rows run as a dense GEMM on a cached fp16 / bf16 copy
+    of W (built at the first such call: +2 bytes per weight resident) instead of the fused dequant -> MFMA op, which is slower
+    than a dense GEMM below ~128 rows on MI355X.  ``rows = 0`` switches it off and frees the copies.  Returns the number of layers
+    touched."""
+    from .inference import QuantizedLinear
+
+    n = 0
+    for m in model.modules():
+        if isinstance(m, QuantizedLinear):
+            m.prefer_dense_below_rows = int(rows)
+            if not rows:
+                m._dense = None
+            n += 1
+    return n

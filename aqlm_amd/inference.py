@@ -74,13 +74,21 @@ class QuantizedLinear(nn.Module):
         self._prepack_deferred = False
         self._shared_input_group = None  # set by aqlm_amd.fusion.fuse_shared_input_linears
         self._fast = None  # compiled fast lane of the decode call (aqlm_amd/_front.py); derived, rebuilt with the kernel choice
+        # Escape hatch for mid-size batches (7 .. N - 1 rows: prefill chunks, speculative verification): run them as a dense GEMM
+        # on a cached fp16 / bf16 copy of W instead of the fused dequant -> MFMA op.  Measured on MI355X at 4096 x 4096
+        # (BENCH detail `bs128_1x16g8_4096x4096`): dense 12.1 / 12.6 / 14.5 us at 16 / 32 / 64 rows against 15.6 / 16.7 / 18.1 us
+        # fused -- the fused op's 2.1 M codebook gathers cannot stream like a dense weight does.  The price is the memory the
+        # format exists to save (2 bytes per weight for every layer that uses it), so it is off (0) unless asked for:
+        # `module.prefer_dense_below_rows = 129`, or `aqlm.checkpoint.enable_dense_below_rows(model, 129)`.
+        self.prefer_dense_below_rows = 0
+        self._dense = None  # (fingerprint, W) -- derived, never saved
 
     # Everything the module derives from its parameters (kernel choice, autograd ops, prepacked / permuted codes, the compiled
     # fast lane -- a pybind11 object that cannot be pickled) is left out of copies and pickles: `copy.deepcopy(model)`,
     # `torch.save(model)` and `pickle` work at any time (EMA copies, PEFT `modules_to_save`, draft-model clones), and the copy
     # rebuilds its derived state at its first forward.  A module whose canonical codes were dropped hands them back to the copy.
     _DERIVED_DEFAULTS = {"gemv_op": None, "gemm_op": None, "use_gemv_rule": None, "_fast": None, "_packed_codes": None,
-                         "_packed_fingerprint": None, "_cpu_codes_alt": None, "_prepack_deferred": False}
+                         "_packed_fingerprint": None, "_cpu_codes_alt": None, "_prepack_deferred": False, "_dense": None}
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -123,8 +131,30 @@ class QuantizedLinear(nn.Module):
                                                              packed._ints)
             else:
                 return hip_kernel.code1x16_matmat_packed(input, packed, self.codebooks, self.scales, self.bias)
+        if (self.prefer_dense_below_rows and input.is_cuda and GEMV_MAX_ROWS < math.prod(input.shape[:-1]) < self.prefer_dense_below_rows
+                and input.dtype == self.codebooks.dtype and not (torch.is_grad_enabled() and input.requires_grad)
+                and not torch.compiler.is_compiling()):
+            return torch.nn.functional.linear(input, self._dense_weight(), self.bias)
         op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
         return op.apply(input, self._canonical_codes(), self.codebooks, self.scales, self.bias)
+
+    def _dense_weight(self) -> torch.Tensor:
+        """W in the storage dtype, dequantised once and kept while codes / codebooks / scales are what they were (same rounding
+        as the reference's large-batch path: dequantise, then a library GEMM -- cuda_kernel.cpp:249-301)."""
+        def ver(t):
+            try:
+                return t._version
+            except RuntimeError:
+                return 0
+
+        fp = (self._codes_fingerprint(), self.codebooks.data_ptr(), ver(self.codebooks), self.scales.data_ptr(), ver(self.scales))
+        if self._dense is None or self._dense[0] != fp:
+            from .utils import _dequantize_weight, unpack_int_data
+
+            with torch.no_grad():
+                w = _dequantize_weight(unpack_int_data(self._canonical_codes(), self.nbits_per_codebook), self.codebooks, self.scales)
+            self._dense = (fp, w.to(self.codebooks.dtype).contiguous())
+        return self._dense[1]
 
     def _codes_fingerprint(self):
         c = self.codes
@@ -195,6 +225,7 @@ class QuantizedLinear(nn.Module):
         self._packed_codes = None
         self._cpu_codes_alt = None
         self._prepack_deferred = False
+        self._dense = None
         return out
 
     def prepare_matmul_op(self, input: torch.Tensor):

@@ -417,6 +417,24 @@ def large_batch_detail(dev, reps):
         by_rows[f"rows{rows}"] = {"fused_mfma_us": timegraph(lambda l, xin: hk.code1x16_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), xr),
                                   "dense_fp16_gemm_us": timegraph(lambda l, xin: F.linear(xin, Ws[l.seed % 8]), xr)}
     out["graph_by_rows"] = by_rows
+    # 2..8 rows (speculative decode, small-batch serving; the module sends <= 6 rows to the matvec kernels): the prepacked matvec
+    # (one more LDS read + 4 dots per entry and row) against the MFMA op (cost of 16 rows whatever the count), hipGraph, cold
+    small = {}
+    for (fi, fo) in ((4096, 4096), (4096, 11008)):
+        ls = [Layer(fi, fo, 1, 16, 8, 434343 + i, dev, batch=8) for i in range(max(8, int(600e6 / algorithmic_bytes(fi, fo)) + 1))]
+        keep, layers = layers, ls
+        try:
+            per = {}
+            for rows in (2, 3, 4, 5, 6, 8):
+                xr = torch.randn((rows, fi), device=dev, dtype=torch.float16)
+                mv = timegraph(lambda l, xin: hk.code1x16_matmat_packed(xin, l.packed, l.codebooks, l.scales, None), xr) if ls[0].packed is not None else None
+                mm = timegraph(lambda l, xin: hk.code1x16_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), xr)
+                per[f"rows{rows}"] = {"prepacked_matvec_us": mv, "mfma_op_us": mm}
+            small[f"{fi}->{fo}"] = per
+        finally:
+            layers = keep
+        del ls
+    out["small_batch_rows"] = small
     # why the op switches to dequant + library GEMM above FUSED_MFMA_MAX_ROWS: the fused kernel re-gathers per 128-row slab
     old = hk.FUSED_MFMA_MAX_ROWS
     try:
@@ -538,7 +556,60 @@ def sharded_70b(lib, dev, rank, world, steps):
                 out["xgmi_one_shot"] = {"skipped": "no peer access between all GPUs of the node, or a shard is not prepacked"}
         except Exception as e:  # noqa: BLE001 - diagnostics only
             out["xgmi_one_shot"] = {"error": f"{type(e).__name__}: {e}"}
+    out["mlp_plans"] = sharded_mlp_plans(lib, dev, rank, world, steps)
     return out
+
+
+def sharded_mlp_plans(lib, dev, rank, world, steps):
+    """The Llama-3-70B MLP (gate, up: 8192 -> 28672; down: 28672 -> 8192) under the two tensor-parallel plans of SURVEY.md 8(e), per rank:
+      * in-split everywhere (north-star config 5 applied to every layer): gate / up shards 8192/N -> 28672, down 28672/N -> 8192,
+        THREE all-reduces (28672, 28672, 8192 values);
+      * Megatron pairing (aqlm_amd.sharded.shard_mlp): gate / up out-split 8192 -> 28672/N with NO collective, down in-split on the
+        same cut, ONE all-reduce of 8192 values.
+    With world == 1 the shard shapes of N = 8 are timed without collectives (what every rank of 8 would run): the pairing's kernels
+    are cheaper before any collective is counted."""
+    import torch.distributed as dist
+
+    parts = world if world > 1 else 8
+    hid, inter = 8192, 28672
+    i_sh = (inter // parts + 63) // 64 * 64  # the pairing cuts the inner dimension at whole 8-group code words
+    plans = {"in_split_everywhere": [(hid // parts, inter), (hid // parts, inter), (inter // parts // 8 * 8, hid)],
+             "paired": [(hid, i_sh), (hid, i_sh), (i_sh, hid)]}
+    reduces = {"in_split_everywhere": [inter, inter, hid], "paired": [0, 0, hid]}
+    res = {"parts": parts, "note": "per rank: three shard matvecs per MLP (prepacked kernel), hipGraph-timed kernels; collectives "
+                                   "(fp16, RCCL) timed eagerly behind them when world > 1"}
+    for name, shapes in plans.items():
+        sets = [[Layer(fi, fo, 1, 16, 8, 2000 + rank * 100 + 10 * k + i, dev) for k, (fi, fo) in enumerate(shapes)] for i in range(6)]
+        flat = [l for st in sets for l in st]
+        gp = GraphedPass(flat, lib)
+        us = gp.time_replays(max(4, steps // 2)) * 1e3 / len(sets)
+        entry = {"shard_shapes": [f"{fi}->{fo}" for fi, fo in shapes], "kernels_us_per_mlp": us,
+                 "collectives_per_mlp": sum(1 for n in reduces[name] if n), "allreduce_values": [n for n in reduces[name] if n]}
+        if world > 1:
+            s = torch.cuda.current_stream()
+            bufs = [torch.zeros((n,), device=dev, dtype=torch.float16) if n else None for n in reduces[name]]
+
+            def one(st):
+                for l, b in zip(st, bufs):
+                    l.launch(lib, s.cuda_stream)
+                    if b is not None:
+                        dist.all_reduce(b)
+
+            for st in sets[:2]:
+                one(st)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            n = 30
+            for i in range(n):
+                one(sets[i % len(sets)])
+            torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t0) / n], device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            entry["end_to_end_us_per_mlp"] = float(dt.item()) * 1e6
+        res[name] = entry
+        del gp, flat, sets
+    return res
 
 
 def launcher_command(gpus, argv, port=None):

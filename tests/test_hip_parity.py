@@ -1188,6 +1188,26 @@ def test_gemv_8x8_lut_planar_multi_is_bit_identical_to_separate_launches(hk, g, 
         check_close(y.float().cpu().numpy(), y64, dtype, f"planar lut multi 8x8g{g} {fin}->{L['codes'].shape[0]}")
 
 
+@pytest.mark.parametrize("planar", [True, False])
+def test_gemv_8x8_lut_many_rows_per_workgroup(hk, planar):
+    """More rows per workgroup than one staging pass holds (2048): the walk / hand-in loop runs several passes with the staging
+    area reused between barriers.  100 000 rows x 128 groups (3125 rows per workgroup in both layouts); checked against the C oracle (streams the rows, no dense W)."""
+    fin, fout, g = 4096, 100_000, 32
+    L = orc.make_layer(4900, fin, fout, 8, 8, g, batch=1, bias=True)
+    T = to_dev(L, torch.float16)
+    ref = c_oracle.DequantGemv(L["codebooks"], L["codes"], L["scales"], L["bias"], 8, nthreads=0)
+    y64 = ref(L["x"][0]).copy()
+    if planar:
+        pl = hk.planar_8x8_pack(T["codes"], g, codebooks=T["codebooks"])
+        y = hk.code8x8_matmat_planar(T["x"], pl, T["codebooks"], T["scales"], T["bias"])
+        assert torch.equal(hk.code8x8_matmat_planar(T["x"], pl, T["codebooks"], T["scales"], T["bias"]), y)
+    else:
+        y = hk._gemv_8x8_lut(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    check_close(y[0].float().cpu().numpy(), y64, torch.float16, f"lut, 100000 rows, planar={planar}")
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    assert int(hk._LUT_CELLS[key].abs().max()) == 0
+
+
 def test_8x8_module_uses_planar_codes_and_can_drop_the_canonical_ones(hk):
     """QuantizedLinear of an 8x8 scheme: single-row calls run on the planar copy, 2..6 rows and backward on the canonical codes;
     dropping the canonical codes keeps 2.0 bits per weight of codes resident and state_dict() lossless; fused q/k/v in one launch."""
@@ -2030,3 +2050,33 @@ def test_gpu_modules_copy_and_pickle_after_a_forward(hk):
         for n in Ls:
             assert torch.equal(getattr(c, n)(x), want[n]), n
             assert torch.equal(getattr(holder, n)(x), want[n]), n
+
+
+def test_prefer_dense_below_rows_escape_hatch(hk):
+    """Opt-in: 7 .. N - 1 rows run as a dense GEMM on a cached copy of W (the fused MFMA op is slower than dense below ~128 rows);
+    1 .. 6 rows and >= N rows keep their kernels; the copy follows the parameters; off by default."""
+    from aqlm.checkpoint import enable_dense_below_rows
+
+    fin, fout = 1024, 512
+    L = orc.make_layer(515, fin, fout, 1, 16, 8, batch=40, bias=True)
+    m, T = _module_from(L, 1, 16, 8, fin, fout, torch.float16)
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    with torch.no_grad():
+        assert m.prefer_dense_below_rows == 0
+        base = m(T["x"][:20])
+        assert m._dense is None
+        holder = torch.nn.ModuleDict({"l": m})
+        assert enable_dense_below_rows(holder, 33) == 1
+        y20 = m(T["x"][:20])
+        assert m._dense is not None and tuple(m._dense[1].shape) == (fout, fin)
+        check_close(y20.float().cpu().numpy(), y64[:20], torch.float16, "dense hatch, 20 rows")
+        check_close(y20.float().cpu().numpy(), base.double().cpu().numpy(), torch.float16, "dense hatch vs fused op")
+        assert torch.equal(m(T["x"][:3]), hk.code1x16_matmat(T["x"][:3], T["codes"], T["codebooks"], T["scales"], T["bias"]))  # matvec path
+        w_before = m._dense[1]
+        m(T["x"][:40])                                   # 40 rows >= 33: the fused op, no new copy
+        assert m._dense[1] is w_before
+        m.scales.mul_(2.0)                               # parameters change: the copy is rebuilt
+        y20b = m(T["x"][:20])
+        check_close(y20b.float().cpu().numpy(), 2.0 * (y64[:20] - L["bias"].astype(np.float64)) + L["bias"].astype(np.float64), torch.float16, "dense hatch after a scale update")
+        enable_dense_below_rows(holder, 0)
+        assert m._dense is None and m.prefer_dense_below_rows == 0
