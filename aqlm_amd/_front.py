@@ -13,7 +13,7 @@ import warnings
 from . import _native  # noqa: F401  (loads libaqlm_hip.so first: the extension links against the same file)
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_aqlm_front.so")
-KIND_PACKED_1X16, KIND_GEMV_1X16, KIND_GEMV_KX8 = 0, 1, 2
+KIND_PACKED_1X16, KIND_GEMV_1X16, KIND_GEMV_KX8, KIND_LUT_PLANAR_8X8 = 0, 1, 2, 3
 
 ext = None
 # AQLM_AMD_HIP_LIB points the ctypes side at ANOTHER build of the library; the extension is linked against the in-tree one

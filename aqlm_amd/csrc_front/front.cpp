@@ -27,7 +27,7 @@
 
 namespace {
 
-enum Kind : int { kPacked1x16 = 0, kGemv1x16 = 1, kGemvKx8 = 2 };
+enum Kind : int { kPacked1x16 = 0, kGemv1x16 = 1, kGemvKx8 = 2, kLutPlanar8x8 = 3 };
 
 struct Watched {  // a parameter of the module: same Python object, same storage, same version as when the lane was built
   PyObject* obj = nullptr;
@@ -82,7 +82,8 @@ class FastGroup;
 class FastLinear {
  public:
   // params: the module's _parameters dict (codes, codebooks, scales, bias).  packed / desc_bytes: the prepacked buffer
-  // and the bytes of its aqlm_hip_packed_desc (kind 0 only).
+  // and the bytes of its aqlm_hip_packed_desc (kind 0), or the planar 8x8 codes and the 4 bytes of their codebook bound (kind 3:
+  // single-row look-up-table matvec, aqlm_hip_gemv_8x8_lut_planar; the reference reaches Triton here, kernel_selector.py:91-94).
   FastLinear(py::dict params, int kind, c10::optional<at::Tensor> packed, std::string desc_bytes, int64_t in_features,
              int64_t out_features, int64_t num_codebooks, int64_t in_group_size, bool watch_codes, int64_t max_rows)
       : params_(std::move(params)), kind_(kind), in_(in_features), out_(out_features), K_((int)num_codebooks),
@@ -105,6 +106,12 @@ class FastLinear {
       packed_ = *packed;
       std::memcpy(&desc_, desc_bytes.data(), sizeof(desc_));
       TORCH_CHECK(desc_.codebook_absmax > 0.f, "FastLinear: the packed lane needs the codebook range (single-kernel finalize)");
+    } else if (kind_ == kLutPlanar8x8) {
+      TORCH_CHECK(packed && packed->is_cuda() && desc_bytes.size() == sizeof(float), "FastLinear: planar codes + codebook bound required");
+      packed_ = *packed;
+      std::memcpy(&absmax_, desc_bytes.data(), sizeof(float));
+      TORCH_CHECK(absmax_ > 0.f && K_ == 8, "FastLinear: the look-up-table lane needs 8 codebooks and a positive codebook bound");
+      max_rows_ = 1;
     } else {
       TORCH_CHECK(codes_.defined() && codes_.is_cuda() && codes_.is_contiguous(), "FastLinear: canonical codes required");
     }
@@ -125,11 +132,15 @@ class FastLinear {
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
     void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream();
     const void* bias = bias_ ? bias_->data_ptr() : nullptr;
-    void* cells = kind_ == kPacked1x16 ? stream_cells(x, stream, rows * out_ * 8) : nullptr;
+    void* cells = (kind_ == kPacked1x16 || kind_ == kLutPlanar8x8) ? stream_cells(x, stream, rows * out_ * 8) : nullptr;
+    if (kind_ == kLutPlanar8x8 && !cells) return py::none();  // (a capture on a stream without cells: the Python path's two-kernel form)
     int rc;
     {
       py::gil_scoped_release nogil;
-      if (kind_ == kPacked1x16 && cells)
+      if (kind_ == kLutPlanar8x8)
+        rc = aqlm_hip_gemv_8x8_lut_planar(packed_.data_ptr(), codebooks_.data_ptr(), scales_.data_ptr(), bias, x2.data_ptr(), y.data_ptr(),
+                                          (int)out_, (int)in_, g_, dtype_, absmax_, cells, (size_t)kCellsBytes, 1, stream);
+      else if (kind_ == kPacked1x16 && cells)
         rc = aqlm_hip_gemv_1x16_packed_cells(&desc_, packed_.data_ptr(), codebooks_.data_ptr(), scales_.data_ptr(), bias, x2.data_ptr(),
                                              y.data_ptr(), (int)rows, x2.stride(0), out_, dtype_, cells, (size_t)kCellsBytes, stream);
       else if (kind_ == kPacked1x16)
@@ -169,6 +180,7 @@ class FastLinear {
   c10::optional<at::Tensor> bias_;
   Watched w_codes_, w_cb_, w_scales_, w_bias_;
   aqlm_hip_packed_desc desc_{};
+  float absmax_ = 0.f;
 };
 
 // Shared-input launch of 2..AQLM_HIP_MAX_SEGMENTS members of one kind (q/k/v, gate/up; aqlm_amd/fusion.py): one check of x, one
@@ -204,17 +216,20 @@ class FastGroup {
     if (x2.stride(1) != 1 || (rows > 1 && x2.stride(0) % 8 != 0) || (reinterpret_cast<uintptr_t>(x2.data_ptr()) & 15u)) x2 = x2.contiguous();
     const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
     void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream();
-    void* cells = a.kind_ == kPacked1x16 ? stream_cells(x, stream, rows * total * 8) : nullptr;
-    if (a.kind_ == kPacked1x16 && !cells) return py::none();
+    const bool needs_cells = a.kind_ == kPacked1x16 || a.kind_ == kLutPlanar8x8;
+    void* cells = needs_cells ? stream_cells(x, stream, rows * total * 8) : nullptr;
+    if (needs_cells && !cells) return py::none();
     const int n = (int)m_.size();
     aqlm_hip_segment seg[AQLM_HIP_MAX_SEGMENTS];
     const aqlm_hip_packed_desc* descs[AQLM_HIP_MAX_SEGMENTS];
+    float absmax[AQLM_HIP_MAX_SEGMENTS];
     std::vector<at::Tensor> ys;
     ys.reserve(n);
     for (int k = 0; k < n; ++k) {
       FastLinear& f = *m_[k];
       ys.push_back(at::empty({rows, f.out_}, x.options()));
-      seg[k].codes = a.kind_ == kPacked1x16 ? f.packed_.data_ptr() : f.codes_.data_ptr();
+      seg[k].codes = needs_cells ? f.packed_.data_ptr() : f.codes_.data_ptr();
+      absmax[k] = f.absmax_;
       seg[k].codebook = f.codebooks_.data_ptr();
       seg[k].scales = f.scales_.data_ptr();
       seg[k].bias = f.bias_ ? f.bias_->data_ptr() : nullptr;
@@ -227,7 +242,9 @@ class FastGroup {
     int rc;
     {
       py::gil_scoped_release nogil;
-      if (a.kind_ == kPacked1x16)
+      if (a.kind_ == kLutPlanar8x8)
+        rc = aqlm_hip_gemv_8x8_lut_planar_multi(seg, absmax, n, x2.data_ptr(), (int)a.in_, a.g_, a.dtype_, cells, (size_t)kCellsBytes, 1, stream);
+      else if (a.kind_ == kPacked1x16)
         rc = aqlm_hip_gemv_1x16_packed_multi_cells(seg, descs, n, x2.data_ptr(), (int)a.in_, (int)rows, x2.stride(0), a.dtype_, cells,
                                                    (size_t)kCellsBytes, stream);
       else if (a.kind_ == kGemv1x16)

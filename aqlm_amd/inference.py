@@ -298,9 +298,13 @@ class QuantizedLinear(nn.Module):
 
         packed = self._packed_codes
         scheme = (self.num_codebooks, self.nbits_per_codebook, self.in_group_size)
-        if packed is not None and not isinstance(packed, hip_kernel.PackedCodes):
-            return  # planar 8x8 codes: Python path (one launch, no compiled lane yet)
-        if packed is not None:
+        if isinstance(packed, hip_kernel.PlanarCodes):
+            if not (hip_kernel.USE_8X8_LUT and hip_kernel.USE_8X8_LUT_FUSED and packed.codebook_absmax > 0.0 and packed.range_is_current(self.codebooks)):
+                return  # two-kernel form (needs a workspace): Python path
+            import struct
+
+            kind, buf, desc = _front.KIND_LUT_PLANAR_8X8, packed.buf, struct.pack("<f", packed.codebook_absmax)
+        elif packed is not None:
             if not (hip_kernel.FUSED_FINALIZE and packed.desc.codebook_absmax > 0.0 and packed.range_is_current(self.codebooks)):
                 return  # two-kernel finalize (needs a workspace): Python path
             kind, buf, desc = _front.KIND_PACKED_1X16, packed.buf, bytes(packed.desc)

@@ -1227,6 +1227,11 @@ def test_8x8_module_uses_planar_codes_and_can_drop_the_canonical_ones(hk):
         y1 = holder.q_proj(x1)
         assert isinstance(holder.q_proj._packed_codes, hk.PlanarCodes)
         assert torch.equal(y1, hk.code8x8_matmat_planar(x1, holder.q_proj._packed_codes, T["codebooks"], T["scales"], T["bias"]))
+        from aqlm_amd import _front
+        if _front.available():   # the compiled lane serves single rows on the same kernel, and hands anything else back
+            assert holder.q_proj._fast is not None and holder.q_proj._fast.kind == _front.KIND_LUT_PLANAR_8X8
+            assert torch.equal(holder.q_proj._fast(x1), y1) and holder.q_proj._fast(x3) is None
+            assert torch.equal(holder.q_proj(x1), y1)
         y64 = orc.dequantize_gemm(Ls["q_proj"]["x"], Ls["q_proj"]["codes"], Ls["q_proj"]["codebooks"], Ls["q_proj"]["scales"], Ls["q_proj"]["bias"])
         check_close(y1.float().cpu().numpy(), y64[:1], torch.float16, "8x8 module, one row")
         check_close(holder.q_proj(x3).float().cpu().numpy(), y64, torch.float16, "8x8 module, three rows")
