@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (AMD's 5 PF figure includes 2:1 sparsity)
 # 1x16 g8 layers with at least this many codes run the prepacked (slice-bucketed) decode kernel, like
 # aqlm_amd.inference.PREPACK_MIN_CODES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
 PACK_MIN_OUT = 500_000
@@ -612,6 +613,27 @@ def sharded_mlp_plans(lib, dev, rank, world, steps):
     return res
 
 
+def gpu_reference_baseline():
+    """The reference's own GPU kernel on this GPU, beside `cpu_baseline`: its Triton gemv (triton_kernel.py:30-205 -- the only reference
+    kernel that runs on ROCm; its CUDA extension carries inline PTX), staged unmodified under oracle/_ref/ by `make -C oracle ref`,
+    timed with this file's protocol (hipGraph replay over > 600 MB of distinct layers) on 1x16g8 4096 -> 4096 next to the HIP operator.
+    Checker side only: nothing under aqlm_amd/ imports it.  All four cases: profiles/r04_reference_triton.json."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import reference_triton as rt
+
+        res = rt.run(quick=True)
+        if not res.get("available"):
+            return {"available": False, "why": res.get("why")}
+        t, p = res["timing"][0], res["parity"][0]
+        return {"available": True, "kind": "reference", "kernel": "aqlm.inference_kernels.triton_kernel.triton_matmul (Triton, autotuned)",
+                "workload": "1x16g8 4096->4096, bs=1, cold (layers rotated through > 600 MB), hipGraph", "us": t["reference_triton_us"],
+                "value": t["reference_triton_GBps"], "unit": "GB/s", "hip_operator_us": t["hip_us"], "hip_speedup": t["speedup"],
+                "reference_autotune_s": t["reference_autotune_s"], "parity_mean_rel": p}
+    except Exception as e:  # noqa: BLE001 - a reported extra, never fatal for the benchmark
+        return {"available": False, "why": f"{type(e).__name__}: {e}"}
+
+
 def launcher_command(gpus, argv, port=None):
     """The command `python bench.py --gpus N` re-executes itself as when it was not started by torch.distributed.run
     (the driver's own form: one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
@@ -915,11 +937,46 @@ def main():
                 del gf, fused
             del gp, tok
         detail["bs128_1x16g8_4096x4096"] = large_batch_detail(dev, reps)
+        # ---- roofline objects of BASELINE configs 3 and 4 (same fields as the top-level `roofline` of config 2).  Config 3:
+        # the two schemes at the Llama-2-7B shapes 4096->4096 / 4096->11008, one launch per layer, cold (> 600 MB rotated);
+        # traffic = HBM bytes per launch from the committed PMC passes of the kernels (profiles/, rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE over the microbenchmark of the same kernel; null when absent).  Config 4: dense MFMA peak.
+        def pmc_traffic(fname):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                c = pm["counters_mean_per_dispatch"]
+                return 2.0 * c["FETCH_SIZE"] * 1024 + c.get("WRITE_SIZE", 0.0) * 1024  # KiB counters; reads x 2 (gfx950 correction)
+            except Exception:
+                return None
+
+        for sname, (K, nb, g), pmc in (("2x8g8", (2, 8, 8), "r04_2x8_rep_kernel_pmc.json"), ("8x8g32", (8, 8, 32), "r04_8x8_lut_planar_kernel_pmc.json")):
+            per, tot_b, tot_us = {}, 0.0, 0.0
+            for fi, fo in ((4096, 4096), (4096, 11008)):
+                ls = [Layer(fi, fo, K, nb, g, 9500 + rank * 10000 + i, dev) for i in range(int(600e6 / algorithmic_bytes(fi, fo, K, nb, g)) + 1)]
+                gpx = GraphedPass(ls, lib)
+                us = gpx.time_replays(reps) * 1e3 / gpx.n
+                per[f"{fi}->{fo}"] = {"cold_us": us, "GBps": ls[0].bytes / us * 1e-3, "frac_of_8TBps": ls[0].bytes / us * 1e-3 / HBM_PEAK_GBPS}
+                tot_b += ls[0].bytes
+                tot_us += us
+                del gpx, ls
+            ach = tot_b / tot_us * 1e-3
+            detail[f"config3_{sname}"] = {"roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                                                       "traffic": pmc_traffic(pmc), "traffic_source": f"profiles/{pmc} (4096-row layers of the kernel's microbenchmark; per launch)"},
+                                          "per_shape": per,
+                                          "kernel": "gemv_kx8_rep_kernel (16-fold replicated codebooks in LDS)" if K == 2 else
+                                                    "gemv_8x8_lut_kernel on planar codes (per-token look-up tables in LDS)"}
+        lb = detail["bs128_1x16g8_4096x4096"]
+        detail["config4_bs128"] = {"roofline": {"bound": "mfma", "achieved": lb["fused_TFLOPs"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": lb["fused_TFLOPs"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("r03_gemm_glds_kernel_pmc.json")},
+                                   "fused_mfma_us": lb["fused_mfma_us"], "dense_fp16_gemm_us": lb["dense_fp16_gemm_us"],
+                                   "kernel": "gemm_1x16_glds_kernel + gemm_glds_finalize_kernel"}
         result["detail"] = detail
         result["sharded_70b"] = sharded_70b(lib, dev, rank, world, args.steps)
 
     if rank == 0:  # rank 0 at every N (the other ranks wait at the barrier below; outside every timed region)
         result["cpu_baseline"] = None if args.no_cpu else cpu_baseline()
+        if not args.no_cpu:
+            result["gpu_reference_baseline"] = gpu_reference_baseline()
 
     if rank == 0:
         print(json.dumps(result))
