@@ -114,7 +114,12 @@ constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (
 constexpr int PK_CNT_BITS = PK_S_LOG + 1;                       // counts 0 .. PK_S
 constexpr unsigned long long PK_CNT_MASK = (1ull << PK_CNT_BITS) - 1ull;
 constexpr int PK_VAL_SHIFT = 2 * PK_CNT_BITS;                   // 10 for 16 slices
-constexpr int PK_FIX_BITS = 51 - PK_S_LOG;                      // |slice sum| < 2^e is stored in units of 2^(e - PK_FIX_BITS): PK_S addends stay below 2^51
+// |slice sum| < 2^e is stored in units of 2^(e - PK_FIX_BITS).  The finite test lets an addend reach 2 x the bound (rounding slack, a
+// slightly stale codebook range), so PK_S addends stay below 2^(PK_FIX_BITS + 1 + PK_S_LOG), which must fit the signed sum field of
+// 64 - PK_VAL_SHIFT bits: PK_FIX_BITS <= 60 - 3 PK_S_LOG.  16 slices: 47 (the 51 - PK_S_LOG of rounds 2-3); 32 slices (g16): 45 -- with
+// 46 a stale range could wrap the sum instead of giving the NaN the header promises.
+constexpr int PK_FIX_BITS = (51 - PK_S_LOG) < (60 - 3 * PK_S_LOG) ? (51 - PK_S_LOG) : (60 - 3 * PK_S_LOG);
+static_assert(PK_FIX_BITS + 1 + PK_S_LOG <= 63 - 2 * (PK_S_LOG + 1), "PK_S addends of up to twice the bound must fit the sum field");
 
 // x copies (batch-1 kernel): copy c of x starts at 16-B slot c * stride with stride = 4 (mod 16), i.e. its bank-group
 // pattern is rotated by 4 c: an entry can read the copy whose bank group is still free in its service group.
