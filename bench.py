@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the driver's measurement contract for the AQLM QuantizedLinear matvec path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -18,8 +18,11 @@ N > 1 = N independent replicas of the step (one process per GPU, no data-path co
 
 Extra objects: "roofline" (dominant kernel = the 1x16 gemv; duration from HIP events over the timed region on the
 launch stream, i.e. including inter-launch gaps), "cpu_baseline" (oracle C port of the reference CPU path on the host
-cores, rank 0, N=1 only, bounded sample), "detail" (per-shape cold/warm timings, Llama-3-8B / Llama-2-7B tokens/s,
-other schemes).
+cores, rank 0, bounded sample), "gpu_reference_baseline" (the reference's own Triton gemv on this GPU, staged under
+oracle/_ref/ -- checker side only), "parity_mean_rel_vs_cpu_oracle" (tripwire against the C oracle, outside the timed region),
+"config" (workload + the load-time / memory price of the prepacked path), "detail" (per-shape cold/warm timings, Llama-3-8B /
+Llama-2-7B / Llama-3-70B tokens/s, roofline objects of BASELINE configs 3 and 4, 2..8-row cross-over), "sharded_70b"
+(+ the two tensor-parallel plans of the 70B MLP).
 """
 import argparse
 import json
