@@ -15,7 +15,7 @@ MB=$R/tools/microbench/mb
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -1
 # kernel counters first: bench.py reads the traffic of configs 3 / 4 from profiles/
-for spec in "2x8g8 4096 kx8 gemv_kx8_rep_kernel r04_2x8_rep_kernel_pmc.json" "8x8g32LUTP 4096 lutp gemv_8x8_lut_kernel r04_8x8_lut_planar_kernel_pmc.json"; do
+for spec in "2x8g8 4096 kx8 gemv_kx8_rep_kernel r04_2x8_rep_kernel_pmc.json" "8x8g32LUTP 4096 lutp gemv_8x8_lut_kernel r04_8x8_lut_planar_kernel_pmc.json" "8x8g32LUT= 4096 lutc gemv_8x8_lut_kernel r04_8x8_lut_kernel_pmc.json"; do
   set -- $spec
   bash tools/gpu/gpu_pmc.sh $1 $2 ${TAG}_$3 > $OUT/pmc_$3.log 2>&1
   python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$3 $4 $OUT/$5 > /dev/null

@@ -486,7 +486,10 @@ static void bench_gemv(int argc, char** argv) {
   printf("# empty-kernel graph: %.2f us per launch (launch gap floor)\n", gap);
   printf("%-9s %6s %6s %2s %-26s %9s %9s %8s %8s\n", "scheme", "in", "out", "B", "variant", "cold_us", "warm_us", "coldGB/s", "%8TB/s");
   for (const auto& c : cases) {
-    if (only && !strstr(c.s.name, only)) continue;
+    if (only) {  // substring of the scheme name; a trailing '=' asks for the exact name ("8x8g32LUT=" does not match 8x8g32LUTP)
+      const size_t n = strlen(only);
+      if (n && only[n - 1] == '=' ? !(strlen(c.s.name) == n - 1 && !strncmp(c.s.name, only, n - 1)) : !strstr(c.s.name, only)) continue;
+    }
     if (only_out && c.out != only_out) continue;
     const size_t ab1 = algo_bytes(c.in, c.out, c.s, 1);
     int n = (int)((600u << 20) / ab1) + 1;
