@@ -124,7 +124,11 @@ class QuantizedLinear(nn.Module):
 
             if isinstance(packed, hip_kernel.PlanarCodes):
                 # 8x8 on planar codes: the look-up-table matvec takes one row; anything else goes through the ordinary ops below
-                if input.numel() == input.shape[-1] and not torch.compiler.is_compiling():
+                if input.numel() == input.shape[-1]:
+                    if torch.compiler.is_compiling():  # traced: the dispatcher op (it has a fake implementation)
+                        return torch.ops.aqlm.code8x8_matmat_planar(input, packed.buf, self.codebooks, self.scales, self.bias,
+                                                                    [packed.out_features, packed.in_features, packed.in_group_size],
+                                                                    packed.codebook_absmax)
                     return hip_kernel.code8x8_matmat_planar(input, packed, self.codebooks, self.scales, self.bias)
             elif torch.compiler.is_compiling():  # traced: go through the dispatcher op (it has a fake implementation)
                 return torch.ops.aqlm.code1x16_matmat_packed(input, packed.buf, self.codebooks, self.scales, self.bias,

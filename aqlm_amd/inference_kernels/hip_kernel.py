@@ -1086,6 +1086,25 @@ _LIB.impl("code1x16_matmat_packed", _packed_op, "CUDA")
 torch.library.register_fake("aqlm::code1x16_matmat_packed")(_fake_packed)
 
 
+# the planar 8x8 matvec as a dispatcher op (same reason; geometry = [out_features, in_features, in_group_size], the codebook bound
+# travels as a float: 0 = unknown -> the two-kernel form)
+def _planar_op(input, planar, codebooks, scales, bias, geometry, codebook_absmax):
+    pl = PlanarCodes(planar, int(geometry[0]), int(geometry[1]), int(geometry[2]))
+    pl.codebook_absmax = float(codebook_absmax)
+    pl._range_of = (codebooks.data_ptr(), _version(codebooks))  # the caller's bound is taken at its word
+    return code8x8_matmat_planar(input, pl, codebooks, scales, bias)
+
+
+def _fake_planar(input, planar, codebooks, scales, bias, geometry, codebook_absmax):
+    return torch.empty(input.shape[:-1] + (int(geometry[0]),), device=input.device, dtype=input.dtype)
+
+
+_LIB.define("code8x8_matmat_planar(Tensor input, Tensor planar, Tensor codebooks, Tensor scales, Tensor? bias, int[] geometry, "
+            "float codebook_absmax) -> Tensor")
+_LIB.impl("code8x8_matmat_planar", _planar_op, "CUDA")
+torch.library.register_fake("aqlm::code8x8_matmat_planar")(_fake_planar)
+
+
 # what benchmark/matmul_benchmark.py:6,103 reaches for: CUDA_KERNEL.code1x16_matmat etc. (pybind module in the
 # reference, cuda_kernel.cpp:686-699)
 HIP_KERNEL = SimpleNamespace(

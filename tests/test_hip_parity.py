@@ -1250,6 +1250,14 @@ def test_8x8_module_uses_planar_codes_and_can_drop_the_canonical_ones(hk):
         for n in Ls:
             Tn = to_dev(Ls[n], torch.float16)
             assert torch.equal(outs[n], hk.code8x8_matmat_planar(x1, want[n], Tn["codebooks"], Tn["scales"], Tn["bias"])), n
+    # torch.compile traces a module on planar codes through the dispatcher op (fake implementation), also without canonical codes
+    with torch.no_grad():
+        solo, _ = _module_from(Ls["q_proj"], 8, 8, 32, fin, 1024, torch.float16)
+        y_solo = solo(x1)
+        assert isinstance(solo._packed_codes, hk.PlanarCodes)
+        solo.drop_canonical_codes()
+        cm = torch.compile(solo, fullgraph=True)
+        assert torch.equal(cm(x1), y_solo)
     holder.q_proj.restore_canonical_codes()
     xg = x1.clone().requires_grad_(True)
     holder.q_proj(xg).sum().backward()
