@@ -7,6 +7,8 @@ Tolerances (BASELINE.json north_star: "fp16 output within 1e-3 rel"):
            the reference's own bf16 CPU result is 2-3e-3 off, see tests/golden generator log);
   * integer / layout properties (row permutation, batch consistency, zero input): bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1502,7 +1504,7 @@ def test_prepack_model_runs_the_load_time_repack_eagerly(hk):
 
 
 # ------------------------------------------------------------------ randomized shapes (seeded): every route, odd sizes
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AQLM_FUZZ_SEEDS", "48"))))  # AQLM_FUZZ_SEEDS=600: the long one-off sweep
 def test_randomized_layer_against_oracle(hk, seed):
     """Random scheme / shape / batch / dtype / bias per seed, module-level forward (so the gemv rule, the large-batch
     op, the prepacked route -- threshold lowered -- and the generic kernels all get hit) against the fp64 oracle."""
@@ -1559,7 +1561,7 @@ def test_randomized_layer_against_oracle(hk, seed):
         assert rel <= (2e-3 if dtype == torch.float16 else 1.2e-2), f"seed {seed}: grad_input mean-rel {rel:.3e}"
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AQLM_FUZZ_GROUP_SEEDS", "10"))))
 def test_randomized_shared_input_groups(hk, seed):
     """Random member count / scheme / shapes / rows for shared-input groups; 1x16 outputs must equal the unfused
     modules bit for bit, K x 8 outputs within the parity bound; both against the oracle."""
