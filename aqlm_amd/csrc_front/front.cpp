@@ -17,8 +17,11 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/hip/HIPGraphsC10Utils.h>
 
+#include <torch/library.h>
+
 #include <map>
 #include <mutex>
+#include <unordered_map>
 
 #include <cstring>
 #include <string>
@@ -266,6 +269,222 @@ class FastGroup {
   std::vector<std::shared_ptr<FastLinear>> m_;
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The reference's stateless ops as compiled dispatcher kernels: aqlm::code1x16_matmat, code2x8_matmat, code1x8_matmat
+// (cuda_kernel.cpp:148-182, 387-421, 552-586 are C++ too; its benchmark/matmul_benchmark.py:103 and vLLM-style integrations call
+// them directly).  Decode calls -- 1..6 rows (1..8 for K x 8) of a well-formed layer -- are launched from here; everything else
+// (more rows -> MFMA / dequant + GEMM, an unknown layer that may want packing, any malformed argument and its error message)
+// is handed to the Python implementation of the same op (hip_kernel.py), which stays the definition of the behaviour.
+//
+// Large 1x16 layers run on the prepacked kernel.  The Python side owns that cache (which layer is packed, eviction, weak
+// references to the codes tensors); after it packed a layer it REGISTERS the result here under the identity of the codes
+// tensor, and forgets it here when it drops it there.  A hit is validated against (storage pointer, version, shape) of the
+// codes and (storage pointer, version) of the codebooks the range was computed from.
+struct RawEntry {
+  const void* codes_data = nullptr;
+  uint32_t codes_version = 0;
+  bool codes_versioned = false;
+  int64_t out = 0, in_groups = 0;
+  const void* cb_data = nullptr;
+  uint32_t cb_version = 0;
+  bool cb_versioned = false;
+  at::Tensor packed;
+  aqlm_hip_packed_desc desc{};
+};
+
+static std::mutex g_raw_mu;
+static std::unordered_map<const void*, RawEntry> g_raw;  // key: the codes tensor's TensorImpl
+static bool g_raw_on = true;            // false: every call takes the Python implementation (set_fused_finalize(False), experiments)
+static bool g_raw_prepack = true;       // mirror of hip_kernel.RAW_OP_PREPACK
+static int64_t g_raw_min_codes = 500000;  // mirror of hip_kernel.RAW_OP_PREPACK_MIN_CODES
+static int64_t g_raw_gemm_rows = 7;     // mirror of hip_kernel.MATMAT_GEMM_MIN_ROWS
+static PyObject* g_raw_py[3] = {nullptr, nullptr, nullptr};  // Python implementations (leaked on purpose: they outlive the interpreter's teardown order)
+static uint64_t g_raw_served = 0;
+
+static bool versioned(const at::Tensor& t) { return !t.is_inference(); }
+
+static at::Tensor raw_python(int which, const at::Tensor& input, const at::Tensor& codes, const at::Tensor& codebooks,
+                             const at::Tensor& scales, const c10::optional<at::Tensor>& bias) {
+  py::gil_scoped_acquire gil;
+  TORCH_CHECK(g_raw_py[which] != nullptr, "aqlm raw op: no Python implementation installed");
+  py::object fn = py::reinterpret_borrow<py::object>(g_raw_py[which]);
+  py::object b = bias ? py::cast(*bias) : py::object(py::none());
+  return fn(input, codes, codebooks, scales, b).cast<at::Tensor>();
+}
+
+struct RawCall {  // what every launch needs once the arguments have been accepted
+  at::Tensor x2, y;
+  int64_t rows = 0;
+  void* stream = nullptr;
+  int dtype = 0;
+};
+
+// common argument checks of the three ops; false = not a call for this lane
+static bool raw_accept(const at::Tensor& input, const at::Tensor& codes, const at::Tensor& codebooks, const at::Tensor& scales,
+                       const c10::optional<at::Tensor>& bias, at::ScalarType code_type, int64_t K, int64_t codebook_size, int64_t max_rows,
+                       RawCall& c, int64_t& in_features, int64_t& out_features, int& g) {
+  if (!g_raw_on || !input.is_cuda() || input.dim() < 1) return false;
+  const at::ScalarType st = input.scalar_type();
+  if (st != at::kHalf && st != at::kBFloat16) return false;
+  if (codebooks.scalar_type() != st || scales.scalar_type() != st || (bias && bias->scalar_type() != st)) return false;
+  const auto dev = input.device();
+  if (codes.device() != dev || codebooks.device() != dev || scales.device() != dev || (bias && bias->device() != dev)) return false;
+  if (codebooks.dim() != 4 || codebooks.size(0) != K || codebooks.size(1) != codebook_size || codebooks.size(2) != 1) return false;
+  if (codes.dim() != 3 || codes.size(2) != K || codes.scalar_type() != code_type) return false;
+  if (!codes.is_contiguous() || !codebooks.is_contiguous() || !scales.is_contiguous() || (bias && !bias->is_contiguous())) return false;
+  g = (int)codebooks.size(3);
+  out_features = codes.size(0);
+  in_features = codes.size(1) * g;
+  if (out_features < 1 || in_features < 1 || input.size(-1) != in_features || scales.numel() != out_features ||
+      (bias && bias->numel() != out_features))
+    return false;
+  if (input.requires_grad() && at::GradMode::is_enabled()) return false;  // (the op has no autograd formula either way; Python decides)
+  c.rows = input.numel() / in_features;
+  if (c.rows < 1 || c.rows > max_rows) return false;
+  c.dtype = st == at::kHalf ? AQLM_HIP_F16 : AQLM_HIP_BF16;
+  return true;
+}
+
+static void raw_prepare(const at::Tensor& input, int64_t in_features, int64_t out_features, RawCall& c) {
+  c.x2 = input.reshape({c.rows, in_features});
+  if (c.x2.stride(1) != 1 || (c.rows > 1 && c.x2.stride(0) % 8 != 0) || (reinterpret_cast<uintptr_t>(c.x2.data_ptr()) & 15u)) c.x2 = c.x2.contiguous();
+  c.y = at::empty({c.rows, out_features}, input.options());
+  c.stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(input.device().index()).stream();
+}
+
+static at::Tensor raw_result(const at::Tensor& input, const RawCall& c, int64_t out_features) {
+  std::vector<int64_t> shape(input.sizes().begin(), input.sizes().end());
+  shape.back() = out_features;
+  ++g_raw_served;
+  return c.y.view(shape);
+}
+
+static at::Tensor raw_code1x16_matmat(const at::Tensor& input, const at::Tensor& codes, const at::Tensor& codebooks,
+                                      const at::Tensor& scales, const c10::optional<at::Tensor>& bias) {
+  RawCall c;
+  int64_t in_features = 0, out_features = 0;
+  int g = 0;
+  if (!raw_accept(input, codes, codebooks, scales, bias, at::kShort, 1, 65536, g_raw_gemm_rows - 1, c, in_features, out_features, g) ||
+      (g != 8 && g != 16))
+    return raw_python(0, input, codes, codebooks, scales, bias);
+  const void* bias_p = bias ? bias->data_ptr() : nullptr;
+  // a layer the Python side has packed and registered?
+  at::Tensor packed;
+  aqlm_hip_packed_desc desc{};
+  bool hit = false;
+  {
+    std::lock_guard<std::mutex> lock(g_raw_mu);
+    auto it = g_raw.find((const void*)codes.unsafeGetTensorImpl());
+    if (it != g_raw.end()) {
+      const RawEntry& e = it->second;
+      hit = e.codes_data == codes.data_ptr() && e.out == out_features && e.in_groups == codes.size(1) &&
+            e.codes_versioned == versioned(codes) && (!e.codes_versioned || e.codes_version == codes._version()) &&
+            e.cb_data == codebooks.data_ptr() && e.cb_versioned == versioned(codebooks) &&
+            (!e.cb_versioned || e.cb_version == codebooks._version());
+      if (hit) {
+        packed = e.packed;
+        desc = e.desc;
+      }
+    }
+  }
+  const bool direct = !hit && (!g_raw_prepack || out_features * codes.size(1) < g_raw_min_codes);
+  if (!hit && !direct) return raw_python(0, input, codes, codebooks, scales, bias);  // Python packs (or not) and registers
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
+  raw_prepare(input, in_features, out_features, c);
+  int rc;
+  if (hit) {
+    void* cells = stream_cells(input, c.stream, c.rows * out_features * 8);
+    if (cells)
+      rc = aqlm_hip_gemv_1x16_packed_cells(&desc, packed.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), bias_p, c.x2.data_ptr(),
+                                           c.y.data_ptr(), (int)c.rows, c.x2.stride(0), out_features, c.dtype, cells, (size_t)kCellsBytes,
+                                           c.stream);
+    else
+      rc = aqlm_hip_gemv_1x16_packed(&desc, packed.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), bias_p, c.x2.data_ptr(),
+                                     c.y.data_ptr(), (int)c.rows, c.x2.stride(0), out_features, c.dtype, nullptr, 0, c.stream);
+  } else {
+    rc = aqlm_hip_gemv_1x16(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), bias_p, c.x2.data_ptr(), c.y.data_ptr(),
+                            (int)out_features, (int)in_features, g, (int)c.rows, c.x2.stride(0), out_features, c.dtype, c.stream);
+  }
+  if (rc != 0) return raw_python(0, input, codes, codebooks, scales, bias);  // Python repeats the call and reports the error
+  return raw_result(input, c, out_features);
+}
+
+template <int K, int WHICH>
+static at::Tensor raw_codekx8_matmat(const at::Tensor& input, const at::Tensor& codes, const at::Tensor& codebooks,
+                                     const at::Tensor& scales, const c10::optional<at::Tensor>& bias) {
+  RawCall c;
+  int64_t in_features = 0, out_features = 0;
+  int g = 0;
+  if (!raw_accept(input, codes, codebooks, scales, bias, at::kChar, K, 256, AQLM_HIP_MAX_GEMV_BATCH, c, in_features, out_features, g))
+    return raw_python(WHICH, input, codes, codebooks, scales, bias);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
+  raw_prepare(input, in_features, out_features, c);
+  const int rc = aqlm_hip_gemv_kx8(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                                   c.x2.data_ptr(), c.y.data_ptr(), (int)out_features, (int)in_features, K, g, (int)c.rows, c.x2.stride(0),
+                                   out_features, c.dtype, c.stream);
+  if (rc != 0) return raw_python(WHICH, input, codes, codebooks, scales, bias);
+  return raw_result(input, c, out_features);
+}
+
+// Installs the three kernels for the CUDA dispatch key (the schemas are defined by hip_kernel.py, which then registers no
+// Python kernel for these names).  `impls`: the Python implementations, the fallback of every call not served here.
+static void raw_install(py::object code1x16, py::object code2x8, py::object code1x8) {
+  static torch::Library* lib = nullptr;
+  TORCH_CHECK(lib == nullptr, "aqlm raw ops: already installed");
+  g_raw_py[0] = code1x16.release().ptr();
+  g_raw_py[1] = code2x8.release().ptr();
+  g_raw_py[2] = code1x8.release().ptr();
+  lib = new torch::Library(torch::Library::IMPL, "aqlm", c10::make_optional(c10::DispatchKey::CUDA), __FILE__, __LINE__);  // never destroyed
+  lib->impl("code1x16_matmat", TORCH_FN(raw_code1x16_matmat));
+  lib->impl("code2x8_matmat", TORCH_FN((raw_codekx8_matmat<2, 1>)));
+  lib->impl("code1x8_matmat", TORCH_FN((raw_codekx8_matmat<1, 2>)));
+}
+
+static int64_t raw_register(const at::Tensor& codes, const at::Tensor& packed, const std::string& desc_bytes, const at::Tensor& codebooks) {
+  TORCH_CHECK(desc_bytes.size() == sizeof(aqlm_hip_packed_desc) && packed.is_cuda() && codes.dim() == 3, "aqlm raw ops: bad registration");
+  RawEntry e;
+  std::memcpy(&e.desc, desc_bytes.data(), sizeof(e.desc));
+  if (!(e.desc.codebook_absmax > 0.f)) return 0;  // the single-kernel finalize needs the codebook range: stay on the Python path
+  e.codes_data = codes.data_ptr();
+  e.codes_versioned = versioned(codes);
+  e.codes_version = e.codes_versioned ? codes._version() : 0;
+  e.out = codes.size(0);
+  e.in_groups = codes.size(1);
+  e.cb_data = codebooks.data_ptr();
+  e.cb_versioned = versioned(codebooks);
+  e.cb_version = e.cb_versioned ? codebooks._version() : 0;
+  e.packed = packed;
+  const void* key = (const void*)codes.unsafeGetTensorImpl();
+  std::lock_guard<std::mutex> lock(g_raw_mu);
+  g_raw[key] = std::move(e);
+  return (int64_t)(intptr_t)key;
+}
+
+static void raw_forget(int64_t key) {
+  at::Tensor keep;  // the packed buffer is released outside the lock
+  std::lock_guard<std::mutex> lock(g_raw_mu);
+  auto it = g_raw.find((const void*)(intptr_t)key);
+  if (it != g_raw.end()) {
+    keep = std::move(it->second.packed);
+    g_raw.erase(it);
+  }
+}
+
+static void raw_clear() {
+  std::unordered_map<const void*, RawEntry> old;
+  std::lock_guard<std::mutex> lock(g_raw_mu);
+  old.swap(g_raw);
+}
+
+static void raw_config(bool on, bool prepack, int64_t min_codes, int64_t gemm_rows) {
+  std::lock_guard<std::mutex> lock(g_raw_mu);
+  g_raw_on = on;
+  g_raw_prepack = prepack;
+  g_raw_min_codes = min_codes;
+  g_raw_gemm_rows = gemm_rows;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -283,4 +502,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(py::init<std::vector<std::shared_ptr<FastLinear>>>(), py::arg("members"))
       .def("forward", &FastGroup::forward)
       .def("__call__", &FastGroup::forward);
+  // the same kernels as plain functions (what the reference's pybind module exposes, cuda_kernel.cpp:686-699, and its benchmark calls,
+  // benchmark/matmul_benchmark.py:103): no dispatcher in between
+  m.def("code1x16_matmat", &raw_code1x16_matmat, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
+  m.def("code2x8_matmat", &raw_codekx8_matmat<2, 1>, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
+  m.def("code1x8_matmat", &raw_codekx8_matmat<1, 2>, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
+  m.def("raw_install", &raw_install, "register the compiled kernels of aqlm::code1x16_matmat / code2x8_matmat / code1x8_matmat (CUDA key)");
+  m.def("raw_register", &raw_register, "a packed layer of the raw op's cache -> key");
+  m.def("raw_forget", &raw_forget);
+  m.def("raw_clear", &raw_clear);
+  m.def("raw_config", &raw_config, py::arg("on"), py::arg("prepack"), py::arg("min_codes"), py::arg("gemm_rows"));
+  m.def("raw_served", []() { return g_raw_served; }, "calls launched by the compiled raw ops so far");
+  m.def("raw_entries", []() { std::lock_guard<std::mutex> lock(g_raw_mu); return g_raw.size(); });
 }

@@ -264,6 +264,7 @@ def set_fused_finalize(on: bool) -> None:
     global FUSED_FINALIZE
     _native.set_tuning("packed_fused_finalize", 1 if on else 0)
     FUSED_FINALIZE = bool(on)
+    _raw_sync_config()  # the compiled raw ops launch the single-kernel form only: off with the switch
 
 
 def _refresh_range(packed: PackedCodes, codebooks: torch.Tensor) -> None:
@@ -538,6 +539,30 @@ RAW_OP_PREPACK_MAX_BYTES = 1 << 30  # of packed buffers held for callers of the 
 RAW_OP_PREPACK_MAX_MISSES = 8
 _RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None)
 _RAW_STATS = {"bytes": 0, "packs_without_hit": 0, "hits": 0, "packs": 0}
+# Compiled kernels of the three reference ops (csrc_front/front.cpp, installed at the end of this file when the extension is
+# built): calls through torch.ops.aqlm.* of <= 6 rows are launched from C++; this module stays their fallback and the owner of
+# the cache above -- a packed layer is REGISTERED with the extension (key below) and forgotten there when it is dropped here.
+_RAW_FAST = None                      # the extension once its kernels are installed
+_RAW_FAST_KEYS = {}                   # id(codes) -> (key of the extension's entry, id of the codebooks it was registered with, their version)
+
+
+def _raw_sync_config():
+    """Push the knobs the compiled raw ops mirror (call after changing RAW_OP_PREPACK*, MATMAT_GEMM_MIN_ROWS, FUSED_FINALIZE;
+    clear_raw_op_prepack_cache() does)."""
+    if _RAW_FAST is not None:
+        _RAW_FAST.raw_config(bool(FUSED_FINALIZE), bool(RAW_OP_PREPACK), int(RAW_OP_PREPACK_MIN_CODES), int(MATMAT_GEMM_MIN_ROWS))
+
+
+def _raw_register_fast(codes, packed, codebooks):
+    if _RAW_FAST is None or not FUSED_FINALIZE or packed.desc.codebook_absmax <= 0.0:
+        return
+    have = _RAW_FAST_KEYS.get(id(codes))
+    mark = (id(codebooks), _version(codebooks), codebooks.data_ptr())
+    if have is not None and have[1] == mark:
+        return
+    key = _RAW_FAST.raw_register(codes, packed.buf, bytes(packed.desc), codebooks)
+    if key:
+        _RAW_FAST_KEYS[id(codes)] = (key, mark)
 
 
 def _raw_fingerprint(codes):
@@ -548,6 +573,9 @@ def _raw_drop(key):
     entry = _RAW_PACKED.pop(key, None)
     if entry is not None and entry[2] is not None:
         _RAW_STATS["bytes"] -= entry[2].numel()
+    fast = _RAW_FAST_KEYS.pop(key, None)
+    if fast is not None and _RAW_FAST is not None:
+        _RAW_FAST.raw_forget(fast[0])
 
 
 def clear_raw_op_prepack_cache():
@@ -555,6 +583,10 @@ def clear_raw_op_prepack_cache():
     for key in list(_RAW_PACKED):
         _raw_drop(key)
     _RAW_STATS["packs_without_hit"] = 0
+    if _RAW_FAST is not None:
+        _RAW_FAST.raw_clear()
+        _RAW_FAST_KEYS.clear()
+    _raw_sync_config()
 
 
 def _raw_packed_for(codes, codebooks, input):
@@ -618,7 +650,9 @@ def code1x16_matmat(input, codes, codebooks, scales, bias=None):
         return code1x16_matmat_dequant(input, codes, codebooks, scales, bias)
     packed = _raw_packed_for(codes, codebooks, input)
     if packed is not None and scales.dtype == input.dtype and input.device == codes.device:
-        return code1x16_matmat_packed(input, packed, codebooks, scales, bias)
+        y = code1x16_matmat_packed(input, packed, codebooks, scales, bias)
+        _raw_register_fast(codes, packed, codebooks)  # (after the call: it brought the codebook range up to date)
+        return y
     return _gemv(input, codes, codebooks, scales, bias, "1x16")
 
 
@@ -1052,10 +1086,21 @@ _OPS = {
     "generic_matmat_dequant_transposed": (generic_matmat_dequant_transposed, _fake_transposed),
 }
 
+# the three reference matvec ops get compiled kernels when the front end is built (front.cpp: decode calls are launched from
+# C++, everything else comes back to the functions above); without it the functions above ARE the kernels
+_RAW_FAST_NAMES = ("code1x16_matmat", "code2x8_matmat", "code1x8_matmat")
+from .. import _front  # noqa: E402
+
+_compiled_raw = _front.available() and hasattr(_front.ext, "raw_install") and os.environ.get("AQLM_AMD_NO_RAW_FRONT", "0") != "1"
 for _name, (_impl, _fake) in _OPS.items():
     _LIB.define(f"{_name}{_SCHEMA}")
-    _LIB.impl(_name, _impl, "CUDA")
+    if not (_compiled_raw and _name in _RAW_FAST_NAMES):
+        _LIB.impl(_name, _impl, "CUDA")
     torch.library.register_fake(f"aqlm::{_name}")(_fake)
+if _compiled_raw:
+    _front.ext.raw_install(code1x16_matmat, code2x8_matmat, code1x8_matmat)
+    _RAW_FAST = _front.ext
+    _raw_sync_config()
 
 # shared-input launch (no reference counterpart)
 def _fake_multi(input, codes, codebooks, scales, bias):
@@ -1128,4 +1173,8 @@ HIP_KERNEL = SimpleNamespace(
     code1x16_matmat_multi=code1x16_matmat_multi,
     codekx8_matmat_multi=codekx8_matmat_multi,
 )
+if _RAW_FAST is not None:  # the compiled functions, as in the reference's pybind module (the Python ones above remain their fallback)
+    HIP_KERNEL.code1x16_matmat = _RAW_FAST.code1x16_matmat
+    HIP_KERNEL.code2x8_matmat = _RAW_FAST.code2x8_matmat
+    HIP_KERNEL.code1x8_matmat = _RAW_FAST.code1x8_matmat
 CUDA_KERNEL = HIP_KERNEL

@@ -1893,6 +1893,109 @@ def test_fast_lane_equals_python_path(hk, K, nbits, g, fin, fout):
         assert m._fast is not None and m._fast.is_current()
 
 
+@pytest.mark.raw_prepack
+def test_compiled_raw_ops_equal_the_python_implementations(hk):
+    """torch.ops.aqlm.code1x16_matmat / code2x8_matmat / code1x8_matmat are compiled dispatcher kernels when the front end is
+    built (front.cpp; the reference's ops are C++ too, cuda_kernel.cpp:148-182): decode calls are launched from C++ on the same
+    kernels as the Python functions (bit-identical), large 1x16 layers through the Python-owned prepack cache, and every call
+    outside the lane -- more rows, malformed arguments with their error types, a layer edited in place -- behaves as before."""
+    import gc
+
+    from aqlm_amd import _front
+
+    if not (_front.available() and hk._RAW_FAST is not None):
+        pytest.skip("compiled raw ops not installed (aqlm_amd/_aqlm_front.so not built)")
+    ext = _front.ext
+    ops = {(1, 16): (torch.ops.aqlm.code1x16_matmat, hk.code1x16_matmat), (2, 8): (torch.ops.aqlm.code2x8_matmat, hk.code2x8_matmat),
+           (1, 8): (torch.ops.aqlm.code1x8_matmat, hk.code1x8_matmat)}
+    # small layers (direct kernels), 1 / 3 / 6 rows, with and without bias, both dtypes, a strided input
+    for (K, nbits), fin, fout, rows, bias, dt in (((1, 16), 512, 300, 1, True, "float16"), ((1, 16), 1024, 77, 6, False, "bfloat16"),
+                                                  ((2, 8), 1024, 200, 3, True, "float16"), ((2, 8), 4096, 333, 1, False, "bfloat16"),
+                                                  ((1, 8), 512, 64, 6, True, "float16"), ((1, 16), 2048, 128, 3, True, "float16")):
+        dtype = tdtype(dt)
+        L = orc.make_layer(777 + fin + fout, fin, fout, K, nbits, 8, batch=rows, bias=bias, float_dtype=np.float16 if dt == "float16" else "bfloat16")
+        T = to_dev(L, dtype)
+        op, pyfn = ops[(K, nbits)]
+        n0 = ext.raw_served()
+        y = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+        assert ext.raw_served() == n0 + 1, "the call was not launched by the compiled op"
+        assert torch.equal(y, pyfn(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]))
+        check_close(y.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"]), dtype,
+                    f"compiled raw op {K}x{nbits} {fin}->{fout} rows={rows}")
+        wide = torch.zeros(rows, fin + 16, dtype=dtype, device=DEV)
+        wide[:, 8:8 + fin] = T["x"]
+        assert torch.equal(op(wide[:, 8:8 + fin], T["codes"], T["codebooks"], T["scales"], T["bias"]), y)
+        assert op(T["x"].reshape(1, rows, fin), T["codes"], T["codebooks"], T["scales"], T["bias"]).shape == (1, rows, fout)
+    # a large 1x16 layer: the first call packs (Python), registers; from then on C++ launches the prepacked kernel
+    fin, fout = 4096, 2048
+    L = orc.make_layer(4242, fin, fout, 1, 16, 8, batch=2, bias=True)
+    T = to_dev(L, torch.float16)
+    op, pyfn = ops[(1, 16)]
+    p0, e0 = hk._RAW_STATS["packs"], ext.raw_entries()
+    y0 = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert hk._RAW_STATS["packs"] == p0 + 1 and ext.raw_entries() == e0 + 1
+    n0 = ext.raw_served()
+    y1 = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    y1b = op(T["x"][:1], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert ext.raw_served() == n0 + 2 and torch.equal(y0, y1) and torch.equal(y1b[0], y1[0])
+    assert torch.equal(y1, hk.code1x16_matmat_packed(T["x"], hk._RAW_PACKED[id(T["codes"])][2], T["codebooks"], T["scales"], T["bias"]))
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    check_close(y1.float().cpu().numpy(), y64, torch.float16, "compiled raw op on the prepacked kernel")
+    # inside a hipGraph (no packing, no allocation of cells: the registered layer is launched as it is)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        yg = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y1)
+    # not the lane's calls: 9 rows (MFMA kernel through the Python op), wrong dtypes / shapes with the reference's error types
+    n0 = ext.raw_served()
+    x9 = T["x"][:1].expand(9, fin).contiguous()
+    check_close(op(x9, T["codes"], T["codebooks"], T["scales"], T["bias"])[8].float().cpu().numpy(), y64[0], torch.float16, "9 rows")
+    with pytest.raises(NotImplementedError, match="only support float16 and bfloat16"):
+        op(T["x"].float(), T["codes"], T["codebooks"], T["scales"], T["bias"])
+    with pytest.raises(NotImplementedError):
+        op(T["x"].bfloat16(), T["codes"], T["codebooks"], T["scales"], T["bias"])
+    with pytest.raises(ValueError):
+        op(T["x"][:, :fin - 8], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    with pytest.raises(NotImplementedError):
+        torch.ops.aqlm.code2x8_matmat(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert ext.raw_served() == n0
+    # the codebooks change in place: the registered range is stale -> Python refreshes it and registers again; values follow
+    T["codebooks"].mul_(2.0)
+    y2 = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    check_close(y2.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L["codes"], 2.0 * L["codebooks"].astype(np.float32), L["scales"], L["bias"]),
+                torch.float16, "compiled raw op after a codebook update")
+    n0 = ext.raw_served()
+    assert torch.equal(op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]), y2) and ext.raw_served() == n0 + 1
+    # the codes change in place: packed again, registered again
+    L2 = orc.make_layer(4243, fin, fout, 1, 16, 8, batch=2, bias=True)
+    T["codes"].copy_(torch.from_numpy(L2["codes"]).to(DEV))
+    y3 = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    check_close(y3.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L2["codes"], 2.0 * L["codebooks"].astype(np.float32), L["scales"], L["bias"]),
+                torch.float16, "compiled raw op after an in-place edit of the codes")
+    assert hk._RAW_STATS["packs"] == p0 + 2
+    # a dead codes tensor leaves nothing behind on either side; the knobs reach the compiled side through the cache's clear
+    e1 = ext.raw_entries()
+    del T["codes"]
+    gc.collect()
+    assert ext.raw_entries() == e1 - 1
+    hk.clear_raw_op_prepack_cache()
+    assert ext.raw_entries() == 0
+    hk.set_fused_finalize(False)   # two-kernel finalize: the compiled ops stand down
+    try:
+        T5 = to_dev(orc.make_layer(9, 512, 64, 1, 16, 8, batch=1, bias=False), torch.float16)
+        n0 = ext.raw_served()
+        op(T5["x"], T5["codes"], T5["codebooks"], T5["scales"], None)
+        assert ext.raw_served() == n0
+    finally:
+        hk.set_fused_finalize(True)
+
+
 def test_packed_layer_runs_on_two_streams_at_once(hk):
     """Re-entrancy of the single-kernel finalize (reference launcher: stateless on the caller's stream,
     cuda_kernel.cu:505-509): one prepacked module -- i.e. one packed buffer -- driven from two streams concurrently, through
