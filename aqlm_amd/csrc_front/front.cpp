@@ -66,18 +66,26 @@ static bool unchanged(const py::dict& params, const char* name, const Watched& w
 // (_packed_cells): the packed buffers are only read, so a layer may run on several streams at once.  Never freed.
 constexpr int64_t kCellsBytes = (int64_t)AQLM_HIP_MAX_GEMV_BATCH * 131072 * 8;
 
-static void* stream_cells(const at::Tensor& like, void* stream, int64_t need_bytes) {
-  if (need_bytes > kCellsBytes) return nullptr;
+// ONE registry for the whole process: the Python ops take their cells from here too (stream_cells_tensor below) when the
+// extension is loaded, so a stream has one 8 MiB set, not one per code path.
+static at::Tensor stream_cells_tensor(const at::Tensor& like, void* stream, int64_t need_bytes) {
+  if (need_bytes > kCellsBytes) return at::Tensor();
   static std::mutex mu;
   static std::map<std::pair<int, void*>, at::Tensor> cells;
   std::lock_guard<std::mutex> lock(mu);
   auto key = std::make_pair((int)like.device().index(), stream);
   auto it = cells.find(key);
   if (it == cells.end()) {
-    if (c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None) return nullptr;  // cells inside the packed buffer
+    if (c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None) return at::Tensor();  // cells inside the packed buffer
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(like.device());
     it = cells.emplace(key, at::zeros({kCellsBytes / 8}, like.options().dtype(at::kLong))).first;
   }
-  return it->second.data_ptr();
+  return it->second;
+}
+
+static void* stream_cells(const at::Tensor& like, void* stream, int64_t need_bytes) {
+  const at::Tensor t = stream_cells_tensor(like, stream, need_bytes);
+  return t.defined() ? t.data_ptr() : nullptr;
 }
 
 class FastGroup;
@@ -507,6 +515,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("code1x16_matmat", &raw_code1x16_matmat, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
   m.def("code2x8_matmat", &raw_codekx8_matmat<2, 1>, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
   m.def("code1x8_matmat", &raw_codekx8_matmat<1, 2>, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
+  m.def("stream_cells", [](const at::Tensor& like, int64_t stream, int64_t need_bytes) -> py::object {
+    const at::Tensor t = stream_cells_tensor(like, (void*)(intptr_t)stream, need_bytes);
+    return t.defined() ? py::cast(t) : py::object(py::none());
+  }, "the zero-at-rest accumulator cells of (device of `like`, stream): int64 tensor, or None (too large / first use inside a capture)");
   m.def("raw_install", &raw_install, "register the compiled kernels of aqlm::code1x16_matmat / code2x8_matmat / code1x8_matmat (CUDA key)");
   m.def("raw_register", &raw_register, "a packed layer of the raw op's cache -> key");
   m.def("raw_forget", &raw_forget);

@@ -242,9 +242,43 @@ PACKED_CELLS_BYTES = _native.MAX_GEMV_BATCH * 131072 * 8
 _PACKED_CELLS = {}
 
 
+def _shared_cells(device: torch.device, stream: int, nbytes: int):
+    """The per-(device, stream) set kept by the compiled front end, when it is loaded: ONE registry for the module lanes, the
+    compiled ops and the Python ops (False: no extension, the dictionaries below are the registry)."""
+    from .. import _front
+
+    if not _front.available() or not hasattr(_front.ext, "stream_cells"):
+        return False
+    like = _CELLS_LIKE.get(device.index)
+    if like is None:
+        like = _CELLS_LIKE[device.index] = torch.empty((0,), dtype=torch.float16, device=device)
+    return _front.ext.stream_cells(like, stream, nbytes)
+
+
+_CELLS_LIKE = {}
+
+
+def accumulator_cells(device: Optional[torch.device] = None, stream: Optional[int] = None):
+    """Every accumulator-cell tensor that exists for (device, stream) -- defaults: the current ones -- whichever registry holds
+    it.  Diagnostics and tests: all of them must read zero whenever the stream is idle."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    stream = torch.cuda.current_stream(device).cuda_stream if stream is None else stream
+    found = []
+    shared = _shared_cells(device, stream, 8)
+    if shared is not False and shared is not None:
+        found.append(shared)
+    for reg in (_PACKED_CELLS, _LUT_CELLS):
+        if (device.index, stream) in reg:
+            found.append(reg[(device.index, stream)])
+    return found
+
+
 def _packed_cells(device: torch.device, stream: int, nbytes: int):
     if nbytes > PACKED_CELLS_BYTES:
         return None
+    shared = _shared_cells(device, stream, nbytes)
+    if shared is not False:
+        return shared
     key = (device.index, stream)
     cells = _PACKED_CELLS.get(key)
     if cells is None:
@@ -404,6 +438,10 @@ _LUT_CELLS_RETIRED = []
 def _lut_cells(device: torch.device, stream: int, rows: int) -> Optional[torch.Tensor]:
     if not USE_8X8_LUT_FUSED:
         return None
+    if rows * 8 <= PACKED_CELLS_BYTES:  # both kernels leave their cells zero and launches of a stream are ordered: one set serves both
+        shared = _shared_cells(device, stream, rows * 8)
+        if shared is not False and shared is not None:
+            return shared
     key = (device.index, stream)
     cells = _LUT_CELLS.get(key)
     if cells is None or cells.numel() < rows:

@@ -954,9 +954,8 @@ def test_gemv_8x8_lut_fused_finalize(hk, g, fin, fout, dt):
     run = lambda x: hk._gemv_8x8_lut(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
     assert hk.USE_8X8_LUT_FUSED
     y = run(T["x"])
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    cells = hk._LUT_CELLS[key]
-    assert int(cells.abs().max()) == 0, "cells must be zero when the kernel has finished"
+    cells = hk.accumulator_cells()
+    assert cells and all(int(c.abs().max()) == 0 for c in cells), "cells must be zero when the kernel has finished"
     hk.USE_8X8_LUT_FUSED = False
     try:
         y_two = run(T["x"])
@@ -975,7 +974,7 @@ def test_gemv_8x8_lut_fused_finalize(hk, g, fin, fout, dt):
         check_close(ys.float().cpu().numpy(), ys64, dtype, f"lut fused finalize, {what}")
     xn = T["x"].clone()
     xn[0, 5] = float("nan")
-    assert torch.isnan(run(xn)).all() and int(cells.abs().max()) == 0
+    assert torch.isnan(run(xn)).all() and all(int(c.abs().max()) == 0 for c in cells)
     assert torch.equal(run(T["x"]), y)
     # hipGraph: a stream that has run the op captures the single-kernel form; a fresh one falls back to two kernels
     s = torch.cuda.Stream()
@@ -1162,8 +1161,7 @@ def test_gemv_8x8_lut_planar(hk, g, fin, fout, dt, bias):
         finally:
             _native.set_tuning("lut_waves", 0)
     check_close(outs[16].float().cpu().numpy(), y_canon.double().cpu().numpy(), dtype, "planar vs canonical layout")
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    assert int(hk._LUT_CELLS[key].abs().max()) == 0, "cells must be zero when the kernels have finished"
+    assert all(int(c.abs().max()) == 0 for c in hk.accumulator_cells()), "cells must be zero when the kernels have finished"
     if bias:
         yz = hk.code8x8_matmat_planar(torch.zeros_like(T["x"]), planar, T["codebooks"], T["scales"], T["bias"])
         assert torch.equal(yz[0], T["bias"])
@@ -1206,8 +1204,7 @@ def test_gemv_8x8_lut_many_rows_per_workgroup(hk, planar):
     else:
         y = hk._gemv_8x8_lut(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
     check_close(y[0].float().cpu().numpy(), y64, torch.float16, f"lut, 100000 rows, planar={planar}")
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    assert int(hk._LUT_CELLS[key].abs().max()) == 0
+    assert all(int(c.abs().max()) == 0 for c in hk.accumulator_cells())
 
 
 def test_8x8_module_uses_planar_codes_and_can_drop_the_canonical_ones(hk):
@@ -2020,8 +2017,9 @@ def test_packed_layer_runs_on_two_streams_at_once(hk):
         for key, y in out.items():
             assert torch.equal(y, ref[key[1]]), f"stream-concurrent launch {key} differs from the single-stream result"
         # the cells inside the packed buffer were not used and the per-stream cells are back to zero
-        for cells in hk._PACKED_CELLS.values():
-            assert int(cells.abs().max()) == 0
+        for st in (s1, s2, torch.cuda.current_stream()):
+            cells = hk.accumulator_cells(stream=st.cuda_stream)
+            assert cells and all(int(c.abs().max()) == 0 for c in cells)
 
 
 def test_packed_layer_under_inference_mode(hk):
