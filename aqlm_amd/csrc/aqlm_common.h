@@ -150,7 +150,7 @@ struct Tuning {
   int gemv1x16_aux = AUX_DEFAULT;  // cache policy of the codebook gathers: 0 default, 1 sc0, 2 nt, 16 sc1
   int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
-  int gemm_variant = 0;          // large-batch 1x16 op: 0 = LDS-DMA pipeline (gemm_1x16_glds_kernel), 1 = register-staged split-K kernel (round 1)
+  int gemm_variant = 0;          // large-batch 1x16 op: 0 = by batch (16-row no-split kernel <= 64 rows, K-split LDS-DMA pipeline above), 1 = register-staged split-K kernel (round 1), 2 = 16-row kernel wherever it applies, 3 = K-split pipeline only
   int gemm_debug = 0;            // LDS-DMA pipeline: knock-out switches for timing experiments (never set in production: results are wrong)
   int gemm_store_nt = 0;         // LDS-DMA pipeline: fp32 partials stored with the non-temporal hint
   int force_generic = 0;         // 1: route every gemv through the generic kernel (testing)

@@ -641,6 +641,294 @@ static int launch_glds(const GldsParams& p, const GldsPlan& g, hipStream_t strea
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 16-row blocks, no K split (round 4).  The pipeline above minimises what goes through a CU's L1 (X is read once per K slice)
+// and pays for it with two launches, 16.8 MB of fp32 partials and a finalize: 8.3 + 3.9 us of a 23 us op at 128 rows, and the
+// same 8.3 us at 16 rows.  Here a block owns 16 output rows over ALL of K: no partials, no workspace, no second kernel -- and
+// every block streams all of X (B x K x 2 bytes) through its L1 next to its 8192 gathers.  That trade wins when X is small
+// next to the gathers' 128-B lines (16 x 8 KiB rows of X = 128 KiB against 1 MiB of lines) and is about even at 128 rows.
+//   wave 0            codes -> LDS -> 2 gathers per 64-k chunk (one 1-KiB MFMA A fragment per 32 k), NSW - 1 steps ahead: the
+//                     gathers are latency-bound (a few hundred must be in flight), the fragments are small (2 KiB per chunk)
+//   waves 1..NXP      the X chunks (B rows x 128 B each, XOR-swizzled slots as above) by LDS-DMA, NSX - 1 steps ahead
+//   R16_NC consumers  wave c multiplies the block's ONE A fragment with its batch tiles; fp32 accumulators over all of K,
+//                     scale + bias + one rounding in the epilogue (16 x 16 tile: 4 rows x 1 batch column per lane)
+// One s_barrier per STEP of CPB chunks joins the three roles (counted vmcnt on the DMA waves, as above).  A step lasts only
+// 0.15-0.35 us per chunk, and between "my DMA of this step is accepted" and "everybody has passed the barrier" the texture
+// addresser has nothing queued: with one chunk per step that gap was a quarter of the time (measured: 0.30 gathers / clk / CU
+// against the 0.43 of the flat-out microbenchmark), so small batches take 4 chunks per step.
+constexpr int R16_NC = 4;     // consumer waves
+// where the op takes this kernel (measured, profiles/r04_gemm_rows16_shapes.json): every block streams all of X, so the trade
+// turns with batch x layer size -- up to 16 rows everywhere, up to 64 rows for layers of <= 4096 x 4096
+constexpr int R16_ROWS_ANY = 16, R16_ROWS_SMALL = 64;
+constexpr long R16_SMALL_LAYER = 1L << 24;
+
+template <int NBT, int CPB>
+struct R16Lds {
+  static constexpr int NXP = 2 * NBT >= 4 ? 4 : 2 * NBT;            // X producer waves
+  static constexpr int PXW = CPB * 2 * NBT / NXP;                   // 1-KiB pieces (8 batch rows x 64 k) per X wave and step
+  static constexpr uint32_t X_CHUNK = (uint32_t)NBT * 2048u;        // 16 NBT batch rows x 128 B
+  static constexpr uint32_t X_STAGE = CPB * X_CHUNK;
+  static constexpr uint32_t W_STAGE = CPB * 2048u;                  // 2 fragments of 1 KiB per chunk
+  static constexpr int NSW = CPB == 1 ? 16 : 8;                     // stages of the fragment ring (>= 7 steps = 1800+ gathers in flight)
+  static constexpr int NSX = CPB == 1 ? (NBT <= 2 ? 16 : (NBT <= 4 ? 12 : 7))   // stages of the X ring: as deep in TIME as a load takes,
+                                      : (CPB == 4 ? (NBT <= 1 ? 8 : 4) : (NBT <= 4 ? 6 : 3));  // within 160 KiB
+  static constexpr int NSLOT = 2 * NSW;                             // slots of the code ring (power of two)
+  static constexpr uint32_t CODE_SLOT = 256u * CPB;                 // 16 rows x CPB x 16 B (g = 8) or x 8 B (g = 16, half used)
+  static constexpr uint32_t W = 0;
+  static constexpr uint32_t X = NSW * W_STAGE;
+  static constexpr uint32_t CODES = X + NSX * X_STAGE;
+  static constexpr uint32_t TOTAL = CODES + NSLOT * CODE_SLOT;
+  static constexpr int WAVES = 1 + NXP + R16_NC;
+  static_assert(TOTAL <= 160u * 1024u, "LDS");
+  static_assert((NSLOT & (NSLOT - 1)) == 0, "code ring");
+};
+
+template <int R, int P>  // the last R + 1 steps land: one counted wait + barrier each (the wait count must be an immediate)
+__device__ __forceinline__ void r16_drain() {
+  __builtin_amdgcn_s_waitcnt(gl_vmcnt(R * P));
+  __builtin_amdgcn_s_barrier();
+  if constexpr (R > 0) r16_drain<R - 1, P>();
+}
+
+struct R16Params {
+  const uint8_t* codes;     // [M][in_groups] u16
+  const uint8_t* codebook;  // [65536][G] halfs
+  const uint16_t* X;        // [B][xs]
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* Y;
+  long xs, ys;
+  int M, B, in_groups, nsteps;  // nsteps = K / (64 CPB)
+};
+
+template <class T, int G, int NBT, int CPB>
+__global__ __launch_bounds__((R16Lds<NBT, CPB>::WAVES * 64)) void gemm_1x16_rows16_kernel(const R16Params p) {
+  using LDS = R16Lds<NBT, CPB>;
+  constexpr int NSW = LDS::NSW, NSX = LDS::NSX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int arow = lane & 15, kg = lane >> 4;
+  const int row0 = (int)blockIdx.x * 16;
+  const int n = p.nsteps;  // >= max(NSW, NSX) - 1 (host)
+
+  if (wave == 0) {
+    // ============================================ gather producer ====================================================
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int P0 = 1 + 2 * CPB;  // LDS-DMA operations per step: codes, 2 fragments per chunk
+    static_assert((NSW - 2) * P0 < 64, "vmcnt is 6 bits");
+    // codes of a step: row r holds ROW_BYTES = CPB x 16 B (g = 8: 8 codes per chunk) or CPB x 8 B (g = 16: 4 codes); one DMA
+    // instruction moves the 16 rows in pieces of 16 B (4 B when a row has only 8), lanes in (row, piece) order, so a slot of the
+    // ring reads [row][chunk][codes]
+    constexpr uint32_t CHUNK_BYTES = G == 8 ? 16u : 8u;  // code bytes of one row and chunk
+    constexpr uint32_t RB = CHUNK_BYTES * CPB;
+    constexpr uint32_t DMA_BYTES = RB >= 16u ? 16u : 4u;
+    constexpr int PARTS = (int)(RB / DMA_BYTES);          // lanes per row
+    constexpr int CODE_LANES = 16 * PARTS;
+    static_assert(CODE_LANES <= 64, "one DMA instruction moves the codes of a step");
+    const uint8_t* code_src;
+    {
+      int r = row0 + lane / PARTS;
+      r = r < p.M ? r : p.M - 1;
+      code_src = p.codes + ((size_t)r * p.in_groups) * 2 + (size_t)(lane % PARTS) * DMA_BYTES;
+    }
+    constexpr uint32_t ROW_BYTES = CHUNK_BYTES * CPB;
+    constexpr uint32_t CODE_STEP = G == 8 ? 8u : 4u;  // bytes between the codes of k step 0 and k step 1 of a chunk
+    const uint32_t code_off0 = (uint32_t)arow * ROW_BYTES + (G == 8 ? (uint32_t)kg * 2u : (uint32_t)(kg >> 1) * 2u);
+    const uint32_t half_off = G == 8 ? 0u : (uint32_t)(kg & 1) * 16u;
+    auto dma_codes = [&](int step) {  // step may run past K: clamped (the slot is written, never used)
+      const int cc = step < n ? step : n - 1;
+      if (lane < CODE_LANES) {
+        ggbl_void_ptr src = (ggbl_void_ptr)(code_src + (size_t)cc * RB);
+        glds_void_ptr dst = (glds_void_ptr)(size_t)(LDS::CODES + (uint32_t)(step & (LDS::NSLOT - 1)) * LDS::CODE_SLOT);
+        if constexpr (DMA_BYTES == 16u) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+      }
+    };
+    auto read_codes = [&](int step, uint32_t (&c)[2 * CPB]) {
+      const uint32_t a = LDS::CODES + (uint32_t)(step & (LDS::NSLOT - 1)) * LDS::CODE_SLOT + code_off0;
+#pragma unroll
+      for (int u = 0; u < CPB; ++u)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) c[u * 2 + s] = *(glds_u16_ptr)(size_t)(a + (uint32_t)u * CHUNK_BYTES + (uint32_t)s * CODE_STEP);
+    };
+    auto dma_stage = [&](int stage, const uint32_t (&c)[2 * CPB]) {
+#pragma unroll
+      for (int f = 0; f < 2 * CPB; ++f)
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebook + (size_t)c[f] * (G * 2) + half_off),
+                                         (glds_void_ptr)(size_t)(LDS::W + (uint32_t)stage * LDS::W_STAGE + (uint32_t)f * 1024u), 16, 0, 0);
+    };
+    uint32_t creg[2 * CPB];
+#pragma unroll
+    for (int j = 0; j < NSW; ++j) dma_codes(j);
+    __builtin_amdgcn_s_waitcnt(gl_vmcnt(0));
+    read_codes(0, creg);
+    for (int q = 0; q < NSW - 1; ++q) {  // steps 0 .. NSW - 2 before the first barrier
+      dma_codes(q + NSW);
+      dma_stage(q, creg);
+      read_codes(q + 1, creg);  // requested before the wait above (q + 1 < NSW)
+    }
+    int stage = NSW - 1;  // stage of step i + NSW - 1
+    int i = 0;
+    for (; i + NSW - 1 < n; ++i) {
+      __builtin_amdgcn_s_waitcnt(gl_vmcnt((NSW - 2) * P0));  // what this wave issued NSW - 1 iterations ago has landed
+      __builtin_amdgcn_s_barrier();                           // step i is complete; the consumers are done with step i - 1
+      const int q = i + NSW - 1;
+      dma_codes(q + NSW);
+      dma_stage(stage, creg);
+      read_codes(q + 1, creg);  // requested NSW - 1 iterations ago: covered by the wait that opened this iteration
+      stage = stage == NSW - 1 ? 0 : stage + 1;
+    }
+    r16_drain<NSW - 2, P0>();  // steps n - NSW + 1 .. n - 1 are in flight, one more lands per barrier
+    return;
+  }
+
+  if (wave <= LDS::NXP) {
+    // ============================================== X producer =======================================================
+    constexpr int PX = LDS::PXW;
+    constexpr int PPC = 2 * NBT;  // pieces per chunk
+    static_assert((NSX - 2) * PX < 64, "vmcnt is 6 bits");
+    const int xw = wave - 1;
+    const uint8_t* x_src[PX];
+    uint32_t x_dst[PX];
+#pragma unroll
+    for (int x = 0; x < PX; ++x) {
+      const int piece = xw * PX + x;             // of the step: chunk piece / PPC, chunk piece piece % PPC
+      const int u = piece / PPC, pc = piece % PPC;
+      const int s = pc * 64 + lane;              // slot of the chunk image: batch row s >> 3, k piece (s & 7) ^ swizzle
+      int b = s >> 3;
+      const int c = (s & 7) ^ ((b >> 1) & 7);
+      b = b < p.B ? b : p.B - 1;  // rows past the batch: a valid row, computed and never stored
+      x_src[x] = (const uint8_t*)(p.X + (size_t)b * p.xs + c * 8) + (size_t)u * 128;
+      x_dst[x] = LDS::X + (uint32_t)u * LDS::X_CHUNK + (uint32_t)pc * 1024u;
+    }
+    auto dma_x = [&](int step, int stage) {
+      const int cc = step < n ? step : n - 1;
+#pragma unroll
+      for (int x = 0; x < PX; ++x)
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (size_t)cc * (128 * CPB)),
+                                         (glds_void_ptr)(size_t)(x_dst[x] + (uint32_t)stage * LDS::X_STAGE), 16, 0, 0);
+    };
+    for (int q = 0; q < NSX - 1; ++q) dma_x(q, q);
+    int stage = NSX - 1;
+    int i = 0;
+    for (; i + NSX - 1 < n; ++i) {
+      __builtin_amdgcn_s_waitcnt(gl_vmcnt((NSX - 2) * PX));
+      __builtin_amdgcn_s_barrier();
+      dma_x(i + NSX - 1, stage);
+      stage = stage == NSX - 1 ? 0 : stage + 1;
+    }
+    r16_drain<NSX - 2, PX>();
+    return;
+  }
+
+  // ================================================ consumer ============================================================
+  constexpr int CT = NBT >= R16_NC ? NBT / R16_NC : 1;  // batch tiles per consumer wave
+  const int cw = wave - 1 - LDS::NXP;
+  const bool active = cw * CT < NBT;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int sw = 0, sx = 0;
+  for (int c = 0; c < n; ++c) {
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+      const uint32_t wbase = LDS::W + (uint32_t)sw * LDS::W_STAGE, xbase = LDS::X + (uint32_t)sx * LDS::X_STAGE;
+#pragma unroll
+      for (int u = 0; u < CPB; ++u) {
+        u32x4 a[2], b[2][CT];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          a[s] = *(glds_u32x4_ptr)(size_t)(wbase + (uint32_t)(u * 2 + s) * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+          for (int t = 0; t < CT; ++t)
+            b[s][t] = *(glds_u32x4_ptr)(size_t)(xbase + (uint32_t)u * LDS::X_CHUNK + (uint32_t)xswz((cw * CT + t) * 16 + arow, s * 4 + kg) * 16u);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[t] = mfma16<T>(a[s], b[s][t], acc[t]);
+      }
+    }
+    sw = sw == NSW - 1 ? 0 : sw + 1;
+    sx = sx == NSX - 1 ? 0 : sx + 1;
+  }
+  if (!active) return;
+  // ---- epilogue: lane (arow, kg) holds rows 4 kg .. 4 kg + 3 of the block, batch column 16 (cw CT + t) + arow --------------
+  const int m = row0 + kg * 4;
+  if (m >= p.M) return;
+  float sc[4], bi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mm = m + r < p.M ? m + r : p.M - 1;
+    sc[r] = T::to_float(p.scales[mm]);
+    bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+  }
+  const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0;
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int b = (cw * CT + t) * 16 + arow;
+    if (b < p.B) {
+      uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+      uint16_t h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(acc[t][r], sc[r], bi[r]));
+      if (vec) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+      else
+        for (int r = 0; r < 4; ++r)
+          if (m + r < p.M) dst[r] = h[r];
+    }
+  }
+}
+
+struct R16Plan {
+  int nbt, cpb, nsteps;
+};
+
+// chunks per step: 4 for <= 32 rows, 2 above, where K is a multiple of the step and long enough for the rings; else 1
+static bool plan_rows16(int B, int K, int G, R16Plan& r) {
+  if (K % BK != 0 || B < 1 || B > 128) return false;
+  const int t = (B + 15) / 16;
+  r.nbt = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
+  const int want = r.nbt <= 2 ? 4 : 2;
+  const int chunks = K / BK;
+  // (steps of several chunks move the codes in 16-B pieces: the rows of the code matrix must then be 16-B aligned)
+  if (chunks % want == 0 && chunks / want >= 7 && ((K / G) * 2) % 16 == 0) r.cpb = want;  // rings of 8 / <= 8 stages
+  else if (chunks >= 15) r.cpb = 1;                            // rings of 16 / <= 16 stages
+  else return false;
+  r.nsteps = chunks / r.cpb;
+  return true;
+}
+
+template <class T, int G>
+static int launch_rows16(const R16Params& p, const R16Plan& r, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.M + 15) / 16));
+  auto go = [&](auto kern, size_t lds, int waves) -> int {
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "gemm_1x16_rows16 launch");
+  };
+#define AQLM_R16_CASE(NBT_, CPB_) return go(gemm_1x16_rows16_kernel<T, G, NBT_, CPB_>, R16Lds<NBT_, CPB_>::TOTAL, R16Lds<NBT_, CPB_>::WAVES)
+  if (r.cpb == 1) {
+    switch (r.nbt) {
+      case 1: AQLM_R16_CASE(1, 1);
+      case 2: AQLM_R16_CASE(2, 1);
+      case 4: AQLM_R16_CASE(4, 1);
+      default: AQLM_R16_CASE(8, 1);
+    }
+  }
+  switch (r.nbt) {
+    case 1: AQLM_R16_CASE(1, 4);
+    case 2: AQLM_R16_CASE(2, 4);
+    case 4: AQLM_R16_CASE(4, 2);
+    default: AQLM_R16_CASE(8, 2);
+  }
+#undef AQLM_R16_CASE
+}
+
+
 struct GemmPlan {
   int ksplit, kslice, Bpad, nbt;
 };
@@ -727,9 +1015,36 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
     return AQLM_HIP_E_INVALID;
   }
   // batch > 128 is processed in slabs of 128 columns (codes re-gathered per slab)
-  const bool use_glds = tuning().gemm_variant == 0;
+  // gemm_variant: 0 = by batch and layer size (16-row blocks where they pay, else the K-split pipeline), 1 = register-staged kernel of
+  // round 1, 2 = 16-row blocks wherever they apply, 3 = K-split pipeline only
+  const int variant = tuning().gemm_variant;
+  const bool use_glds = variant != 1;
   for (int b0 = 0; b0 < batch; b0 += 128) {
     const int nb = std::min(128, batch - b0);
+    R16Plan r16{};
+    const bool r16_pays = nb <= R16_ROWS_ANY || (nb <= R16_ROWS_SMALL && (long)out_features * in_features <= R16_SMALL_LAYER);
+    if ((variant == 2 || (variant == 0 && r16_pays)) && plan_rows16(nb, in_features, in_group_size, r16)) {
+      R16Params rp{};
+      rp.codes = (const uint8_t*)codes;
+      rp.codebook = (const uint8_t*)codebook;
+      rp.X = (const uint16_t*)X + (long)b0 * xs;
+      rp.scales = (const uint16_t*)scales;
+      rp.bias = (const uint16_t*)bias;
+      rp.Y = (uint16_t*)Y + (long)b0 * ys;
+      rp.xs = xs;
+      rp.ys = ys;
+      rp.M = out_features;
+      rp.B = nb;
+      rp.in_groups = in_features / in_group_size;
+      rp.nsteps = r16.nsteps;
+      int e;
+      if (dtype == AQLM_HIP_F16)
+        e = in_group_size == 8 ? launch_rows16<F16, 8>(rp, r16, stream) : launch_rows16<F16, 16>(rp, r16, stream);
+      else
+        e = in_group_size == 8 ? launch_rows16<BF16, 8>(rp, r16, stream) : launch_rows16<BF16, 16>(rp, r16, stream);
+      if (e) return e;
+      continue;
+    }
     GldsPlan q;
     if (use_glds && plan_glds(nb, out_features, in_features, q)) {
       GldsParams gp{};

@@ -271,25 +271,36 @@ def test_matmat_dequant_mfma(hk, g, fin, fout, B, dt):
         check_close(y2, y64, dtype, f"mfma slabs g{g} {fin}->{fout} B{B}")
 
 
-def test_matmat_dequant_mfma_register_staged_variant(hk):
-    """The round-1 register-staged split-K kernel stays reachable (tuning knob `gemm_variant` = 1, A/B runs): it must
-    agree with the oracle too, and with the default LDS-DMA pipeline to fp32 round-off."""
+def test_matmat_dequant_mfma_kernel_variants(hk):
+    """The large-batch 1x16 op has three kernels behind one entry (tuning knob `gemm_variant`): the K-split LDS-DMA pipeline (3),
+    the 16-row no-split kernel of round 4 (2; the default picks it by batch and layer size) and the register-staged kernel of
+    round 1 (1).  Each must agree with the oracle on every shape it takes -- ragged row counts, batches that are not multiples
+    of 16, both group sizes, K that is / is not a multiple of the 16-row kernel's step, K too short for its rings (falls through
+    to the pipeline) -- and with the others to fp32 round-off."""
     from aqlm_amd import _native
 
-    for g, fin, fout, B, dt in [(8, 4096, 1000, 100, "float16"), (16, 1024, 256, 20, "bfloat16"), (8, 512, 48, 128, "float16")]:
+    shapes = [(8, 4096, 1000, 100, "float16"), (16, 1024, 256, 20, "bfloat16"), (8, 512, 48, 128, "float16"),
+              (8, 11008, 300, 33, "float16"), (16, 2240, 77, 7, "float16"), (8, 1792, 64, 16, "bfloat16"),
+              (16, 4096, 128, 64, "float16"), (8, 4096, 4096, 9, "float16"), (8, 960, 40, 48, "float16")]
+    for g, fin, fout, B, dt in shapes:
         dtype = tdtype(dt)
-        L = orc.make_layer(5150 + B, fin, fout, 1, 16, g, batch=B, bias=True,
+        L = orc.make_layer(5150 + B + fout, fin, fout, 1, 16, g, batch=B, bias=True,
                            float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
         T = to_dev(L, dtype)
-        y0 = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
-        _native.set_tuning("gemm_variant", 1)
-        try:
-            y1 = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]).float().cpu().numpy()
-        finally:
-            _native.set_tuning("gemm_variant", 0)
         y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-        check_close(y0, y64, dtype, f"mfma lds-dma g{g} {fin}->{fout} B{B}")
-        check_close(y1, y64, dtype, f"mfma register-staged g{g} {fin}->{fout} B{B}")
+        ys = {}
+        for variant in (0, 1, 2, 3):
+            _native.set_tuning("gemm_variant", variant)
+            try:
+                ys[variant] = hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+                assert torch.equal(ys[variant], hk.code1x16_matmat_dequant(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]))
+            finally:
+                _native.set_tuning("gemm_variant", 0)
+            check_close(ys[variant].float().cpu().numpy(), y64, dtype, f"mfma variant {variant} g{g} {fin}->{fout} B{B}")
+        # a strided input (rows of a wider tensor) through the default choice
+        wide = torch.zeros(B, fin + 64, dtype=dtype, device=DEV)
+        wide[:, 32:32 + fin] = T["x"]
+        assert torch.equal(hk.code1x16_matmat_dequant(wide[:, 32:32 + fin], T["codes"], T["codebooks"], T["scales"], T["bias"]), ys[0])
 
 
 @pytest.mark.parametrize("g,fin,fout,B,dt", [

@@ -830,6 +830,23 @@ static void bench_gemm(bool nosync) {
       int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
       if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
     });
+    // 16-row blocks without K split (round 4): same entry, knob 2; cross-check, then time
+    aqlm_hip_set_tuning("gemm_variant", 2);
+    CK(hipMemset(Y, 0xff, y1.size() * 2));
+    aqlm_hip_gemm_1x16_mfma(layers[0].codes, layers[0].cb, layers[0].scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(y1.data(), Y, y1.size() * 2, hipMemcpyDeviceToHost));
+    {
+      auto h2f = [](uint16_t h) { _Float16 f; memcpy(&f, &h, 2); return (float)f; };
+      double num = 0, den = 0; size_t same = 0;
+      for (size_t i = 0; i < y0.size(); ++i) { num += fabs(h2f(y0[i]) - h2f(y1[i])); den += fabs(h2f(y0[i])); same += y0[i] == y1[i]; }
+      printf("# LDS-DMA pipeline vs 16-row no-split kernel: mean-rel diff %.3e, %zu of %zu bit-identical%s\n", num / den, same, y0.size(), num / den < 1e-3 ? "" : "   <-- MISMATCH");
+    }
+    const double r16_us = time_it([&](const Layer& L, hipStream_t st) {
+      int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
+      if (rc) { fprintf(stderr, "gemm rc=%d %s\n", rc, aqlm_hip_last_error()); exit(5); }
+    });
+    printf("%-28s %5d %10.2f %10.1f\n", "gemm_1x16_mfma (16-row)", B, r16_us, 2.0 * B * in * out / r16_us * 1e-6);
     aqlm_hip_set_tuning("gemm_variant", 0);
     fprintf(stderr, "B=%d dequant\n", B);
     const double deq = time_it([&](const Layer& L, hipStream_t st) {
