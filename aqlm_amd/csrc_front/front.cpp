@@ -309,6 +309,7 @@ static int64_t g_raw_min_codes = 500000;  // mirror of hip_kernel.RAW_OP_PREPACK
 static int64_t g_raw_gemm_rows = 7;     // mirror of hip_kernel.MATMAT_GEMM_MIN_ROWS
 static PyObject* g_raw_py[3] = {nullptr, nullptr, nullptr};  // Python implementations (leaked on purpose: they outlive the interpreter's teardown order)
 static uint64_t g_raw_served = 0;
+static uint64_t g_raw_hits = 0;  // calls served from a registered (prepacked) layer: the Python cache reads this as its hit count
 
 static bool versioned(const at::Tensor& t) { return !t.is_inference(); }
 
@@ -402,6 +403,7 @@ static at::Tensor raw_code1x16_matmat(const at::Tensor& input, const at::Tensor&
   raw_prepare(input, in_features, out_features, c);
   int rc;
   if (hit) {
+    ++g_raw_hits;
     void* cells = stream_cells(input, c.stream, c.rows * out_features * 8);
     if (cells)
       rc = aqlm_hip_gemv_1x16_packed_cells(&desc, packed.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), bias_p, c.x2.data_ptr(),
@@ -525,5 +527,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("raw_clear", &raw_clear);
   m.def("raw_config", &raw_config, py::arg("on"), py::arg("prepack"), py::arg("min_codes"), py::arg("gemm_rows"));
   m.def("raw_served", []() { return g_raw_served; }, "calls launched by the compiled raw ops so far");
+  m.def("raw_hits", []() { return g_raw_hits; }, "calls the compiled code1x16_matmat served from a registered prepacked layer");
   m.def("raw_entries", []() { std::lock_guard<std::mutex> lock(g_raw_mu); return g_raw.size(); });
 }

@@ -646,6 +646,11 @@ def _raw_packed_for(codes, codebooks, input):
                 _RAW_PACKED[key] = _RAW_PACKED.pop(key)  # most recently used last (dicts keep insertion order)
             return entry[2]
         _raw_drop(key)  # the tensor was modified in place / rebound: pack again
+    if _RAW_FAST is not None:  # hits served by the compiled op never pass through here: read its counter
+        fast_hits = _RAW_FAST.raw_hits()
+        if fast_hits != _RAW_STATS.get("fast_hits_seen", 0):
+            _RAW_STATS["fast_hits_seen"] = fast_hits
+            _RAW_STATS["packs_without_hit"] = 0
     if (_RAW_STATS["packs_without_hit"] >= RAW_OP_PREPACK_MAX_MISSES or torch.cuda.is_current_stream_capturing()
             or torch.compiler.is_compiling()):
         return None

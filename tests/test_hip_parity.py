@@ -1987,8 +1987,26 @@ def test_compiled_raw_ops_equal_the_python_implementations(hk):
     check_close(y3.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L2["codes"], 2.0 * L["codebooks"].astype(np.float32), L["scales"], L["bias"]),
                 torch.float16, "compiled raw op after an in-place edit of the codes")
     assert hk._RAW_STATS["packs"] == p0 + 2
+    # many layers, each called twice (the reference benchmark's pattern): the second calls are hits of the COMPILED op, and the
+    # cache must count them -- it once read "packs without a single hit" and switched itself off after 8 layers
+    hk.clear_raw_op_prepack_cache()
+    many = [to_dev(orc.make_layer(6000 + k, 4096, 1024, 1, 16, 8, batch=1, bias=False), torch.float16) for k in range(12)]
+    pk0 = hk._RAW_STATS["packs"]
+    for Tm in many:
+        for _ in range(2):
+            op(Tm["x"], Tm["codes"], Tm["codebooks"], Tm["scales"], None)
+    assert hk._RAW_STATS["packs"] == pk0 + 12 and ext.raw_entries() >= 12
+    n0 = ext.raw_served()
+    for Tm in many:
+        op(Tm["x"], Tm["codes"], Tm["codebooks"], Tm["scales"], None)
+    assert ext.raw_served() == n0 + 12 and hk._RAW_STATS["packs"] == pk0 + 12
+    del many, Tm
+    gc.collect()
+    assert ext.raw_entries() == 0
     # a dead codes tensor leaves nothing behind on either side; the knobs reach the compiled side through the cache's clear
+    op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
     e1 = ext.raw_entries()
+    assert e1 == 1
     del T["codes"]
     gc.collect()
     assert ext.raw_entries() == e1 - 1
