@@ -153,7 +153,10 @@ int aqlm_hip_dequant_generic(const void* codes, const void* codebooks, const voi
 
 /*
  * Large-batch path: Y[B][out] = (X[B][in] @ W^T) * scales + bias with W dequantised tile-by-tile into LDS and
- * contracted on the matrix cores (v_mfma_f32_32x32x16_f16/bf16); W never touches HBM.
+ * contracted on the matrix cores (v_mfma_f32_16x16x32_f16/bf16: a gathered codebook vector IS a fragment lane); W never
+ * touches HBM.  Two kernels behind the entry, chosen by batch and layer size (tuning key `gemm_variant` forces one): a K-split
+ * pipeline with fp32 partials in `workspace` + a finalize launch, and (<= 16 rows; <= 64 rows on layers of <= 4096 x 4096) a
+ * single launch of 16-row blocks over all of K that uses no workspace.
  * Replaces: code1x16_matmat_dequant = Code1x16Dequant + F::linear(cuBLAS) + epilogue (cuda_kernel.cpp:249-301).
  * X and Y are row-major with the given row strides (elements).  workspace: aqlm_hip_workspace_bytes(...) bytes
  * (may be 0 -> NULL allowed).
