@@ -670,9 +670,16 @@ struct R16Lds {
   static constexpr uint32_t X_CHUNK = (uint32_t)NBT * 2048u;        // 16 NBT batch rows x 128 B
   static constexpr uint32_t X_STAGE = CPB * X_CHUNK;
   static constexpr uint32_t W_STAGE = CPB * 2048u;                  // 2 fragments of 1 KiB per chunk
-  static constexpr int NSW = CPB == 1 ? 16 : 8;                     // stages of the fragment ring (>= 7 steps = 1800+ gathers in flight)
+  // Ring depths.  Steps of several chunks carry 256-512 lane-gathers each, so 3 steps in flight cover the gather latency; short
+  // rings also mean a short prologue and, at <= 16 rows, 72 KiB of LDS: two blocks per CU, whose prologues and tails overlap
+  // (measured against 8-stage rings: 4096 -> 11008 at 16 rows 33.1 -> 30.5 us, 4096^2 13.7 -> 13.2).
+#ifndef AQLM_R16_DEEP
+#define AQLM_R16_DEEP 0  // 1: the first cut's 8-stage rings (A/B builds)
+#endif
+  static constexpr int NSW = CPB == 1 ? 16 : (AQLM_R16_DEEP ? 8 : 4);  // stages of the fragment ring
   static constexpr int NSX = CPB == 1 ? (NBT <= 2 ? 16 : (NBT <= 4 ? 12 : 7))   // stages of the X ring: as deep in TIME as a load takes,
-                                      : (CPB == 4 ? (NBT <= 1 ? 8 : 4) : (NBT <= 4 ? 6 : 3));  // within 160 KiB
+                             : AQLM_R16_DEEP ? (CPB == 4 ? (NBT <= 1 ? 8 : 4) : (NBT <= 4 ? 6 : 3))
+                                             : (CPB == 4 ? (NBT <= 1 ? 4 : 3) : (NBT <= 4 ? 4 : 3));  // within 160 KiB
   static constexpr int NSLOT = 2 * NSW;                             // slots of the code ring (power of two)
   static constexpr uint32_t CODE_SLOT = 256u * CPB;                 // 16 rows x CPB x 16 B (g = 8) or x 8 B (g = 16, half used)
   static constexpr uint32_t W = 0;
@@ -895,7 +902,7 @@ static bool plan_rows16(int B, int K, int G, R16Plan& r) {
   const int want = r.nbt <= 2 ? 4 : 2;
   const int chunks = K / BK;
   // (steps of several chunks move the codes in 16-B pieces: the rows of the code matrix must then be 16-B aligned)
-  if (chunks % want == 0 && chunks / want >= 7 && ((K / G) * 2) % 16 == 0) r.cpb = want;  // rings of 8 / <= 8 stages
+  if (chunks % want == 0 && chunks / want >= 7 && ((K / G) * 2) % 16 == 0) r.cpb = want;  // (7 steps: any ring depth of the several-chunk configurations)
   else if (chunks >= 15) r.cpb = 1;                            // rings of 16 / <= 16 stages
   else return false;
   r.nsteps = chunks / r.cpb;
