@@ -793,6 +793,7 @@ static void bench_gemm(bool nosync) {
       return ms * 1e3 / (5.0 * layers.size());
     };
     fprintf(stderr, "B=%d wsb=%zu fused\n", B, wsb);
+    aqlm_hip_set_tuning("gemm_variant", 3);  // the K-split LDS-DMA pipeline by name (the default picks a kernel by batch and layer size)
     auto run_fused = [&]() {
       return time_it([&](const Layer& L, hipStream_t st) {
         int rc = aqlm_hip_gemm_1x16_mfma(L.codes, L.cb, L.scales, nullptr, X, Y, B, out, in, 8, in, out, AQLM_HIP_F16, ws, wsb, st);
