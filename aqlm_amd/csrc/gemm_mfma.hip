@@ -936,6 +936,255 @@ static int launch_rows16(const R16Params& p, const R16Plan& r, hipStream_t strea
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K x 8-bit schemes, large batch (round 4): Y = X W^T with W never materialised.  Replaces (behaviour) Code2x8Dequant /
+// CodeKx8Dequant + F::linear + the epilogue launches of code2x8_matmat_dequant / code1x8_matmat_dequant
+// (cuda_kernel.cpp:450-484, 615-649).  Unlike 1x16 there is no gather floor: the codebooks (K x 4 KiB) live in LDS, so a weight
+// vector costs an LDS read, and 2-bit codes + the streamed X are all that moves: the op is FASTER than a dense fp16 GEMM at every
+// batch size it takes.  Same frame as the 16-row kernel above (a block owns 16 output rows over all of K; X by LDS-DMA into a
+// ring of steps; one barrier per step), but the four compute waves split K, not the batch: within a step of 2 CPB k-steps (32 k
+// each) wave c takes k-steps c, c + 4, ...; for each it reads its lane's code (row = lane % 16, group = 4 t + lane / 16: K bytes,
+// prefetched 3 steps ahead in registers), gathers the K codebook vectors from LDS, sums them (ONE rounding to the storage type,
+// as the dequantisation kernel does) -- the result IS its lane of the 16 x 32 MFMA A fragment -- and multiplies it with every
+// batch tile of the step's X.  The four partial accumulators meet in LDS at the end in wave order (deterministic), then
+// scale + bias + one rounding.
+constexpr int KX_NC = 4;   // compute waves
+constexpr int KX_PD = 3;   // steps the codes are requested ahead
+
+template <int K, int NBT, int CPB>
+struct KxLds {
+  static constexpr int NXP = 2 * NBT >= 4 ? 4 : 2 * NBT;            // X producer waves
+  static constexpr int PXW = CPB * 2 * NBT / NXP;                   // 1-KiB pieces (8 batch rows x 64 k) per X wave and step
+  static constexpr uint32_t X_CHUNK = (uint32_t)NBT * 2048u;
+  static constexpr uint32_t X_STAGE = CPB * X_CHUNK;
+  static constexpr int NSX = CPB == 4 ? (NBT <= 1 ? 4 : 3) : (NBT <= 4 ? 4 : 3);
+  static constexpr uint32_t CB = 0;                                 // [K][256][16 B]
+  static constexpr uint32_t X = (uint32_t)K * 4096u;
+  static constexpr uint32_t TOTAL = X + NSX * X_STAGE;
+  static constexpr uint32_t RED = X;                                // [KX_NC][NBT][1 KiB] fp32 partial tiles, after the last step
+  static constexpr int WAVES = NXP + KX_NC;
+  static_assert(KX_NC * NBT * 1024u <= NSX * X_STAGE, "the reduction reuses the X ring");
+  static_assert(TOTAL <= 160u * 1024u, "LDS");
+};
+
+struct KxParams {
+  const uint8_t* codes;      // [M][in_groups][K] u8
+  const uint8_t* codebooks;  // [K][256][8] halfs
+  const uint16_t* X;         // [B][xs]
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* Y;
+  long xs, ys;
+  int M, B, in_groups, nsteps;  // nsteps = K_features / (64 CPB)
+};
+
+template <class T>
+__device__ __forceinline__ u32x4 kx_add8(u32x4 a, u32x4 b);
+template <>
+__device__ __forceinline__ u32x4 kx_add8<F16>(u32x4 a, u32x4 b) {  // 4 x v_pk_add_f16: the exact sum, rounded once
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(u32x4, __builtin_bit_cast(h8, a) + __builtin_bit_cast(h8, b));
+}
+__device__ __forceinline__ uint32_t kx_add2_bf16(uint32_t a, uint32_t b) {
+  return (uint32_t)BF16::from_float(BF16::lo(a) + BF16::lo(b)) | ((uint32_t)BF16::from_float(BF16::hi(a) + BF16::hi(b)) << 16);
+}
+template <>
+__device__ __forceinline__ u32x4 kx_add8<BF16>(u32x4 a, u32x4 b) {  // fp32 sums, one rounding each
+  return u32x4{kx_add2_bf16(a.x, b.x), kx_add2_bf16(a.y, b.y), kx_add2_bf16(a.z, b.z), kx_add2_bf16(a.w, b.w)};
+}
+
+template <class T, int K, int NBT, int CPB>
+__global__ __launch_bounds__((KxLds<K, NBT, CPB>::WAVES * 64)) void gemm_kx8_rows16_kernel(const KxParams p) {
+  using LDS = KxLds<K, NBT, CPB>;
+  constexpr int NSX = LDS::NSX;
+  constexpr int NT = LDS::WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int arow = lane & 15, kg = lane >> 4;
+  const int row0 = (int)blockIdx.x * 16;
+  const int n = p.nsteps;  // >= NSX - 1 (host)
+
+  if (wave < LDS::NXP) {
+    // ============================================== X producer =======================================================
+    constexpr int PX = LDS::PXW;
+    constexpr int PPC = 2 * NBT;  // pieces per chunk
+    static_assert((NSX - 2) * PX < 64, "vmcnt is 6 bits");
+    const uint8_t* x_src[PX];
+    uint32_t x_dst[PX];
+#pragma unroll
+    for (int x = 0; x < PX; ++x) {
+      const int piece = wave * PX + x;
+      const int u = piece / PPC, pc = piece % PPC;
+      const int s = pc * 64 + lane;  // slot of the chunk image: batch row s >> 3, k piece (s & 7) ^ swizzle
+      int b = s >> 3;
+      const int c = (s & 7) ^ ((b >> 1) & 7);
+      b = b < p.B ? b : p.B - 1;
+      x_src[x] = (const uint8_t*)(p.X + (size_t)b * p.xs + c * 8) + (size_t)u * 128;
+      x_dst[x] = LDS::X + (uint32_t)u * LDS::X_CHUNK + (uint32_t)pc * 1024u;
+    }
+    auto dma_x = [&](int step, int stage) {
+      const int cc = step < n ? step : n - 1;
+#pragma unroll
+      for (int x = 0; x < PX; ++x)
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (size_t)cc * (128 * CPB)),
+                                         (glds_void_ptr)(size_t)(x_dst[x] + (uint32_t)stage * LDS::X_STAGE), 16, 0, 0);
+    };
+    for (int q = 0; q < NSX - 1; ++q) dma_x(q, q);
+    __builtin_amdgcn_s_barrier();  // the codebooks are in LDS (compute waves)
+    int stage = NSX - 1;
+    int i = 0;
+    for (; i + NSX - 1 < n; ++i) {
+      __builtin_amdgcn_s_waitcnt(gl_vmcnt((NSX - 2) * PX));
+      __builtin_amdgcn_s_barrier();
+      dma_x(i + NSX - 1, stage);
+      stage = stage == NSX - 1 ? 0 : stage + 1;
+    }
+    r16_drain<NSX - 2, PX>();
+    return;
+  }
+
+  // ================================================ compute =============================================================
+  const int cw = wave - LDS::NXP;
+  constexpr int KS = 2 * CPB / KX_NC;  // k-steps of a step per wave: k-step t = cw + 4 j
+  static_assert(KS >= 1 && KS * KX_NC == 2 * CPB, "k-steps deal evenly");
+  // codebooks -> LDS (the compute waves only: the X waves are already streaming)
+  for (int i = tid - LDS::NXP * 64; i < K * 256; i += KX_NC * 64)
+    *reinterpret_cast<u32x4*>(glds_smem + LDS::CB + (uint32_t)i * 16u) = reinterpret_cast<const u32x4*>(p.codebooks)[i];
+  // this lane's codes: row arow, group (step * 8 CPB) + 4 t + kg -> K bytes; requested KX_PD steps ahead, static ring slots
+  const uint8_t* code_base;
+  {
+    int r = row0 + arow;
+    r = r < p.M ? r : p.M - 1;
+    code_base = p.codes + ((size_t)r * p.in_groups + kg) * K;
+  }
+  auto load_codes = [&](int step, uint32_t (&c)[KS]) {  // unconditional; steps past the end re-read the last one
+    const int cc = step < n ? step : n - 1;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const uint8_t* src = code_base + ((size_t)cc * (8 * CPB) + 4 * (cw + KX_NC * j)) * K;
+      if constexpr (K == 2) c[j] = *reinterpret_cast<const uint16_t*>(src);
+      else c[j] = *src;
+    }
+  };
+  uint32_t cring[KX_PD][KS];
+#pragma unroll
+  for (int q = 0; q < KX_PD; ++q) load_codes(q, cring[q]);
+  f32x4 acc[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // codebooks visible to every compute wave
+
+  int sx = 0;
+  auto do_step = [&](const uint32_t (&c)[KS]) {
+    __builtin_amdgcn_s_barrier();  // the step's X has landed; everybody is done with the stage that is refilled next
+    const uint32_t xbase = LDS::X + (uint32_t)sx * LDS::X_STAGE;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int t = cw + KX_NC * j;  // k-step of the step: chunk t / 2, half t % 2
+      u32x4 w = *(glds_u32x4_ptr)(size_t)(LDS::CB + (c[j] & 0xffu) * 16u);
+      if constexpr (K == 2) {
+        const u32x4 w1 = *(glds_u32x4_ptr)(size_t)(LDS::CB + 4096u + (c[j] >> 8) * 16u);
+        w = kx_add8<T>(w, w1);
+      }
+      u32x4 b[NBT];
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt)
+        b[bt] = *(glds_u32x4_ptr)(size_t)(xbase + (uint32_t)(t >> 1) * LDS::X_CHUNK + (uint32_t)xswz(bt * 16 + arow, (t & 1) * 4 + kg) * 16u);
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) acc[bt] = mfma16<T>(w, b[bt], acc[bt]);
+    }
+    sx = sx == NSX - 1 ? 0 : sx + 1;
+  };
+  int i = 0;
+  for (; i + KX_PD <= n; i += KX_PD) {
+#pragma unroll
+    for (int q = 0; q < KX_PD; ++q) {  // static ring slots: the refill lands in the registers just consumed
+      do_step(cring[q]);
+      load_codes(i + KX_PD + q, cring[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KX_PD - 1; ++q)
+    if (i + q < n) do_step(cring[q]);
+
+  // ---- the four K shares meet in LDS (the X ring is free once every compute wave is past its last step) ----------------
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt)
+    *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)(cw * NBT + bt) * 1024u + (uint32_t)lane * 16u) = acc[bt];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // wave cw finishes batch tiles cw, cw + 4, ...: lane (arow, kg) holds rows 4 kg .. 4 kg + 3, batch column 16 bt + arow
+  const int m = row0 + kg * 4;
+  float sc[4], bi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mm = m + r < p.M ? m + r : p.M - 1;
+    sc[r] = T::to_float(p.scales[mm]);
+    bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+  }
+  const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0;
+  for (int bt = cw; bt < NBT; bt += KX_NC) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)bt * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+    for (int w = 1; w < KX_NC; ++w) {  // wave order: the result does not depend on who finishes
+      const f32x4 o = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(w * NBT + bt) * 1024u + (uint32_t)lane * 16u);
+      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    const int b = bt * 16 + arow;
+    if (b < p.B && m < p.M) {
+      uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+      uint16_t h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(v[r], sc[r], bi[r]));
+      if (vec) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+      else
+        for (int r = 0; r < 4; ++r)
+          if (m + r < p.M) dst[r] = h[r];
+    }
+  }
+}
+
+struct KxPlan {
+  int nbt, cpb, nsteps;
+};
+
+static bool plan_kx8(int B, int Kf, KxPlan& r) {
+  if (Kf % (2 * BK) != 0 || B < 1 || B > 128) return false;
+  const int t = (B + 15) / 16;
+  r.nbt = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
+  const int chunks = Kf / BK;
+  r.cpb = (r.nbt <= 2 && chunks % 4 == 0) ? 4 : 2;
+  r.nsteps = chunks / r.cpb;
+  return r.nsteps >= 3;  // the X ring's prologue (NSX <= 4)
+}
+
+template <class T, int K>
+static int launch_kx8(const KxParams& p, const KxPlan& r, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.M + 15) / 16));
+  auto go = [&](auto kern, size_t lds, int waves) -> int {
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "gemm_kx8_rows16 launch");
+  };
+#define AQLM_KX_CASE(NBT_, CPB_) return go(gemm_kx8_rows16_kernel<T, K, NBT_, CPB_>, KxLds<K, NBT_, CPB_>::TOTAL, KxLds<K, NBT_, CPB_>::WAVES)
+  if (r.cpb == 4) {
+    if (r.nbt == 1) AQLM_KX_CASE(1, 4);
+    AQLM_KX_CASE(2, 4);
+  }
+  switch (r.nbt) {
+    case 1: AQLM_KX_CASE(1, 2);
+    case 2: AQLM_KX_CASE(2, 2);
+    case 4: AQLM_KX_CASE(4, 2);
+    default: AQLM_KX_CASE(8, 2);
+  }
+#undef AQLM_KX_CASE
+}
+
 struct GemmPlan {
   int ksplit, kslice, Bpad, nbt;
 };
@@ -988,6 +1237,56 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   if (plan_glds(std::min(batch, 128), out_features, in_features, q) && q.ksplit > 1)
     need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
   return need;
+}
+
+extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* X,
+                                      void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
+                                      long xs, long ys, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!codes || !codebooks || !scales || !X || !Y) {
+    set_last_error("aqlm_hip_gemm_kx8_mfma: null pointer argument");
+    return AQLM_HIP_E_INVALID;
+  }
+  if (batch <= 0 || out_features <= 0 || in_features <= 0) {
+    set_last_error("aqlm_hip_gemm_kx8_mfma: sizes must be positive");
+    return AQLM_HIP_E_INVALID;
+  }
+  if ((num_codebooks != 1 && num_codebooks != 2) || in_group_size != 8) {
+    set_last_error("aqlm_hip_gemm_kx8_mfma: 1 or 2 codebooks of 256 x 8 only, got %d codebooks, group %d", num_codebooks, in_group_size);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (dtype != AQLM_HIP_F16 && dtype != AQLM_HIP_BF16) {
+    set_last_error("aqlm_hip_gemm_kx8_mfma: AQLM HIP kernels only support float16 and bfloat16 (dtype id %d)", dtype);
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  KxPlan probe{};
+  if (!plan_kx8(std::min(batch, 128), in_features, probe) || !aligned16(codebooks) || !aligned16(X) || xs % 8 != 0) {
+    set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
+    return AQLM_HIP_E_UNSUPPORTED;
+  }
+  for (int b0 = 0; b0 < batch; b0 += 128) {  // slabs of 128 rows (the codes are re-read per slab: they are 2 bits per weight)
+    const int nb = std::min(128, batch - b0);
+    KxPlan r{};
+    plan_kx8(nb, in_features, r);
+    KxParams kp{};
+    kp.codes = (const uint8_t*)codes;
+    kp.codebooks = (const uint8_t*)codebooks;
+    kp.X = (const uint16_t*)X + (long)b0 * xs;
+    kp.scales = (const uint16_t*)scales;
+    kp.bias = (const uint16_t*)bias;
+    kp.Y = (uint16_t*)Y + (long)b0 * ys;
+    kp.xs = xs;
+    kp.ys = ys;
+    kp.M = out_features;
+    kp.B = nb;
+    kp.in_groups = in_features / 8;
+    kp.nsteps = r.nsteps;
+    int e;
+    if (dtype == AQLM_HIP_F16) e = num_codebooks == 2 ? launch_kx8<F16, 2>(kp, r, stream) : launch_kx8<F16, 1>(kp, r, stream);
+    else e = num_codebooks == 2 ? launch_kx8<BF16, 2>(kp, r, stream) : launch_kx8<BF16, 1>(kp, r, stream);
+    if (e) return e;
+  }
+  return 0;
 }
 
 extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, const void* scales, const void* bias,

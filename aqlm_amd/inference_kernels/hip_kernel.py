@@ -1040,11 +1040,52 @@ def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
 def _matmat_dequant_kx8(input, codes, codebooks, scales, bias):
     """Reference pipeline for the 8-bit schemes (cuda_kernel.cpp:450-484, 615-649): dequantise (our kernel), one
     library GEMM, scale + bias."""
-    _dtype_id(input)
+    dt = _dtype_id(input)
+    y = _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt)
+    if y is not None:
+        return y
     # W without the scales: exact for one codebook, one rounding of the K-term sum otherwise (as in the reference, which
     # also scales y after the GEMM, cuda_kernel.cpp:478-483); folding the scales into W would round every weight again
     W = _dequant(codes, codebooks, None, "kx8")
     return _scale_bias_fp32(F.linear(input, W), scales, bias)
+
+
+# Rows up to which the 8-bit schemes' large-batch ops run the fused kernel (aqlm_hip_gemm_kx8_mfma: one launch per 128 rows, every
+# 16-row block streams all of X); beyond, W is dequantised once and hipBLASLt runs the GEMM, as the reference does.  Measured
+# (profiles/r04_gemm_kx8_shapes.log, 2x8 g8, hipGraph, us; fused / dequant + GEMM / dense fp16): 4096^2 at 16 / 128 / 256 rows
+# 8.3 / 16.3 / 31.7 vs 36 / 41 / 41 vs 12.7 / 24.6 / 23.5; 4096 -> 11008 at 16 / 128 / 256 rows 18.2 / 46.5 / 89.8 vs 53 / 60 / 79.
+FUSED_KX8_MFMA_MAX_ROWS = 128         # any layer
+FUSED_KX8_MFMA_MAX_ROWS_SMALL = 256   # layers of <= 4096 x 4096
+USE_FUSED_KX8_MFMA = True
+
+
+def _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt):
+    """The fused dequant -> MFMA kernel for 1x8 g8 / 2x8 g8 (W never materialised), or None when the call is outside it."""
+    K, size, og, g = codebooks.shape
+    if not USE_FUSED_KX8_MFMA or K not in (1, 2) or size != 256 or og != 1 or g != 8 or codes.dtype != torch.int8:
+        return None
+    in_features = codes.shape[1] * g
+    if in_features % 128 != 0 or in_features < 384 or input.shape[-1] != in_features:
+        return None
+    if codebooks.dtype != input.dtype or scales.dtype != input.dtype or (bias is not None and bias.dtype != input.dtype):
+        return None
+    x = _flat_rows(input)
+    B = x.shape[0]
+    out_features = codes.shape[0]
+    if B < 1 or B > (FUSED_KX8_MFMA_MAX_ROWS_SMALL if out_features * in_features <= (1 << 24) else FUSED_KX8_MFMA_MAX_ROWS):
+        return None
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    with _device_guard(input.device):
+        rc = _lib.aqlm_hip_gemm_kx8_mfma(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(), y.data_ptr(),
+                                         B, out_features, in_features, K, g, x.stride(0), out_features, dt, _stream_ptr(input.device))
+    if rc == _native.E_UNSUPPORTED:
+        return None
+    if rc:
+        _native.check(rc, "aqlm gemm_kx8_mfma")
+    return y.reshape(input.shape[:-1] + (out_features,))
 
 
 def code2x8_matmat_dequant(input, codes, codebooks, scales, bias=None):

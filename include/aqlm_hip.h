@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 5
+#define AQLM_HIP_ABI_VERSION 6
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -380,6 +380,20 @@ int aqlm_hip_gemv_8x8_lut_planar(const void* planar, const void* codebooks, cons
 int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const float* codebook_absmax, int num_segments,
                                        const void* x, int in_features, int in_group_size, int dtype, void* workspace,
                                        size_t workspace_bytes, int fused, void* stream);
+
+/*
+ * Large-batch path of the 8-bit schemes (ABI 6): Y[B][out] = (X[B][in] @ W^T) * scales + bias for 1 or 2 codebooks of 256 x 8
+ * (1x8 g8, 2x8 g8), W never materialised: the codebooks live in LDS, a block owns 16 output rows over all of K, every lane
+ * builds its part of the 16 x 32 MFMA fragment from its code bytes (K-term sum rounded once to the storage type, as
+ * aqlm_hip_dequant_kx8 does), X streams through LDS.  No workspace, one launch per 128 batch rows.
+ * Replaces: code2x8_matmat_dequant / code1x8_matmat_dequant = Code2x8Dequant / CodeKx8Dequant + F::linear(cuBLAS) + epilogue
+ * (cuda_kernel.cpp:450-484, 615-649; kernels cuda_kernel.cu:235-294, 392-468).
+ * AQLM_HIP_E_UNSUPPORTED (the caller dequantises + calls its GEMM, like the reference): other schemes, in_features not a
+ * multiple of 128 or < 384, X rows not 16-B aligned.
+ */
+int aqlm_hip_gemm_kx8_mfma(const void* codes_i8, const void* codebooks, const void* scales, const void* bias, const void* X,
+                           void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
+                           long x_row_stride, long y_row_stride, int dtype, void* stream);
 
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3

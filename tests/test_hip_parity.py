@@ -337,6 +337,55 @@ def test_matmat_dequant_kx8(hk, K, g):
     check_close(y, y64, torch.float16, f"{K}x8 dequant+gemm")
 
 
+@pytest.mark.parametrize("K,fin,fout,B,dt,bias", [
+    (2, 4096, 4096, 128, "float16", False),   # the headline large-batch shape of the scheme
+    (2, 4096, 300, 7, "float16", True),       # the smallest batch the module sends (gemv rule + 1), ragged rows
+    (2, 11008, 512, 33, "bfloat16", True),    # K = 172 chunks (a multiple of 4), three batch tiles computed as four
+    (1, 2048, 192, 40, "float16", True),      # one codebook: W is exact
+    (2, 384, 64, 16, "float16", False),       # the shortest K the kernel takes (3 steps of 2 chunks)
+    (2, 640, 48, 100, "bfloat16", True),      # K = 10 chunks: steps of 2 chunks only
+    (1, 1280, 77, 200, "float16", True),      # two slabs of 128 rows, ragged rows
+    (2, 1024, 16, 256, "float16", False),     # two full slabs, a single row block
+])
+def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
+    """The 8-bit schemes' large-batch ops on the fused dequant -> MFMA kernel (aqlm_hip_gemm_kx8_mfma, round 4): against the fp64
+    oracle, against the dequantise + library-GEMM route of the same op (the reference's pipeline, cuda_kernel.cpp:450-484), bit
+    for bit repeatable, batch rows independent of their neighbours, strided inputs; shapes the kernel does not take fall through."""
+    dtype = tdtype(dt)
+    L = orc.make_layer(8800 + fin + B, fin, fout, K, 8, 8, batch=B, bias=bias, float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    T = to_dev(L, dtype)
+    op = hk.code2x8_matmat_dequant if K == 2 else hk.code1x8_matmat_dequant
+    assert hk._fused_kx8_mfma(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], hk._dtype_id(T["x"])) is not None
+    y = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    assert torch.equal(y, op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]))
+    y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+    wide = 1.0 if K == 1 else (1.6 if dtype == torch.float16 else 3.0)  # W is rounded once to the storage type (as in the reference's pipeline)
+    check_close(y.float().cpu().numpy(), y64, dtype, f"fused {K}x8 mfma {fin}->{fout} B{B}", el_scale=wide)
+    hk.USE_FUSED_KX8_MFMA = False
+    try:
+        y_lib = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+    finally:
+        hk.USE_FUSED_KX8_MFMA = True
+    den = float(y_lib.float().abs().mean())
+    assert float((y.float() - y_lib.float()).abs().mean()) / den < (2e-3 if dtype == torch.float16 else 1e-2)
+    # a row's result does not depend on the rows around it (same kernel instance: same batch-tile count)
+    if B >= 3:
+        x2 = T["x"].clone()
+        x2[1:] = torch.flip(x2[1:], dims=(0,))
+        y2 = op(x2, T["codes"], T["codebooks"], T["scales"], T["bias"])
+        assert torch.equal(y2[0], y[0]) and torch.equal(y2[1], y[B - 1])
+    wide_x = torch.zeros(B, fin + 32, dtype=dtype, device=DEV)
+    wide_x[:, 16:16 + fin] = T["x"]
+    assert torch.equal(op(wide_x[:, 16:16 + fin], T["codes"], T["codebooks"], T["scales"], T["bias"]), y)
+    # outside the kernel: in_features not a multiple of 128 -> dequantise + GEMM, same answer within the bound
+    if fin == 2048:
+        L3 = orc.make_layer(17, 448, 40, K, 8, 8, batch=9, bias=True)
+        T3 = to_dev(L3, torch.float16)
+        assert hk._fused_kx8_mfma(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], T3["bias"], hk._dtype_id(T3["x"])) is None
+        check_close(op(T3["x"], T3["codes"], T3["codebooks"], T3["scales"], T3["bias"]).float().cpu().numpy(),
+                    orc.dequantize_gemm(L3["x"], L3["codes"], L3["codebooks"], L3["scales"], L3["bias"]), torch.float16, "kx8 fall-through")
+
+
 # ------------------------------------------------------------------ module level: QuantizedLinear + autograd + graphs
 def _module_from(L, K, nbits, g, fin, fout, dtype):
     from aqlm import QuantizedLinear

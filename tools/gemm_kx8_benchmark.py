@@ -1,0 +1,33 @@
+"""Large-batch ops of the 8-bit schemes: the fused dequant -> MFMA kernel (aqlm_hip_gemm_kx8_mfma) against the dequantise + library-GEMM
+route of the same op (the reference's pipeline) and a dense fp16 GEMM on rotating weights; hipGraph replay over 24 layers.
+
+    python tools/gemm_kx8_benchmark.py > profiles/r04_gemm_kx8_shapes.log
+"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import aqlm_amd.inference_kernels.hip_kernel as hk
+from tools.gemm_variants_benchmark import timeit, dev
+def layers(fin, fout, K, n):
+    gen = torch.Generator(device=dev).manual_seed(fin + fout)
+    out = []
+    for _ in range(n):
+        codes = torch.randint(-128, 128, (fout, fin // 8, K), generator=gen, device=dev, dtype=torch.int32).to(torch.int8)
+        out.append((codes, torch.randn((K, 256, 1, 8), generator=gen, device=dev).half()))
+    return out
+for K in (2, 1):
+    for fin, fout in ((4096, 4096), (4096, 11008), (11008, 4096)):
+        ls = layers(fin, fout, K, 24)
+        scales = torch.ones((fout, 1, 1, 1), device=dev, dtype=torch.float16)
+        Ws = [torch.randn((fout, fin), device=dev).half() for _ in range(24)]
+        op = hk.code2x8_matmat_dequant if K == 2 else hk.code1x8_matmat_dequant
+        for B in (8, 16, 32, 64, 128, 256):
+            x = torch.randn((B, fin), device=dev).half()
+            hk.USE_FUSED_KX8_MFMA = True
+            t_f = timeit(lambda c, cb: op(x, c, cb, scales, None), ls)
+            hk.USE_FUSED_KX8_MFMA = False
+            t_l = timeit(lambda c, cb: op(x, c, cb, scales, None), ls)
+            hk.USE_FUSED_KX8_MFMA = True
+            it = iter(range(10**9))
+            t_d = timeit(lambda c, cb: torch.nn.functional.linear(x, Ws[next(it) % 24]), ls)
+            print(f"{K}x8g8 {fin}->{fout} B={B}: fused {t_f:.2f} us  dequant+gemm {t_l:.2f} us  dense fp16 (rotating weights) {t_d:.2f} us", flush=True)
