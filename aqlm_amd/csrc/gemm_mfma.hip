@@ -952,7 +952,7 @@ static int launch_rows16(const R16Params& p, const R16Plan& r, hipStream_t strea
 constexpr int KX_NC = 4;   // compute waves
 constexpr int KX_PD = 3;   // steps the codes are requested ahead
 
-template <int K, int NBT, int CPB>
+template <int K, int NBT, int CPB, int RT>
 struct KxLds {
   static constexpr int NXP = 2 * NBT >= 4 ? 4 : 2 * NBT;            // X producer waves
   static constexpr int PXW = CPB * 2 * NBT / NXP;                   // 1-KiB pieces (8 batch rows x 64 k) per X wave and step
@@ -962,9 +962,9 @@ struct KxLds {
   static constexpr uint32_t CB = 0;                                 // [K][256][16 B]
   static constexpr uint32_t X = (uint32_t)K * 4096u;
   static constexpr uint32_t TOTAL = X + NSX * X_STAGE;
-  static constexpr uint32_t RED = X;                                // [KX_NC][NBT][1 KiB] fp32 partial tiles, after the last step
+  static constexpr uint32_t RED = X;                                // [KX_NC][RT][NBT][1 KiB] fp32 partial tiles, after the last step
   static constexpr int WAVES = NXP + KX_NC;
-  static_assert(KX_NC * NBT * 1024u <= NSX * X_STAGE, "the reduction reuses the X ring");
+  static_assert(KX_NC * RT * NBT * 1024u <= NSX * X_STAGE, "the reduction reuses the X ring");
   static_assert(TOTAL <= 160u * 1024u, "LDS");
 };
 
@@ -994,17 +994,18 @@ __device__ __forceinline__ u32x4 kx_add8<BF16>(u32x4 a, u32x4 b) {  // fp32 sums
   return u32x4{kx_add2_bf16(a.x, b.x), kx_add2_bf16(a.y, b.y), kx_add2_bf16(a.z, b.z), kx_add2_bf16(a.w, b.w)};
 }
 
-template <class T, int K, int NBT, int CPB>
-__global__ __launch_bounds__((KxLds<K, NBT, CPB>::WAVES * 64)) void gemm_kx8_rows16_kernel(const KxParams p) {
-  using LDS = KxLds<K, NBT, CPB>;
+// RT = 16-row tiles per block: every block streams all of X through its L1, so tall layers (>= 8192 rows: still >= 256 blocks)
+// take two tiles per block -- half the X traffic, every X fragment feeds two MFMAs.
+template <class T, int K, int NBT, int CPB, int RT>
+__global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8_rows16_kernel(const KxParams p) {
+  using LDS = KxLds<K, NBT, CPB, RT>;
   constexpr int NSX = LDS::NSX;
-  constexpr int NT = LDS::WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int arow = lane & 15, kg = lane >> 4;
-  const int row0 = (int)blockIdx.x * 16;
+  const int row0 = (int)blockIdx.x * (16 * RT);
   const int n = p.nsteps;  // >= NSX - 1 (host)
 
   if (wave < LDS::NXP) {
@@ -1053,49 +1054,60 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB>::WAVES * 64)) void gemm_kx8_row
   // codebooks -> LDS (the compute waves only: the X waves are already streaming)
   for (int i = tid - LDS::NXP * 64; i < K * 256; i += KX_NC * 64)
     *reinterpret_cast<u32x4*>(glds_smem + LDS::CB + (uint32_t)i * 16u) = reinterpret_cast<const u32x4*>(p.codebooks)[i];
-  // this lane's codes: row arow, group (step * 8 CPB) + 4 t + kg -> K bytes; requested KX_PD steps ahead, static ring slots
-  const uint8_t* code_base;
-  {
-    int r = row0 + arow;
+  // this lane's codes: row (tile rt) arow, group (step * 8 CPB) + 4 t + kg -> K bytes; requested KX_PD steps ahead, static ring slots
+  const uint8_t* code_base[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int r = row0 + rt * 16 + arow;
     r = r < p.M ? r : p.M - 1;
-    code_base = p.codes + ((size_t)r * p.in_groups + kg) * K;
+    code_base[rt] = p.codes + ((size_t)r * p.in_groups + kg) * K;
   }
-  auto load_codes = [&](int step, uint32_t (&c)[KS]) {  // unconditional; steps past the end re-read the last one
+  auto load_codes = [&](int step, uint32_t (&c)[RT][KS]) {  // unconditional; steps past the end re-read the last one
     const int cc = step < n ? step : n - 1;
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-      const uint8_t* src = code_base + ((size_t)cc * (8 * CPB) + 4 * (cw + KX_NC * j)) * K;
-      if constexpr (K == 2) c[j] = *reinterpret_cast<const uint16_t*>(src);
-      else c[j] = *src;
-    }
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const uint8_t* src = code_base[rt] + ((size_t)cc * (8 * CPB) + 4 * (cw + KX_NC * j)) * K;
+        if constexpr (K == 2) c[rt][j] = *reinterpret_cast<const uint16_t*>(src);
+        else c[rt][j] = *src;
+      }
   };
-  uint32_t cring[KX_PD][KS];
+  uint32_t cring[KX_PD][RT][KS];
 #pragma unroll
   for (int q = 0; q < KX_PD; ++q) load_codes(q, cring[q]);
-  f32x4 acc[NBT];
+  f32x4 acc[RT][NBT];
 #pragma unroll
-  for (int t = 0; t < NBT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // codebooks visible to every compute wave
 
   int sx = 0;
-  auto do_step = [&](const uint32_t (&c)[KS]) {
+  auto do_step = [&](const uint32_t (&c)[RT][KS]) {
     __builtin_amdgcn_s_barrier();  // the step's X has landed; everybody is done with the stage that is refilled next
     const uint32_t xbase = LDS::X + (uint32_t)sx * LDS::X_STAGE;
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int t = cw + KX_NC * j;  // k-step of the step: chunk t / 2, half t % 2
-      u32x4 w = *(glds_u32x4_ptr)(size_t)(LDS::CB + (c[j] & 0xffu) * 16u);
-      if constexpr (K == 2) {
-        const u32x4 w1 = *(glds_u32x4_ptr)(size_t)(LDS::CB + 4096u + (c[j] >> 8) * 16u);
-        w = kx_add8<T>(w, w1);
+      u32x4 w[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        w[rt] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (c[rt][j] & 0xffu) * 16u);
+        if constexpr (K == 2) {
+          const u32x4 w1 = *(glds_u32x4_ptr)(size_t)(LDS::CB + 4096u + (c[rt][j] >> 8) * 16u);
+          w[rt] = kx_add8<T>(w[rt], w1);
+        }
       }
       u32x4 b[NBT];
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt)
         b[bt] = *(glds_u32x4_ptr)(size_t)(xbase + (uint32_t)(t >> 1) * LDS::X_CHUNK + (uint32_t)xswz(bt * 16 + arow, (t & 1) * 4 + kg) * 16u);
 #pragma unroll
-      for (int bt = 0; bt < NBT; ++bt) acc[bt] = mfma16<T>(w, b[bt], acc[bt]);
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) acc[rt][bt] = mfma16<T>(w[rt], b[bt], acc[rt][bt]);
     }
     sx = sx == NSX - 1 ? 0 : sx + 1;
   };
@@ -1114,33 +1126,33 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB>::WAVES * 64)) void gemm_kx8_row
   // ---- the four K shares meet in LDS (the X ring is free once every compute wave is past its last step) ----------------
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int bt = 0; bt < NBT; ++bt)
-    *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)(cw * NBT + bt) * 1024u + (uint32_t)lane * 16u) = acc[bt];
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt)
+      *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)((cw * RT + rt) * NBT + bt) * 1024u + (uint32_t)lane * 16u) = acc[rt][bt];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // wave cw finishes batch tiles cw, cw + 4, ...: lane (arow, kg) holds rows 4 kg .. 4 kg + 3, batch column 16 bt + arow
-  const int m = row0 + kg * 4;
-  float sc[4], bi[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int mm = m + r < p.M ? m + r : p.M - 1;
-    sc[r] = T::to_float(p.scales[mm]);
-    bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
-  }
+  // wave cw finishes tiles cw, cw + 4, ... of the RT x NBT output tiles: lane (arow, kg) holds rows 4 kg .. 4 kg + 3, batch column arow
   const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0;
-  for (int bt = cw; bt < NBT; bt += KX_NC) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)bt * 1024u + (uint32_t)lane * 16u);
+  for (int tile = cw; tile < RT * NBT; tile += KX_NC) {
+    const int rt = tile / NBT, bt = tile - rt * NBT;
+    f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)tile * 1024u + (uint32_t)lane * 16u);
 #pragma unroll
     for (int w = 1; w < KX_NC; ++w) {  // wave order: the result does not depend on who finishes
-      const f32x4 o = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(w * NBT + bt) * 1024u + (uint32_t)lane * 16u);
-      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+      const f32x4 o = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(w * RT * NBT + tile) * 1024u + (uint32_t)lane * 16u);
+      v = v + o;
     }
+    const int m = row0 + rt * 16 + kg * 4;
     const int b = bt * 16 + arow;
     if (b < p.B && m < p.M) {
       uint16_t* dst = p.Y + (size_t)b * p.ys + m;
       uint16_t h[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(v[r], sc[r], bi[r]));
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m + r < p.M ? m + r : p.M - 1;
+        const float sc = T::to_float(p.scales[mm]), bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+        h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
+      }
       if (vec) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
       else
         for (int r = 0; r < 4; ++r)
@@ -1150,38 +1162,47 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB>::WAVES * 64)) void gemm_kx8_row
 }
 
 struct KxPlan {
-  int nbt, cpb, nsteps;
+  int nbt, cpb, rt, nsteps;
 };
 
-static bool plan_kx8(int B, int Kf, KxPlan& r) {
+static bool plan_kx8(int B, int M, int Kf, KxPlan& r) {
   if (Kf % (2 * BK) != 0 || B < 1 || B > 128) return false;
   const int t = (B + 15) / 16;
   r.nbt = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
   const int chunks = Kf / BK;
   r.cpb = (r.nbt <= 2 && chunks % 4 == 0) ? 4 : 2;
   r.nsteps = chunks / r.cpb;
+  // two row tiles per block where that still fills the chip AND X is what the block mostly moves (measured, 4096 -> 11008: 128 rows
+  // 46.5 -> 39.6 us, 64 rows 28.5 -> 26.9, but 16 rows 18.2 -> 20.8: 344 blocks are 1.3 rounds of the chip)
+  r.rt = ((M + 31) / 32 >= 256 && r.nbt >= 4) ? 2 : 1;
   return r.nsteps >= 3;  // the X ring's prologue (NSX <= 4)
 }
 
 template <class T, int K>
 static int launch_kx8(const KxParams& p, const KxPlan& r, hipStream_t stream) {
-  const dim3 grid((unsigned)((p.M + 15) / 16));
+  const dim3 grid((unsigned)((p.M + 16 * r.rt - 1) / (16 * r.rt)));
   auto go = [&](auto kern, size_t lds, int waves) -> int {
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemm_kx8_rows16 launch");
   };
-#define AQLM_KX_CASE(NBT_, CPB_) return go(gemm_kx8_rows16_kernel<T, K, NBT_, CPB_>, KxLds<K, NBT_, CPB_>::TOTAL, KxLds<K, NBT_, CPB_>::WAVES)
+#define AQLM_KX_CASE(NBT_, CPB_, RT_) return go(gemm_kx8_rows16_kernel<T, K, NBT_, CPB_, RT_>, KxLds<K, NBT_, CPB_, RT_>::TOTAL, KxLds<K, NBT_, CPB_, RT_>::WAVES)
+#define AQLM_KX_RT(NBT_, CPB_)        \
+  do {                                \
+    if (r.rt == 2) AQLM_KX_CASE(NBT_, CPB_, 2); \
+    AQLM_KX_CASE(NBT_, CPB_, 1);      \
+  } while (0)
   if (r.cpb == 4) {
-    if (r.nbt == 1) AQLM_KX_CASE(1, 4);
-    AQLM_KX_CASE(2, 4);
+    if (r.nbt == 1) AQLM_KX_RT(1, 4);
+    AQLM_KX_RT(2, 4);
   }
   switch (r.nbt) {
-    case 1: AQLM_KX_CASE(1, 2);
-    case 2: AQLM_KX_CASE(2, 2);
-    case 4: AQLM_KX_CASE(4, 2);
-    default: AQLM_KX_CASE(8, 2);
+    case 1: AQLM_KX_RT(1, 2);
+    case 2: AQLM_KX_RT(2, 2);
+    case 4: AQLM_KX_RT(4, 2);
+    default: AQLM_KX_RT(8, 2);
   }
+#undef AQLM_KX_RT
 #undef AQLM_KX_CASE
 }
 
@@ -1260,14 +1281,14 @@ extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, 
     return AQLM_HIP_E_UNSUPPORTED;
   }
   KxPlan probe{};
-  if (!plan_kx8(std::min(batch, 128), in_features, probe) || !aligned16(codebooks) || !aligned16(X) || xs % 8 != 0) {
+  if (!plan_kx8(std::min(batch, 128), out_features, in_features, probe) || !aligned16(codebooks) || !aligned16(X) || xs % 8 != 0) {
     set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
     return AQLM_HIP_E_UNSUPPORTED;
   }
   for (int b0 = 0; b0 < batch; b0 += 128) {  // slabs of 128 rows (the codes are re-read per slab: they are 2 bits per weight)
     const int nb = std::min(128, batch - b0);
     KxPlan r{};
-    plan_kx8(nb, in_features, r);
+    plan_kx8(nb, out_features, in_features, r);
     KxParams kp{};
     kp.codes = (const uint8_t*)codes;
     kp.codebooks = (const uint8_t*)codebooks;

@@ -346,6 +346,8 @@ def test_matmat_dequant_kx8(hk, K, g):
     (2, 640, 48, 100, "bfloat16", True),      # K = 10 chunks: steps of 2 chunks only
     (1, 1280, 77, 200, "float16", True),      # two slabs of 128 rows, ragged rows
     (2, 1024, 16, 256, "float16", False),     # two full slabs, a single row block
+    (2, 1024, 8200, 40, "float16", True),     # tall layer: two 16-row tiles per block, the last block half empty
+    (1, 512, 11008, 128, "bfloat16", False),  # tall layer, full batch tiles, bf16 sums
 ])
 def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
     """The 8-bit schemes' large-batch ops on the fused dequant -> MFMA kernel (aqlm_hip_gemm_kx8_mfma, round 4): against the fp64

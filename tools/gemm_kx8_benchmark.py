@@ -15,8 +15,8 @@ def layers(fin, fout, K, n):
         codes = torch.randint(-128, 128, (fout, fin // 8, K), generator=gen, device=dev, dtype=torch.int32).to(torch.int8)
         out.append((codes, torch.randn((K, 256, 1, 8), generator=gen, device=dev).half()))
     return out
-for K in (2, 1):
-    for fin, fout in ((4096, 4096), (4096, 11008), (11008, 4096)):
+for K in (2,):
+    for fin, fout in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192)):
         ls = layers(fin, fout, K, 24)
         scales = torch.ones((fout, 1, 1, 1), device=dev, dtype=torch.float16)
         Ws = [torch.randn((fout, fin), device=dev).half() for _ in range(24)]
