@@ -421,6 +421,26 @@ def large_batch_detail(dev, reps):
         by_rows[f"rows{rows}"] = {"fused_mfma_us": timegraph(lambda l, xin: hk.code1x16_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), xr),
                                   "dense_fp16_gemm_us": timegraph(lambda l, xin: F.linear(xin, Ws[l.seed % 8]), xr)}
     out["graph_by_rows"] = by_rows
+    # the 8-bit scheme's large-batch op (code2x8_matmat_dequant): fused dequant -> MFMA kernel with the codebooks in LDS (no gather
+    # floor) vs the reference's pipeline (dequantise + library GEMM) vs dense fp16, same shape, same protocol
+    keep = layers
+    try:
+        layers = [Layer(fin, fout, 2, 8, 8, 454545 + i, dev) for i in range(24)]
+        kx = {}
+        for rows in (16, 64, 128):
+            xr = torch.randn((rows, fin), device=dev, dtype=torch.float16)
+            f_us = timegraph(lambda l, xin: hk.code2x8_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), xr)
+            hk.USE_FUSED_KX8_MFMA = False
+            try:
+                d_us = timegraph(lambda l, xin: hk.code2x8_matmat_dequant(xin, l.codes, l.codebooks, l.scales, None), xr)
+            finally:
+                hk.USE_FUSED_KX8_MFMA = True
+            kx[f"rows{rows}"] = {"fused_mfma_us": f_us, "dequant_plus_gemm_us": d_us,
+                                 "dense_fp16_gemm_us": timegraph(lambda l, xin: F.linear(xin, Ws[l.seed % 8]), xr),
+                                 "fused_TFLOPs": 2.0 * rows * fin * fout / f_us * 1e-6}
+        out["kx8_2x8g8_4096x4096"] = kx
+    finally:
+        layers = keep
     # 2..8 rows (speculative decode, small-batch serving; the module sends <= 6 rows to the matvec kernels): the prepacked matvec
     # (one more LDS read + 4 dots per entry and row) against the MFMA op (cost of 16 rows whatever the count), hipGraph, cold
     small = {}
