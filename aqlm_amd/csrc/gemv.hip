@@ -664,6 +664,16 @@ static int dispatch_kx8_nb(int nb, const GemvParams& p, hipStream_t s) {
 }
 }  // namespace aqlm
 
+// 3..8 rows of a 1x8 / 2x8 g8 layer: the matvec kernels pay one more x read + 4 dot products per code and row (2x8 g8 4096^2:
+// 7.0 / 11.7 / 16.5 / 19.0 us at 2 / 3 / 6 / 8 rows), the fused dequant -> MFMA kernel costs 8.1 us for any count up to 16
+// (4096 -> 11008: 34.5 vs 17.6 us at 6 rows; profiles/r04_kx8_rows_matvec_vs_mfma.log).  From `kx8_mfma_min_rows` rows on (tuning
+// key, default 3, 0 = never) the matvec entries hand the call to aqlm_hip_gemm_kx8_mfma; it rounds the K-term weight sum once to the
+// storage type, as the reference's own 2x8 kernel does (hadd2, cuda_kernel.cu:199-214), where the matvec kernels keep it in fp32.
+static bool kx8_rows_take_mfma(int batch, int K, int G) {
+  const int min_rows = aqlm::tuning().kx8_mfma_min_rows;
+  return min_rows > 0 && batch >= min_rows && G == 8 && (K == 1 || K == 2) && !aqlm::tuning().force_generic;
+}
+
 extern "C" int aqlm_hip_gemv_kx8(const void* codes, const void* codebooks, const void* scales, const void* bias,
                                  const void* x, void* y, int out_features, int in_features, int num_codebooks,
                                  int in_group_size, int batch, long xs, long ys, int dtype, void* stream_) {
@@ -674,6 +684,11 @@ extern "C" int aqlm_hip_gemv_kx8(const void* codes, const void* codebooks, const
   if (num_codebooks < 1 || num_codebooks > 16) {
     set_last_error("aqlm_hip_gemv_kx8: num_codebooks %d outside 1..16", num_codebooks);
     return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (kx8_rows_take_mfma(batch, num_codebooks, in_group_size)) {
+    const int e = aqlm_hip_gemm_kx8_mfma(codes, codebooks, scales, bias, x, y, batch, out_features, in_features, num_codebooks,
+                                         in_group_size, xs, ys, dtype, stream_);
+    if (e != AQLM_HIP_E_UNSUPPORTED) return e;  // (shapes outside the kernel: the matvec kernels below)
   }
   const int in_groups = in_features / in_group_size;
   const size_t x_row_bytes = (size_t)in_features * 2;
@@ -778,7 +793,8 @@ extern "C" int aqlm_hip_gemv_kx8_multi(const aqlm_hip_segment* segments, int num
   const size_t x_budget = std::min<size_t>(kMaxXTileBytes, 160 * 1024 - (size_t)K * 256 * 16 - 2048);
   const bool fast = in_group_size == 8 && (K == 1 || K == 2) && !tuning().force_generic && in_groups % 8 == 0 &&
                     aligned && xs % 8 == 0 && x_row_bytes + 256 <= x_budget;
-  if (!fast) {  // other schemes (8x8 ...) and odd shapes: one launch per segment, same results as the single-layer op
+  // (3+ rows of 1x8 / 2x8 g8: one launch of the fused MFMA kernel per segment beats one matvec launch over all of them)
+  if (!fast || kx8_rows_take_mfma(batch, K, in_group_size)) {  // other schemes (8x8 ...) and odd shapes: one launch per segment, same results as the single-layer op
     for (int k = 0; k < num_segments; ++k) {
       const aqlm_hip_segment& sg = segments[k];
       if (int e = aqlm_hip_gemv_kx8(sg.codes, sg.codebook, sg.scales, sg.bias, x, sg.y, sg.out_features, in_features, K,

@@ -207,7 +207,10 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
     ref = c_oracle.DequantGemv(L["codebooks"], L["codes"], L["scales"], L["bias"], nbits, nthreads=0)
     yh = y.float().cpu().numpy()
     for b in range(4):
-        check_close(yh[b], ref(L["x"][b]).copy(), dtype, f"full {K}x{nbits}g{g} {fin}->{fout} row {b}")
+        # (batches of 3+ rows of 2x8 g8 run on the fused MFMA kernel: W's two-term sum is rounded once to the storage type -- as in
+        # the reference's own kernel, cuda_kernel.cu:199-214 -- which widens the tail of the per-element error; the mean bound stands)
+        check_close(yh[b], ref(L["x"][b]).copy(), dtype, f"full {K}x{nbits}g{g} {fin}->{fout} row {b}",
+                    el_scale=1.6 if (K, nbits, g) == (2, 8, 8) else 1.0)
     # (2) batch consistency: a row of the batched launch == the same row launched alone (bit-exact)
     T1 = dict(T, x=T["x"][2:3].contiguous())
     y_single = run_forward(hk, K, nbits, g, T1)[0]
@@ -220,12 +223,17 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
         # batched result, and the plain LDS kernel (forced) reproduces the batched row bit for bit
         from aqlm_amd import _native
 
-        check_close(y_single.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "replicated vs batched")
+        # (and batches of 3+ rows take the fused MFMA kernel, which rounds the K-term weight sum to the storage type)
+        check_close(y_single.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "replicated vs batched", el_scale=2.0)
         _native.set_tuning("kx8_replicas", 0)
+        _native.set_tuning("kx8_mfma_min_rows", 0)
         try:
-            assert torch.equal(run_forward(hk, K, nbits, g, T1)[0], y[2])
+            y_plain = run_forward(hk, K, nbits, g, T)
+            assert torch.equal(run_forward(hk, K, nbits, g, T1)[0], y_plain[2])
+            check_close(y.float().cpu().numpy(), y_plain.float().cpu().numpy().astype(np.float64), dtype, "mfma vs plain matvec kernel, batched", el_scale=2.0)
         finally:
             _native.set_tuning("kx8_replicas", 1)
+            _native.set_tuning("kx8_mfma_min_rows", 3)
     else:
         assert torch.equal(y_single, y[2])
     # (3) zero input -> exactly the bias
@@ -1151,7 +1159,8 @@ def test_gemv_kx8_multi_matches_separate_launches(hk, K, fin, fouts, dt, batch):
                                                [T["scales"] for T in Ts], [T["bias"] for T in Ts])
     for L, T, y in zip(Ls, Ts, outs):
         y64 = orc.dequantize_gemm(Ls[0]["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-        check_close(y.float().cpu().numpy(), y64, dtype, f"multi {K}x8g8 {fin}->{L['codes'].shape[0]}")
+        check_close(y.float().cpu().numpy(), y64, dtype, f"multi {K}x8g8 {fin}->{L['codes'].shape[0]}",
+                    el_scale=1.6 if (K == 2 and batch >= 3) else 1.0)   # 3+ rows: fused MFMA kernel, W rounded once
         single = hk.codekx8_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
         check_close(y.float().cpu().numpy(), single.float().cpu().numpy().astype(np.float64), dtype, "multi vs single")
         if T["bias"] is not None:   # zero input -> exactly the bias
@@ -1605,7 +1614,7 @@ def test_randomized_layer_against_oracle(hk, seed):
     # weight once -- exactly what the reference's dequant + GEMM path does; with 10^5 outputs the 4.5-sigma tail of that
     # noise needs a slightly wider per-element bound (the mean bound is unchanged)
     wide = 1.0
-    if rows > 6 and K > 1:
+    if (rows > 6 and K > 1) or (rows >= 3 and (K, nbits, g) == (2, 8, 8)):   # (2x8 g8: the fused MFMA kernel from 3 rows on)
         wide = 1.6 if dtype == torch.float16 else 3.0   # bf16: the GEMM output itself is rounded to 8 bits before bias
     check_close(y.float().cpu().numpy(), y64, dtype, f"seed {seed}: {K}x{nbits}g{g} {fin}->{fout} rows={rows} {dt} bias={bias}",
                 el_scale=wide)
@@ -1929,7 +1938,10 @@ def test_fast_lane_equals_python_path(hk, K, nbits, g, fin, fout):
         check_close(y_fast.float().cpu().numpy(), y64, torch.float16, f"fast lane {K}x{nbits}g{g}")
         # shapes are kept; 3-d inputs; one row
         assert m(T["x"].reshape(2, 3, fin)).shape == (2, 3, fout)
-        assert torch.equal(m(T["x"][1:2])[0], y[1])
+        if nbits == 8:   # 3+ rows of 1x8 / 2x8 run on the fused MFMA kernel, single rows on the matvec kernels: close, not equal
+            check_close(m(T["x"][1:2])[0].float().cpu().numpy(), y[1].float().cpu().numpy().astype(np.float64), torch.float16, "one row vs batched")
+        else:
+            assert torch.equal(m(T["x"][1:2])[0], y[1])
         # not the lane's calls
         assert lane(torch.cat([T["x"], T["x"][:1]])) is None                     # 7 rows: the gemm rule of the module
         assert lane(T["x"].float()) is None                                       # another dtype
