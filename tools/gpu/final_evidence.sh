@@ -13,6 +13,7 @@ export TMPDIR=/tmp
 R=$PWD
 MB=$R/tools/microbench/mb
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -1
 # kernel counters first: bench.py reads the traffic of configs 3 / 4 from profiles/
 for spec in "2x8g8 4096 kx8 gemv_kx8_rep_kernel r04_2x8_rep_kernel_pmc.json" "8x8g32LUTP 4096 lutp gemv_8x8_lut_kernel r04_8x8_lut_planar_kernel_pmc.json" "8x8g32LUT= 4096 lutc gemv_8x8_lut_kernel r04_8x8_lut_kernel_pmc.json"; do
