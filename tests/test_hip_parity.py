@@ -1668,7 +1668,9 @@ def test_randomized_shared_input_groups(hk, seed):
         inf.PREPACK_MIN_CODES = old
     for k in range(n):
         y64 = orc.dequantize_gemm(Ls[0]["x"], Ls[k]["codes"], Ls[k]["codebooks"], Ls[k]["scales"], Ls[k]["bias"])
-        check_close(got[k].float().cpu().numpy(), y64, dtype, f"seed {seed} member {k}")
+        # (3+ rows of 2x8 g8 run on the fused MFMA kernel: W's two-term sum rounded once to the storage type, wider per-element tail)
+        wide = (1.6 if dtype == torch.float16 else 3.0) if ((K, nbits, g) == (2, 8, 8) and rows >= 3) else 1.0
+        check_close(got[k].float().cpu().numpy(), y64, dtype, f"seed {seed} member {k}", el_scale=wide)
         if nbits == 16:
             assert torch.equal(got[k], ref[k]), f"seed {seed} member {k}: fused 1x16 output differs from the unfused module"
 
