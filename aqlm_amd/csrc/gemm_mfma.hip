@@ -945,9 +945,9 @@ static int launch_rows16(const R16Params& p, const R16Plan& r, hipStream_t strea
 // batch size it takes.  Same frame as the 16-row kernel above (a block owns 16 output rows over all of K; X by LDS-DMA into a
 // ring of steps; one barrier per step), but the four compute waves split K, not the batch: within a step of 2 CPB k-steps (32 k
 // each) wave c takes k-steps c, c + 4, ...; for each it reads its lane's code (row = lane % 16, group = 4 t + lane / 16: K bytes,
-// prefetched 3 steps ahead in registers), gathers the K codebook vectors from LDS, sums them (ONE rounding to the storage type,
-// as the dequantisation kernel does) -- the result IS its lane of the 16 x 32 MFMA A fragment -- and multiplies it with every
-// batch tile of the step's X.  The four partial accumulators meet in LDS at the end in wave order (deterministic), then
+// prefetched 3 steps ahead in registers), gathers the K codebook vectors from LDS -- each IS a lane of a 16 x 32 MFMA A fragment
+// -- and multiplies each with every batch tile of the step's X: the K terms of a weight meet in the fp32 accumulator (K MFMAs per
+// tile; the matrix cores have room), so W is never rounded -- exact fp16 / bf16 products summed in fp32, like the matvec kernels.  The four partial accumulators meet in LDS at the end in wave order (deterministic), then
 // scale + bias + one rounding.
 constexpr int KX_NC = 4;   // compute waves
 constexpr int KX_PD = 3;   // steps the codes are requested ahead
@@ -978,21 +978,6 @@ struct KxParams {
   long xs, ys;
   int M, B, in_groups, nsteps;  // nsteps = K_features / (64 CPB)
 };
-
-template <class T>
-__device__ __forceinline__ u32x4 kx_add8(u32x4 a, u32x4 b);
-template <>
-__device__ __forceinline__ u32x4 kx_add8<F16>(u32x4 a, u32x4 b) {  // 4 x v_pk_add_f16: the exact sum, rounded once
-  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  return __builtin_bit_cast(u32x4, __builtin_bit_cast(h8, a) + __builtin_bit_cast(h8, b));
-}
-__device__ __forceinline__ uint32_t kx_add2_bf16(uint32_t a, uint32_t b) {
-  return (uint32_t)BF16::from_float(BF16::lo(a) + BF16::lo(b)) | ((uint32_t)BF16::from_float(BF16::hi(a) + BF16::hi(b)) << 16);
-}
-template <>
-__device__ __forceinline__ u32x4 kx_add8<BF16>(u32x4 a, u32x4 b) {  // fp32 sums, one rounding each
-  return u32x4{kx_add2_bf16(a.x, b.x), kx_add2_bf16(a.y, b.y), kx_add2_bf16(a.z, b.z), kx_add2_bf16(a.w, b.w)};
-}
 
 // RT = 16-row tiles per block: every block streams all of X through its L1, so tall layers (>= 8192 rows: still >= 256 blocks)
 // take two tiles per block -- half the X traffic, every X fragment feeds two MFMAs.
@@ -1091,15 +1076,12 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int t = cw + KX_NC * j;  // k-step of the step: chunk t / 2, half t % 2
-      u32x4 w[RT];
+      u32x4 w[RT][K];  // one A fragment lane per codebook: the K terms are accumulated by K MFMAs, never summed in the storage type
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        w[rt] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (c[rt][j] & 0xffu) * 16u);
-        if constexpr (K == 2) {
-          const u32x4 w1 = *(glds_u32x4_ptr)(size_t)(LDS::CB + 4096u + (c[rt][j] >> 8) * 16u);
-          w[rt] = kx_add8<T>(w[rt], w1);
-        }
-      }
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          w[rt][k] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (uint32_t)k * 4096u + ((c[rt][j] >> (8 * k)) & 0xffu) * 16u);
       u32x4 b[NBT];
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt)
@@ -1107,7 +1089,9 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int bt = 0; bt < NBT; ++bt) acc[rt][bt] = mfma16<T>(w[rt], b[bt], acc[rt][bt]);
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int bt = 0; bt < NBT; ++bt) acc[rt][bt] = mfma16<T>(w[rt][k], b[bt], acc[rt][bt]);
     }
     sx = sx == NSX - 1 ? 0 : sx + 1;
   };

@@ -1053,7 +1053,7 @@ def _matmat_dequant_kx8(input, codes, codebooks, scales, bias):
 # Rows up to which the 8-bit schemes' large-batch ops run the fused kernel (aqlm_hip_gemm_kx8_mfma: one launch per 128 rows, every
 # 16-row block streams all of X); beyond, W is dequantised once and hipBLASLt runs the GEMM, as the reference does.  Measured
 # (profiles/r04_gemm_kx8_shapes.log, 2x8 g8, hipGraph, us; fused / dequant + GEMM / dense fp16): 4096^2 at 16 / 128 / 256 rows
-# 8.3 / 16.3 / 31.7 vs 36 / 41 / 41 vs 12.7 / 24.6 / 23.5; 4096 -> 11008 at 16 / 128 / 256 rows 18.2 / 46.5 / 89.8 vs 53 / 60 / 79.
+# 8.2 / 16.8 / 33.2 vs 36 / 41 / 41 vs 12.7 / 24.6 / 23.5; 4096 -> 11008 at 16 / 128 / 256 rows 18.0 / 41.8 / 79 vs 53 / 60 / 79.
 FUSED_KX8_MFMA_MAX_ROWS = 128         # any layer
 FUSED_KX8_MFMA_MAX_ROWS_SMALL = 256   # layers of <= 4096 x 4096
 USE_FUSED_KX8_MFMA = True

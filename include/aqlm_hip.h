@@ -384,8 +384,8 @@ int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const f
 /*
  * Large-batch path of the 8-bit schemes (ABI 6): Y[B][out] = (X[B][in] @ W^T) * scales + bias for 1 or 2 codebooks of 256 x 8
  * (1x8 g8, 2x8 g8), W never materialised: the codebooks live in LDS, a block owns 16 output rows over all of K, every lane
- * builds its part of the 16 x 32 MFMA fragment from its code bytes (K-term sum rounded once to the storage type, as
- * aqlm_hip_dequant_kx8 does), X streams through LDS.  No workspace, one launch per 128 batch rows.
+ * takes its lanes of the 16 x 32 MFMA fragments straight from the codebook entries its code bytes name (one MFMA per codebook:
+ * exact products, fp32 sums -- W is never rounded), X streams through LDS.  No workspace, one launch per 128 batch rows.
  * Replaces: code2x8_matmat_dequant / code1x8_matmat_dequant = Code2x8Dequant / CodeKx8Dequant + F::linear(cuBLAS) + epilogue
  * (cuda_kernel.cpp:450-484, 615-649; kernels cuda_kernel.cu:235-294, 392-468).
  * AQLM_HIP_E_UNSUPPORTED (the caller dequantises + calls its GEMM, like the reference): other schemes, in_features not a
