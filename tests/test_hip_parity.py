@@ -392,6 +392,25 @@ def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
                     orc.dequantize_gemm(L3["x"], L3["codes"], L3["codebooks"], L3["scales"], L3["bias"]), torch.float16, "kx8 fall-through")
 
 
+def test_kx8_mfma_route_inside_hipgraph(hk):
+    """3+ row calls of the 8-bit ops (fused MFMA kernel behind aqlm_hip_gemv_kx8) and the large-batch op are captured and replayed
+    like every other entry: no allocation, no synchronisation, same result as the eager call."""
+    for K, rows, fin, fout in ((2, 4, 4096, 512), (1, 8, 1024, 300), (2, 40, 2048, 192)):
+        L = orc.make_layer(640 + rows, fin, fout, K, 8, 8, batch=rows, bias=True)
+        T = to_dev(L, torch.float16)
+        op = (torch.ops.aqlm.code2x8_matmat_dequant if K == 2 else torch.ops.aqlm.code1x8_matmat_dequant) if rows > 8 else \
+             (torch.ops.aqlm.code2x8_matmat if K == 2 else torch.ops.aqlm.code1x8_matmat)
+        s = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            yg = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"]))
+        check_close(yg.float().cpu().numpy(), orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"]), torch.float16,
+                    f"{K}x8 {rows} rows under hipGraph")
+
+
 # ------------------------------------------------------------------ module level: QuantizedLinear + autograd + graphs
 def _module_from(L, K, nbits, g, fin, fout, dtype):
     from aqlm import QuantizedLinear
