@@ -54,3 +54,49 @@ def test_fill_wait_counts_the_loads_behind_the_last_lds_dma(src, tmp_path):
     n, bad = check_asm(out.read_text())
     assert n >= 60, f"{src}: only {n} packed kernels found in the ISA"
     assert not bad, f"{src}: fill wait does not match the loads issued behind the LDS-DMA: {bad[:5]}"
+
+
+def dma_loops_with_full_drains(text, kernel_pattern):
+    """-> (loops found, [(kernel, label)] of LDS-DMA loops that contain an ``s_waitcnt vmcnt(0)``).
+
+    The producer waves of the MFMA kernels (gemm_mfma.hip) keep several steps of LDS-DMA in flight and wait with a COUNTED
+    ``s_waitcnt vmcnt(N)``, N > 0, once per step.  A ``vmcnt(0)`` inside such a loop (hipcc adds one when it believes an LDS read
+    may alias the DMA's destination) would drain the ring every step: correct results, a fraction of the speed -- exactly the kind
+    of regression no parity test can see.  Loops are taken from the compiler's own annotation ("Loop Header" on the label line)
+    up to the branch back to that label."""
+    loops, bad = 0, []
+    name, header, body = None, None, []
+    for line in text.split("\n"):
+        m = re.match(r"^(_ZN4aqlm\w+):", line)
+        if m:
+            name = m.group(1) if re.search(kernel_pattern, m.group(1)) else None
+            header, body = None, []
+            continue
+        if name is None:
+            continue
+        lm = re.match(r"^(\.LBB\d+_\d+):.*Loop Header", line)
+        if lm:
+            header, body = lm.group(1), []
+            continue
+        if header is None:
+            continue
+        body.append(line)
+        if re.search(r"s_cbranch_\w+\s+" + re.escape(header) + r"\b", line):
+            if any("global_load_lds" in x for x in body) and any("s_barrier" in x for x in body):
+                loops += 1
+                if any(re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", x) for x in body):
+                    bad.append((name, header))
+            header, body = None, []
+    return loops, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_mfma_kernels_dma_loops_never_drain_their_rings(tmp_path):
+    out = tmp_path / "gemm_mfma.s"
+    subprocess.run([HIPCC] + FLAGS + [os.path.join(ROOT, "aqlm_amd", "csrc", "gemm_mfma.hip"), "-o", str(out)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    text = out.read_text()
+    for pattern, least in (("gemm_1x16_rows16_kernel", 16), ("gemm_kx8_rows16_kernel", 16), ("gemm_1x16_glds_kernel", 8)):
+        loops, bad = dma_loops_with_full_drains(text, pattern)
+        assert loops >= least, f"{pattern}: only {loops} LDS-DMA loops found in the ISA"
+        assert not bad, f"{pattern}: vmcnt(0) inside an LDS-DMA loop: {bad[:5]}"
