@@ -1069,6 +1069,8 @@ def _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt):
         return None
     if codebooks.dtype != input.dtype or scales.dtype != input.dtype or (bias is not None and bias.dtype != input.dtype):
         return None
+    if not input.is_cuda or any(t is not None and t.device != input.device for t in (codes, codebooks, scales, bias)):
+        return None  # (the dequantise + GEMM route raises torch's own device-mismatch error)
     x = _flat_rows(input)
     B = x.shape[0]
     out_features = codes.shape[0]
