@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQLM_AMD_HIP_LIB: another build of the same library (same-box A/B runs of two commits, tools/gpu/r3_ab*.sh); default: in-tree
 LIB_PATH = os.environ.get("AQLM_AMD_HIP_LIB") or os.path.join(_HERE, "libaqlm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
@@ -37,28 +37,46 @@ class Segment(ctypes.Structure):
 _segp = ctypes.POINTER(Segment)
 
 
+PACKED_RELABELLED, PACKED_VARGEOM, PACKED_HAS_CODEBOOK = 1, 2, 4   # aqlm_hip_packed_desc.flags
+PREPACK_NO_RELABEL, PREPACK_UNIFORM_ONLY = 1, 2                   # aqlm_hip_prepack_1x16_ex flags
+
+
 class PackedDesc(ctypes.Structure):
     """aqlm_hip_packed_desc (include/aqlm_hip.h): what the kernels need to know about a prepacked 1x16 buffer."""
 
     _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint32), ("out_features", ctypes.c_int32),
                 ("in_features", ctypes.c_int32), ("slices_log2", ctypes.c_int32), ("waves", ctypes.c_int32),
                 ("steps", ctypes.c_int32), ("entry_bytes", ctypes.c_int32), ("used_bytes", ctypes.c_uint64),
-                ("x_copies", ctypes.c_uint32), ("codebook_absmax", ctypes.c_float)]
+                ("x_copies", ctypes.c_uint32), ("codebook_absmax", ctypes.c_float), ("flags", ctypes.c_uint32),
+                ("rows_per_group", ctypes.c_int32), ("slice_groups", ctypes.c_uint8 * 32)]
 
     def as_ints(self):
-        """The descriptor as a list of ints (what the registered torch op takes); the float travels as its bit pattern."""
+        """The descriptor as a list of ints (what the registered torch op takes); the float travels as its bit pattern, the 32
+        row-group counts as four 64-bit words."""
         import struct
 
+        groups = bytes(self.slice_groups)
         return [int(self.magic), int(self.version), int(self.out_features), int(self.in_features),
                 int(self.slices_log2), int(self.waves), int(self.steps), int(self.entry_bytes), int(self.used_bytes),
-                int(self.x_copies), struct.unpack("<I", struct.pack("<f", float(self.codebook_absmax)))[0]]
+                int(self.x_copies), struct.unpack("<I", struct.pack("<f", float(self.codebook_absmax)))[0],
+                int(self.flags), int(self.rows_per_group)] + [int.from_bytes(groups[8 * i:8 * i + 8], "little", signed=True) for i in range(4)]
 
     @classmethod
     def from_ints(cls, v):
         import struct
 
         absmax = struct.unpack("<f", struct.pack("<I", int(v[10]) & 0xFFFFFFFF))[0] if len(v) > 10 else 0.0
-        return cls(*[int(x) for x in v[:10]], absmax)
+        groups = b"".join(int(x).to_bytes(8, "little", signed=True) for x in v[13:17]) if len(v) >= 17 else bytes(32)
+        return cls(*[int(x) for x in v[:10]], absmax, int(v[11]) if len(v) > 11 else 0, int(v[12]) if len(v) > 12 else 0,
+                   (ctypes.c_uint8 * 32)(*groups))
+
+    @property
+    def relabelled(self) -> bool:
+        return bool(self.flags & PACKED_RELABELLED)
+
+    @property
+    def variable_geometry(self) -> bool:
+        return bool(self.flags & PACKED_VARGEOM)
 
 
 _descp = ctypes.POINTER(PackedDesc)
@@ -86,6 +104,10 @@ SIGNATURES = {
     "aqlm_hip_gemv_kx8": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_prepack_1x16_bytes": (_sz, [_ci, _ci, _ci]),
     "aqlm_hip_prepack_1x16": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _descp, _vp]),
+    "aqlm_hip_prepack_1x16_ex": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _descp, _ci, _vp]),
+    "aqlm_hip_packed_set_codebook": (_ci, [_descp, _vp, _vp, _vp]),
+    "aqlm_hip_packed_plan_relabel": (_ci, [_vp, _ci, _vp]),
+    "aqlm_hip_packed_plan_geometry": (_ci, [_vp, _ci, _ci, _ci, _vp]),
     "aqlm_hip_packed_desc_read": (_ci, [_vp, _sz, _descp]),
     "aqlm_hip_unpack_1x16": (_ci, [_descp, _vp, _vp, _vp]),
     "aqlm_hip_gemv_1x16_packed": (_ci, [_descp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),

@@ -1,4 +1,4 @@
-// 1x16 g8 matvec (1..8 input rows) on slice-bucketed ("prepacked") codes, gfx950.  Packed format v6.
+// 1x16 g8 matvec (1..8 input rows) on slice-bucketed ("prepacked") codes, gfx950.  Packed format v7.
 //
 // Why a load-time repack: on MI355X a random 16-B codebook gather that hits L2 costs a whole 128-B line of the CU's
 // L1-fill path (0.43 lane-gathers/clk/CU measured, profiles/r01_call1_mb_l2gather.log), which pins the direct kernel
@@ -7,6 +7,14 @@
 // Bucketing the codes by slice ONCE, when the layer is loaded, removes that search.  (The reference also re-lays codes
 // out at load time for its CPU kernel, inference.py:78-83.)
 //
+// Format v7 = format v6 + balancing at pack time (round 5; the reference's kernels are data-oblivious -- one warp per
+// output row, cuda_kernel.cu:16-27 -- while a slice-bucketed kernel is only as fast as its fullest slice):
+//   * relabelling: the 65536 codebook entries are dealt to the slices by how often the layer uses them (LPT greedy), so the
+//     slices carry equal numbers of codes whatever the checkpoint's labelling; the permutation (unpack stays bit-exact) and a
+//     permuted image of the codebook (what the kernels read) live behind the entries.  Evenly used codebooks keep their labels.
+//   * variable geometry (16-B vectors): an entry used by more than 1/16 of the codes cannot be balanced by labels; the 256
+//     workgroups are then dealt to the slices in proportion to their work: slice s gets n_s row groups of M / n_s rows
+//     (stream index = slice-major; block -> stream keeps an XCD on 32 consecutive streams, i.e. on 2-3 slices).
 // Format v6 (built by aqlm_hip_prepack_1x16; specification + simulation: tests/packed_model.py):
 //   rows -> NG = 16 row-groups of RG rows; codes -> S = 16 slices by (code >> 12); workgroup (g, s) owns stream (g, s).
 //   In a stream every row's codes of the slice are rounded up to whole LANE-STEPS of 4 entries (>= 1; null entries pad)
@@ -44,6 +52,7 @@
 // command processor preloads them into SGPRs (-amdgpu-kernarg-preload-count), so no kernel-argument fetch precedes the
 // first load.
 #include <algorithm>
+#include <vector>
 
 #include "aqlm_common.h"
 
@@ -59,6 +68,10 @@
 #define PK_NS pk_g16
 #define aqlm_hip_prepack_1x16_bytes aqlm_hip_g16_prepack_1x16_bytes
 #define aqlm_hip_prepack_1x16 aqlm_hip_g16_prepack_1x16
+#define aqlm_hip_prepack_1x16_ex aqlm_hip_g16_prepack_1x16_ex
+#define aqlm_hip_packed_set_codebook aqlm_hip_g16_packed_set_codebook
+#define aqlm_hip_packed_plan_relabel aqlm_hip_g16_packed_plan_relabel
+#define aqlm_hip_packed_plan_geometry aqlm_hip_g16_packed_plan_geometry
 #define aqlm_hip_packed_desc_read aqlm_hip_g16_packed_desc_read
 #define aqlm_hip_unpack_1x16 aqlm_hip_g16_unpack_1x16
 #define aqlm_hip_gemv_1x16_packed_cells aqlm_hip_g16_gemv_1x16_packed_cells
@@ -107,8 +120,10 @@ constexpr uint32_t PK_SLICE_BYTES = PK_SLICE_ENTRIES * PK_VB;
 constexpr int PK_MAX_NW = 16;
 constexpr int PK_MAX_T = 1024;
 constexpr int PK_MAX_GROUPS = (int)(65536u / PK_VB) - 2;  // the x offset of a group is a 16-bit byte offset; in_groups itself is the null slot
-constexpr uint32_t PK_MAGIC = 0x36505141u;   // "AQP6"
-constexpr int PK_VERSION = 6;
+constexpr uint32_t PK_MAGIC = 0x37505141u;   // "AQP7"
+constexpr int PK_VERSION = 7;
+constexpr int PK_MIN_GROUPS = PK_NG / 2;     // variable geometry: workgroups of a slice (its rows per group stay <= 2 x the uniform count)
+constexpr int PK_VG_MIN_ROWS = 512;          // ... and only layers of at least this many rows (every group owns >= 1 row)
 constexpr uint32_t PK_XWIN_FULL = 65520;     // x window of the batch-1 kernel (x first, slice behind it)
 // accumulator cell of the fused finalize: [arrivals : CNT bits][non-finite contributions : CNT bits][fixed-point sum]
 constexpr int PK_CNT_BITS = PK_S_LOG + 1;                       // counts 0 .. PK_S
@@ -133,9 +148,91 @@ __host__ __device__ static inline uint32_t pk_get_start_row(uint32_t e0, uint32_
 constexpr int PK_STEP3 = 768;   // bytes of one wave step of 3-byte entries (64 lanes x 12 B)
 constexpr int PK_WREG3 = 776;   // ... per step incl. its 8-B row-end flag word (flag words lead the wave range)
 
+// Stream geometry: which slice and which rows workgroup / stream `st` owns.
+//   uniform (vg == 0, formats <= v6): PK_NG row groups of RG rows for every slice, stream = group * PK_S + slice;
+//   variable (vg == 1): slice s has n[s] row groups, the rows are split evenly over them (the first M % n[s] groups hold one
+//   row more), streams are numbered slice by slice: stream = first[s] + group.
+struct PkGeom {
+  int M;
+  int vg;
+  int RG;                    // most rows of any stream: the row-start tables have RG + 1 entries per stream, the LDS row tables RG + 1
+  uint16_t first[PK_S + 1];  // first stream of slice s (vg)
+  uint8_t n[PK_S];           // row groups (= workgroups) of slice s
+};
+
+__host__ __device__ static inline void pk_group_rows(const PkGeom& G, int s, int k, int& row0, int& nrows) {
+  if (!G.vg) {
+    row0 = k * G.RG;
+    const int n = G.M - row0;
+    nrows = n < 0 ? 0 : (n < G.RG ? n : G.RG);
+    return;
+  }
+  const int n = G.n[s], base = G.M / n, extra = G.M - base * n;
+  row0 = k * base + (k < extra ? k : extra);
+  nrows = base + (k < extra ? 1 : 0);
+}
+__host__ __device__ static inline void pk_stream_slice(const PkGeom& G, int st, int& s, int& k) {
+  if (!G.vg) {
+    s = st & (PK_S - 1);
+    k = st >> PK_S_LOG;
+    return;
+  }
+  s = 0;
+  while (s + 1 < PK_S && (int)G.first[s + 1] <= st) ++s;
+  k = st - (int)G.first[s];
+}
+__host__ __device__ static inline void pk_stream_rows(const PkGeom& G, int st, int& s, int& row0, int& nrows) {
+  int k;
+  pk_stream_slice(G, st, s, k);
+  pk_group_rows(G, s, k, row0, nrows);
+}
+// stream and row-in-stream of (slice, row)
+__host__ __device__ static inline void pk_row_stream(const PkGeom& G, int s, int row, int& st, int& r) {
+  if (!G.vg) {
+    const int k = row / G.RG;
+    r = row - k * G.RG;
+    st = k * PK_S + s;
+    return;
+  }
+  const int n = G.n[s], base = G.M / n, extra = G.M - base * n, thr = extra * (base + 1);
+  int k;
+  if (row < thr) {
+    k = row / (base + 1);
+    r = row - k * (base + 1);
+  } else {
+    k = extra + (row - thr) / base;
+    r = row - thr - (k - extra) * base;
+  }
+  st = (int)G.first[s] + k;
+}
+
+// geometry from the row groups per slice (nullptr: uniform); false if they do not describe PK_NST workgroups
+static bool pk_make_geom(int M, const uint8_t* groups, PkGeom& G) {
+  G.M = M;
+  G.vg = 0;
+  int sum = 0, mn = PK_NG;
+  for (int s = 0; s < PK_S; ++s) {
+    const int n = groups ? (int)groups[s] : PK_NG;
+    if (n < 1) return false;
+    G.n[s] = (uint8_t)n;
+    G.first[s] = (uint16_t)sum;
+    sum += n;
+    mn = n < mn ? n : mn;
+    if (n != PK_NG) G.vg = 1;
+  }
+  G.first[PK_S] = (uint16_t)sum;
+  if (sum != PK_NST) return false;
+  if (G.vg && (PK_G != 8 || M < PK_VG_MIN_ROWS)) return false;
+  G.RG = G.vg ? (M + mn - 1) / mn : (M + PK_NG - 1) / PK_NG;
+  return true;
+}
+
 struct PackedLayout {
   int M, in_groups, RG, NW, T, XC, EB;
   size_t nst, off_winfo, off_rowstart, off_acc, off_ent, ent_bytes, used;
+  PkGeom G;
+  bool relabel;            // permutation (u16 old_of_new[65536]) at off_perm, codebook image at off_cb
+  size_t off_perm, off_cb;
 };
 
 __host__ __device__ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -148,32 +245,39 @@ static bool packed_shape_ok(int out_features, int in_features, int g) {
          packed_max_batch(in_features / PK_G, (out_features + PK_NG - 1) / PK_NG) >= 1;  // slice + x + the row tables of a row group in 160 KiB
 }
 
-static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1, int EB = 4) {
+static bool packed_layout(int out_features, int in_features, int NW, int T, PackedLayout& L, int XC = 1, int EB = 4,
+                          const uint8_t* groups = nullptr, bool relabel = false) {
   if (!packed_shape_ok(out_features, in_features, PK_G) || NW < 1 || NW > PK_MAX_NW || T < 1 || T > PK_MAX_T) return false;
   if (XC < 1 || XC > pk_max_x_copies(in_features / PK_G) || (PK_G != 8 && XC != 1)) return false;
   if (EB != 4 && !(EB == 3 && T <= 32 && PK_G == 8)) return false;  // 3-byte entries: the row-end flags of a column are one 32-bit mask
+  if (!pk_make_geom(out_features, groups, L.G)) return false;
+  if (L.G.vg && (EB != 4 || L.G.RG > 32767 - PK_MAX_NW || packed_max_batch(in_features / PK_G, L.G.RG) < 1)) return false;
   L.XC = XC;
   L.EB = EB;
   L.M = out_features;
   L.in_groups = in_features / PK_G;
-  L.RG = (out_features + PK_NG - 1) / PK_NG;
+  L.RG = L.G.RG;
   L.NW = NW;
   L.T = T;
-  L.nst = (size_t)PK_NG * PK_S;
+  L.nst = (size_t)PK_NST;
   L.off_winfo = 256;
   L.off_rowstart = align_up(L.off_winfo + L.nst * PK_MAX_NW * 16, 256);         // [nst][RG + 1] u32 (offset independent of NW)
   // accumulator cells of the fused finalize: [AQLM_HIP_MAX_GEMV_BATCH][M] u64, zero at rest (offset independent of NW, T)
   L.off_acc = align_up(L.off_rowstart + L.nst * (size_t)(L.RG + 1) * 4, 256);
   L.off_ent = align_up(L.off_acc + (size_t)AQLM_HIP_MAX_GEMV_BATCH * out_features * 8, 1024);
   L.ent_bytes = L.nst * NW * T * (EB == 3 ? (size_t)PK_WREG3 : (size_t)1024);
-  L.used = L.off_ent + L.ent_bytes;
+  L.relabel = relabel;
+  L.off_perm = align_up(L.off_ent + L.ent_bytes, 1024);
+  L.off_cb = L.off_perm + (size_t)65536 * 2;
+  L.used = relabel ? L.off_cb + (size_t)65536 * PK_VB : L.off_ent + L.ent_bytes;
   return L.ent_bytes < ((size_t)1 << 32);  // 32-bit buffer offsets
 }
 
 static bool desc_layout(const aqlm_hip_packed_desc* d, PackedLayout& L) {
   return d && d->magic == PK_MAGIC && d->version == PK_VERSION && d->slices_log2 == PK_S_LOG &&
-         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L, (int)d->x_copies, d->entry_bytes) &&
-         L.used == d->used_bytes;
+         packed_layout(d->out_features, d->in_features, d->waves, d->steps, L, (int)d->x_copies, d->entry_bytes, d->slice_groups,
+                       (d->flags & AQLM_HIP_PACKED_RELABELLED) != 0) &&
+         L.used == d->used_bytes && d->rows_per_group == L.RG && ((d->flags & AQLM_HIP_PACKED_VARGEOM) != 0) == (L.G.vg != 0);
 }
 
 // Wave-steps of work in the longest stream -> waves per workgroup.
@@ -203,8 +307,15 @@ static int choose_waves(uint32_t max_lane_steps) {
 }
 
 // ------------------------------------------------------------------------------------------------ prepack
-// K1: lane-steps per (row, slice) -> a[st][r].  One wave per row.
-__global__ __launch_bounds__(256) void pk_count_kernel(const uint16_t* codes, uint32_t* a, int M, int in_groups, int RG) {
+// K0: how often every codebook entry is used (the relabelling plan is made from it on the host).
+__global__ __launch_bounds__(256) void pk_hist_kernel(const uint16_t* codes, size_t n, uint32_t* hist) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) atomicAdd(&hist[codes[i]], 1u);
+}
+
+// K1: lane-steps per (slice, row) -> ls[s][row] (u16), and their totals per slice.  One wave per row.  `relabel` (nullable):
+// new label of every checkpoint label.
+__global__ __launch_bounds__(256) void pk_count_kernel(const uint16_t* codes, const uint16_t* relabel, uint16_t* ls, uint32_t* slice_steps,
+                                                       int M, int in_groups) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -212,30 +323,40 @@ __global__ __launch_bounds__(256) void pk_count_kernel(const uint16_t* codes, ui
 #pragma unroll
   for (int s = 0; s < PK_S; ++s) cnt[s] = 0;
   for (int j = lane; j < in_groups; j += 64) {
-    const uint32_t sl = codes[(size_t)row * in_groups + j] >> PK_CODE_BITS;
+    uint32_t code = codes[(size_t)row * in_groups + j];
+    if (relabel) code = relabel[code];
+    const uint32_t sl = code >> PK_CODE_BITS;
 #pragma unroll
     for (int s = 0; s < PK_S; ++s) cnt[s] += (sl == (uint32_t)s);
   }
-  const int g = row / RG, r = row - g * RG;
 #pragma unroll
   for (int s = 0; s < PK_S; ++s) {
     uint32_t v = cnt[s];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    if (lane == 0) a[((size_t)g * PK_S + s) * (RG + 1) + r] = v == 0 ? 1u : (v + 3u) >> 2;
+    if (lane == 0) {
+      const uint32_t steps = v == 0 ? 1u : (v + 3u) >> 2;
+      ls[(size_t)s * M + row] = (uint16_t)steps;
+      atomicAdd(&slice_steps[s], steps);
+    }
   }
 }
 
-// K2: per stream, in-place exclusive prefix sum over a[st][0..RG]; a[st][RG] = total; maxL = max total.
-__global__ __launch_bounds__(256) void pk_scan_kernel(uint32_t* a, uint32_t* maxL, int RG) {
+// K2: per stream, exclusive prefix sum of its rows' lane-steps -> a[st][0..RG] (entries past the stream's rows = its total);
+// maxL = longest stream.
+__global__ __launch_bounds__(256) void pk_scan_kernel(const uint16_t* ls, uint32_t* a, uint32_t* maxL, const PkGeom G) {
   __shared__ uint32_t sums[256];
-  uint32_t* row = a + (size_t)blockIdx.x * (RG + 1);
+  const int st = blockIdx.x;
+  int sl, row0, nrows;
+  pk_stream_rows(G, st, sl, row0, nrows);
+  const uint16_t* src = ls + (size_t)sl * G.M + row0;
+  uint32_t* row = a + (size_t)st * (G.RG + 1);
   const int t = threadIdx.x;
-  const int n = RG + 1;
+  const int n = G.RG + 1;
   const int chunk = (n + 255) / 256;
   const int lo = std::min(n, t * chunk), hi = std::min(n, lo + chunk);
   uint32_t s = 0;
-  for (int i = lo; i < hi; ++i) s += row[i];
+  for (int i = lo; i < hi; ++i) s += i < nrows ? (uint32_t)src[i] : 0u;
   sums[t] = s;
   __syncthreads();
   if (t == 0) {
@@ -250,9 +371,8 @@ __global__ __launch_bounds__(256) void pk_scan_kernel(uint32_t* a, uint32_t* max
   __syncthreads();
   uint32_t run = sums[t];
   for (int i = lo; i < hi; ++i) {
-    const uint32_t v = row[i];
     row[i] = run;
-    run += v;
+    run += i < nrows ? (uint32_t)src[i] : 0u;
   }
 }
 
@@ -267,29 +387,30 @@ __device__ __forceinline__ size_t pk_entry_index(uint32_t q, int k, size_t st, i
 }
 
 // K3: scatter the entries, ascending j inside every (row, slice).  One wave per row.
-__global__ __launch_bounds__(256) void pk_scatter_kernel(const uint16_t* codes, const uint32_t* a, uint32_t* ent, int M,
-                                                         int in_groups, int RG, int NW, int T) {
+__global__ __launch_bounds__(256) void pk_scatter_kernel(const uint16_t* codes, const uint16_t* relabel, const uint32_t* a, uint32_t* ent,
+                                                         const PkGeom G, int in_groups, int NW, int T) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int g = row / RG, r = row - g * RG;
+  if (row >= G.M) return;
   uint32_t cnt[PK_S];  // entries of this row already placed, per slice
 #pragma unroll
   for (int s = 0; s < PK_S; ++s) cnt[s] = 0;
   for (int j0 = 0; j0 < in_groups; j0 += 64) {
     const int j = j0 + lane;
     const bool ok = j < in_groups;
-    const uint32_t code = ok ? codes[(size_t)row * in_groups + j] : 0u;
+    uint32_t code = ok ? codes[(size_t)row * in_groups + j] : 0u;
+    if (relabel) code = relabel[code];
     const uint32_t sl = ok ? (code >> PK_CODE_BITS) : 0xffffffffu;
 #pragma unroll
     for (int s = 0; s < PK_S; ++s) {
       const bool mine = sl == (uint32_t)s;
       const unsigned long long m = __ballot(mine);
       if (mine) {
-        const size_t st = (size_t)g * PK_S + s;
+        int st, r;
+        pk_row_stream(G, s, row, st, r);
         const uint32_t i = cnt[s] + __popcll(m & ((1ull << lane) - 1ull));
-        const uint32_t q = a[st * (RG + 1) + r] + (i >> 2);
-        ent[pk_entry_index(q, i & 3, st, NW, T)] = ((uint32_t)j << (16 + PK_VSH)) | ((code & (PK_SLICE_ENTRIES - 1)) << PK_VSH);
+        const uint32_t q = a[(size_t)st * (G.RG + 1) + r] + (i >> 2);
+        ent[pk_entry_index(q, i & 3, (size_t)st, NW, T)] = ((uint32_t)j << (16 + PK_VSH)) | ((code & (PK_SLICE_ENTRIES - 1)) << PK_VSH);
       }
       cnt[s] += __popcll(m);
     }
@@ -327,7 +448,7 @@ __device__ __forceinline__ int pk_group_lane(int grp, int pos) {  // inverse of 
   return half * 32 + h;
 }
 
-__global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint32_t* ent, int M, int in_groups, int RG, int NW,
+__global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint32_t* ent, const PkGeom G, int in_groups, int NW,
                                                         int T, int XC) {
   extern __shared__ uint32_t arr_sm[];
   uint32_t* pool = arr_sm;                                                   // [64 * T * 4] entries in (lane, t, k) order
@@ -335,9 +456,9 @@ __global__ __launch_bounds__(64) void pk_arrange_kernel(const uint32_t* a, uint3
   uint16_t* rem = rowa + (size_t)T * 64;                                    // [64 * T] entries left in the pool of the row starting at that lane-step
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
-  const int g = (int)(st / PK_S);
-  const int nrows = std::min(RG, std::max(0, M - g * RG));
-  const uint32_t* starts = a + st * (RG + 1);
+  int sl_, row0_, nrows;
+  pk_stream_rows(G, (int)st, sl_, row0_, nrows);
+  const uint32_t* starts = a + st * (G.RG + 1);
   const uint32_t total = starts[nrows];
   uint32_t* wave_ent = ent + (((size_t)st * NW + w) * T) * 256;             // + (t * 64 + lane) * 4 + k
   const uint32_t w0 = (uint32_t)w * 64u * (uint32_t)T;
@@ -476,7 +597,7 @@ __device__ __forceinline__ int pk_lane_group(int lane) {  // LDS service group o
   return (lane >> 5) * 2 + g1;
 }
 
-__global__ __launch_bounds__(64) void pk_improve_kernel(const uint32_t* a, uint32_t* ent, int M, int in_groups, int RG, int NW,
+__global__ __launch_bounds__(64) void pk_improve_kernel(const uint32_t* a, uint32_t* ent, const PkGeom G, int in_groups, int NW,
                                                         int T) {
   extern __shared__ uint32_t arr_sm[];
   uint32_t* e = arr_sm;                                                       // [64 * T * 4] entries in (lane, t, k) order: a row's pool is contiguous
@@ -487,9 +608,9 @@ __global__ __launch_bounds__(64) void pk_improve_kernel(const uint32_t* a, uint3
   uint8_t* nulls = reinterpret_cast<uint8_t*>(rowb + (size_t)T * 64);        // [4 T][4][2] null entries per cell and lane parity
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
-  const int g = (int)(st / PK_S);
-  const int nrows = std::min(RG, std::max(0, M - g * RG));
-  const uint32_t* starts = a + st * (RG + 1);
+  int sl_, row0_, nrows;
+  pk_stream_rows(G, (int)st, sl_, row0_, nrows);
+  const uint32_t* starts = a + st * (G.RG + 1);
   const uint32_t total = starts[nrows];
   uint32_t* wave_ent = ent + (((size_t)st * NW + w) * T) * 256;
   const uint32_t w0 = (uint32_t)w * 64u * (uint32_t)T;
@@ -618,24 +739,24 @@ __global__ __launch_bounds__(64) void pk_improve_kernel(const uint32_t* a, uint3
 }
 
 // K4: bookkeeping bits.  Thread (st, r): flag on the row's last lane-step.
-__global__ __launch_bounds__(256) void pk_flag_kernel(const uint32_t* a, uint32_t* ent, int M, int RG, int NW, int T) {
+__global__ __launch_bounds__(256) void pk_flag_kernel(const uint32_t* a, uint32_t* ent, const PkGeom G, int NW, int T) {
   const size_t st = blockIdx.y;
   const int r = blockIdx.x * 256 + threadIdx.x;
-  const int g = (int)(st / PK_S);
-  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  int sl_, row0_, nrows;
+  pk_stream_rows(G, (int)st, sl_, row0_, nrows);
   if (r >= nrows) return;
-  const uint32_t ql = a[st * (RG + 1) + r + 1] - 1;
+  const uint32_t ql = a[st * (G.RG + 1) + r + 1] - 1;
   atomicOr(&ent[pk_entry_index(ql, 0, st, NW, T)], 1u);
 }
 
 // K5: per lane column its starting row (in the spare bits of the column's first lane-step), per wave winfo.
-__global__ __launch_bounds__(64) void pk_column_kernel(const uint32_t* a, uint32_t* ent, uint32_t* winfo, int M, int RG,
+__global__ __launch_bounds__(64) void pk_column_kernel(const uint32_t* a, uint32_t* ent, uint32_t* winfo, const PkGeom G,
                                                        int NW, int T) {
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
-  const int g = (int)(st / PK_S);
-  const int nrows = std::min(RG, std::max(0, M - g * RG));
-  const uint32_t* starts = a + st * (RG + 1);  // starts[r], r < nrows; starts[nrows] == total (rows past M have 0 steps)
+  int sl_, row0_, nrows;
+  pk_stream_rows(G, (int)st, sl_, row0_, nrows);
+  const uint32_t* starts = a + st * (G.RG + 1);  // starts[r], r < nrows; starts[nrows] == total (rows past the stream's have 0 steps)
   const uint32_t total = starts[nrows];
   const uint32_t w0 = (uint32_t)w * 64u * T;
   if (l == 0) {
@@ -689,12 +810,12 @@ __device__ __forceinline__ void pk_unpack3(uint32_t w0, uint32_t w1, uint32_t w2
   e[3] = w2 >> 8;
 }
 
-__global__ __launch_bounds__(64) void pk_compress_kernel(const uint32_t* ent4, uint8_t* ent3, uint32_t* winfo, int M, int RG,
+__global__ __launch_bounds__(64) void pk_compress_kernel(const uint32_t* ent4, uint8_t* ent3, uint32_t* winfo, const PkGeom G,
                                                          int NW, int T) {
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
-  const int g = (int)(st / PK_S);
-  const int nrows = std::min(RG, std::max(0, M - g * RG));
+  int sl_, row0_, nrows;
+  pk_stream_rows(G, (int)st, sl_, row0_, nrows);
   const uint32_t* src = ent4 + (((size_t)st * NW + w) * T) * 256;
   uint8_t* dst = ent3 + ((size_t)st * NW + w) * T * PK_WREG3;
   uint32_t* wi = winfo + (st * NW + w) * 4;
@@ -710,12 +831,13 @@ __global__ __launch_bounds__(64) void pk_compress_kernel(const uint32_t* ent4, u
   }
 }
 
-__global__ __launch_bounds__(64) void pk_unpack3_kernel(const uint8_t* ent3, const uint32_t* winfo, uint16_t* codes, int M,
-                                                        int in_groups, int RG, int NW, int T) {
+__global__ __launch_bounds__(64) void pk_unpack3_kernel(const uint8_t* ent3, const uint32_t* winfo, const uint16_t* old_of_new,
+                                                        uint16_t* codes, const PkGeom G, int in_groups, int NW, int T) {
   const int xstride = pk_x_stride(in_groups);
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
-  const int g = (int)(st / PK_S), s = (int)(st % PK_S);
+  int s, row0, nrows;
+  pk_stream_rows(G, (int)st, s, row0, nrows);
   const uint32_t* wi = winfo + (st * NW + w) * 4;
   const int steps = (int)wi[2];
   const uint8_t* base = ent3 + ((size_t)st * NW + w) * T * PK_WREG3;
@@ -733,7 +855,10 @@ __global__ __launch_bounds__(64) void pk_unpack3_kernel(const uint8_t* ent3, con
     for (int k = 0; k < 4; ++k) {
       const int slot = (int)(e[k] >> 12);
       const int j = slot % xstride;
-      if (j < in_groups && g * RG + row < M) codes[(size_t)(g * RG + row) * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | (e[k] & 0xfffu));
+      if (j < in_groups && row < nrows) {
+        const uint32_t c = ((uint32_t)s << PK_CODE_BITS) | (e[k] & 0xfffu);
+        codes[(size_t)(row0 + row) * in_groups + j] = old_of_new ? old_of_new[c] : (uint16_t)c;
+      }
     }
     const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(base + (size_t)t * 8);
     row += (int)((fl >> l) & 1ull);
@@ -742,12 +867,13 @@ __global__ __launch_bounds__(64) void pk_unpack3_kernel(const uint8_t* ent3, con
 
 // inverse of the repack: canonical codes [M][in_groups] from a packed buffer (lossless; used to drop / restore the
 // canonical codes of inference-only models and by the tests).  One wave per (stream, wave range).
-__global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, const uint32_t* winfo, uint16_t* codes, int M,
-                                                       int in_groups, int RG, int NW, int T) {
+__global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, const uint32_t* winfo, const uint16_t* old_of_new,
+                                                       uint16_t* codes, const PkGeom G, int in_groups, int NW, int T) {
   const int xstride = pk_x_stride(in_groups);
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
-  const int g = (int)(st / PK_S), s = (int)(st % PK_S);
+  int s, row0, nrows;
+  pk_stream_rows(G, (int)st, s, row0, nrows);
   const uint32_t* wi = winfo + (st * NW + w) * 4;
   const int steps = (int)wi[2];
   const uint32_t* col = ent + (((size_t)st * NW + w) * T * 64 + l) * 4;
@@ -756,12 +882,14 @@ __global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, cons
     const uint32_t* e = col + (size_t)t * 256;
     const uint32_t e0 = e[0];
     if (t == 0) local = (int)pk_get_start_row(e0, e[1], e[2], e[3]);
-    const int row = g * RG + local;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t v = e[k];
       const int j = (int)(v >> (16 + PK_VSH)) - (int)((v >> 16) & 3u) * xstride;
-      if (j < in_groups && row < M) codes[(size_t)row * in_groups + j] = (uint16_t)((s << PK_CODE_BITS) | ((v >> PK_VSH) & (uint32_t)(PK_SLICE_ENTRIES - 1)));
+      if (j < in_groups && local < nrows) {
+        const uint32_t c = ((uint32_t)s << PK_CODE_BITS) | ((v >> PK_VSH) & (uint32_t)(PK_SLICE_ENTRIES - 1));
+        codes[(size_t)(row0 + local) * in_groups + j] = old_of_new ? old_of_new[c] : (uint16_t)c;
+      }
     }
     local += (int)(e0 & 1u);
   }
@@ -880,8 +1008,16 @@ struct PackedLds {
 // PUB: the row-parallel shard's variant (the last arrival publishes the fp32 total for the peers instead of writing y).  A
 // template parameter, not a run-time test of p.pub: carrying the publish branches in the ordinary kernel cost 0.15 us per
 // launch (same box, profiles/r03_mb_ab_commits.log).
-template <class T_, int B, int PD, uint32_t XWIN, int EB, bool PUB = false>
-__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block, const int NWB) {
+// VG: variable geometry (format v7): `ns` = the first stream of each of the 16 slices, one byte each; the workgroup finds its
+// slice, row range and stream from them with a handful of instructions (no table in memory: a dependent load in front of the
+// slice fill would cost more than the imbalance it repairs).
+struct PackedVgArgs {
+  uint32_t ns[4];
+};
+
+template <class T_, int B, int PD, uint32_t XWIN, int EB, bool PUB = false, bool VG = false>
+__device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p, const int block, const int NWB,
+                                                      const PackedVgArgs& vg = PackedVgArgs{}) {
   using LDS = PackedLds<B, XWIN>;
   using ring_t = typename std::conditional<EB == 3, u32x3, u32x4>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -899,11 +1035,35 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
 #endif
   // slice = block % 16: blocks are observed to land on XCD block % 8, so each XCD's L2 serves two 64 KiB slices
   // (speed only; any placement is correct).
-  const int slice = block & (PK_S - 1);
-  const int group = block >> PK_S_LOG;
-  const int row_begin = group * p.RG;
-  int nrows = p.M - row_begin;
-  nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
+  int slice, group, row_begin, nrows, stream_ix;
+  if constexpr (VG) {
+    static_assert(PK_S == 16 && PK_NST == 256, "variable geometry: 16 slices, 256 workgroups");
+    // workgroups land on XCD block % 8: XCD x serves streams [32 x, 32 x + 32) -- consecutive streams share their slice
+    stream_ix = ((block & 7) << 5) | (block >> 3);
+    // ns = the first stream of slices 0..15, one byte each (slice 0 starts at 0, the last slice ends at 256).  Lane i < 16
+    // looks at slice i: the slices that start at or before this stream answer the ballot, the last of them owns it.
+    // (A scalar walk over the 16 bytes was ~280 dependent instructions in front of the first load: 0.5 us.)
+    const uint32_t w = lane < 4 ? vg.ns[0] : (lane < 8 ? vg.ns[1] : (lane < 12 ? vg.ns[2] : vg.ns[3]));
+    const uint32_t start_v = (w >> ((lane & 3) * 8)) & 255u;
+    const unsigned long long m = __ballot((uint32_t)stream_ix >= start_v) & 0xffffull;
+    const int s = __popcll(m) - 1;
+    const int start = __builtin_amdgcn_readlane((int)start_v, s);
+    const int end = s == PK_S - 1 ? PK_NST : __builtin_amdgcn_readlane((int)start_v, s < PK_S - 1 ? s + 1 : s);
+    int n = end - start;
+    n = n < 1 ? 1 : n;
+    slice = s;
+    group = stream_ix - start;
+    const int base = p.M / n, extra = p.M - base * n;
+    row_begin = group * base + (group < extra ? group : extra);
+    nrows = base + (group < extra ? 1 : 0);
+  } else {
+    stream_ix = block;
+    slice = block & (PK_S - 1);
+    group = block >> PK_S_LOG;
+    row_begin = group * p.RG;
+    nrows = p.M - row_begin;
+    nrows = nrows < 0 ? 0 : (nrows < p.RG ? nrows : p.RG);
+  }
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();  // LDS map above
 
   const int RG1 = p.RG + 1;
@@ -916,7 +1076,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   const uint32_t xstride16 = (uint32_t)pk_x_stride(p.in_groups) * PK_VB;
   __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc((void*)p.ent, 0, p.ent_bytes, 0x00020000);
   const int wv = wave < p.NW ? wave : p.NW - 1;  // waves beyond the stream's wave count (shared-input launches) idle
-  const uint32_t wbase = (uint32_t)(((size_t)block * p.NW + wv) * p.T) * (EB == 3 ? (uint32_t)PK_WREG3 : 1024u);
+  const uint32_t wbase = (uint32_t)(((size_t)stream_ix * p.NW + wv) * p.T) * (EB == 3 ? (uint32_t)PK_WREG3 : 1024u);
   const int Tm1 = p.T - 1;
   // (0) 3-byte entries: the row-end flag words of this wave range, word t in lane t -- the OLDEST load of the queue, so
   // it has landed whenever the wait of (5) returns
@@ -945,7 +1105,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     // rotated start: the PK_NG workgroups that fill the same slice from the same L2 walk it from different pieces, so at
     // any moment they ask different L2 channels (and, cold, each pulls a different part from HBM first)
     constexpr int PIECES = (int)(PK_SLICE_BYTES / 1024);
-    const int rot = p.fill_rotate ? group * (PIECES / PK_NG) : 0;
+    const int rot = p.fill_rotate ? (group & (PK_NG - 1)) * (PIECES / PK_NG) : 0;
     for (int i0 = wave; i0 < PIECES; i0 += NWD) {
       const int i = (i0 + rot) & (PIECES - 1);
       __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + i * 1024 + lane * 16),
@@ -965,7 +1125,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
     }
     // the stream's row starts (needed by the epilogue only; as an LDS-DMA they are older than the ring loads, see (5)).
     // Rows of the table are only 4-B aligned -> dword DMA, 256 B per wave-instruction.
-    const uint32_t* rs_src = p.rowstart + (size_t)block * RG1;
+    const uint32_t* rs_src = p.rowstart + (size_t)stream_ix * RG1;
     for (int i = wave; i * 64 < RG1; i += NWD) {
       const int idx = i * 64 + lane;
       if (idx < RG1)
@@ -994,7 +1154,7 @@ __device__ __forceinline__ void gemv_1x16_packed_body(const PackedGemvParams& p,
   int steps = wave < p.NW ? p.T : 0;
   [[maybe_unused]] uint32_t wave_start_row = 0u;
   if constexpr (EB == 3) {
-    const const_u32_ptr wi = (const_u32_ptr)(uintptr_t)(p.winfo + ((size_t)block * p.NW + wv) * 4);
+    const const_u32_ptr wi = (const_u32_ptr)(uintptr_t)(p.winfo + ((size_t)stream_ix * p.NW + wv) * 4);
     steps = wave < p.NW ? (int)wi[2] : 0;
     wave_start_row = wi[3];
   }
@@ -1401,6 +1561,56 @@ __global__ __launch_bounds__(1024) void gemv_1x16_packed_kernel(const uint8_t* c
 #endif
   gemv_1x16_packed_body<T_, B, PD, XWIN, EB, PUB>(p, blockIdx.x, NW + NPW);
 }
+
+#if AQLM_PK_G == 8
+// Variable-geometry twin (format v7, flag AQLM_HIP_PACKED_VARGEOM): same body; the 14 preloaded dwords now also carry the row
+// groups of the 16 slices, so three of the ordinary kernel's arguments travel compressed: the row-start table as its distance
+// in front of the entries, in_groups and the row-table size in one word, and the entry bytes are derived (4-byte entries only).
+template <class T_, int B, int PD, uint32_t XWIN>
+__global__ __launch_bounds__(1024) void gemv_1x16_packed_vg_kernel(const uint8_t* codebook, const uint16_t* x, const uint32_t* ent,
+                                                                   uint32_t rowstart_back, uint32_t ig_rg, uint32_t geom, int M,
+                                                                   uint32_t ns0, uint32_t ns1, uint32_t ns2, uint32_t ns3,
+                                                                   const PackedGemvRest rest) {
+  // geom: waves 0..7 | x copies 8..11 | rotated fill 15 | steps 16..31;  ig_rg: in_groups 0..11 | rows per group 12..27
+  const int NW = (int)(geom & 0xffu), XC = (int)((geom >> 8) & 0xfu), T = (int)(geom >> 16);
+  PackedGemvParams p;
+  p.NPW = 0;
+  p.fill_rotate = (int)((geom >> 15) & 1u);
+  p.next_ent = nullptr;
+  p.next_codebook = nullptr;
+  p.next_block_bytes = 0;
+  p.pub = nullptr;
+  p.pub_flag = nullptr;
+  p.pub_epoch = nullptr;
+  p.pub_max_elems = 0;
+  p.ent = ent;
+  p.winfo = rest.winfo;
+  p.rowstart = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ent) - rowstart_back);
+  p.codebook = codebook;
+  p.x = x;
+  p.partial = rest.partial;
+  p.acc = rest.acc;
+  p.cb_absmax = rest.cb_absmax;
+  p.scales = rest.scales;
+  p.bias = rest.bias;
+  p.y = rest.y;
+  p.y_row_stride = rest.y_row_stride;
+  p.x_row_stride = rest.x_row_stride;
+  p.M = M;
+  p.in_groups = (int)(ig_rg & 0xfffu);
+  p.RG = (int)(ig_rg >> 12);
+  p.NW = NW;
+  p.T = T;
+  p.XC = XC;
+  p.ent_bytes = (uint32_t)PK_NST * (uint32_t)NW * (uint32_t)T * 1024u;
+#ifdef AQLM_PACKED_TRACE
+  p.trace = rest.trace;
+  p.dbg = rest.dbg;
+#endif
+  const PackedVgArgs vg{{ns0, ns1, ns2, ns3}};
+  gemv_1x16_packed_body<T_, B, PD, XWIN, 4, false, true>(p, blockIdx.x, NW, vg);
+}
+#endif
 
 // Several prepacked layers that multiply the same x (q/k/v, gate/up) in one launch of 256 workgroups per layer; the
 // next layer's workgroups start as CUs free up, so one layer's tail and the next one's LDS fill overlap.
@@ -2103,6 +2313,10 @@ using namespace aqlm::PK_NS;
 extern "C" {
 size_t aqlm_hip_g16_prepack_1x16_bytes(int, int, int);
 int aqlm_hip_g16_prepack_1x16(const void*, int, int, int, void*, size_t, aqlm_hip_packed_desc*, void*);
+int aqlm_hip_g16_prepack_1x16_ex(const void*, int, int, int, void*, size_t, aqlm_hip_packed_desc*, int, void*);
+int aqlm_hip_g16_packed_set_codebook(aqlm_hip_packed_desc*, void*, const void*, void*);
+int aqlm_hip_g16_packed_plan_relabel(const uint32_t*, int, uint16_t*);
+int aqlm_hip_g16_packed_plan_geometry(const uint64_t*, int, int, int, uint8_t*);
 int aqlm_hip_g16_packed_desc_read(const void*, size_t, aqlm_hip_packed_desc*);
 int aqlm_hip_g16_unpack_1x16(const aqlm_hip_packed_desc*, const void*, void*, void*);
 int aqlm_hip_g16_gemv_1x16_packed_cells(const aqlm_hip_packed_desc*, const void*, const void*, const void*, const void*, const void*, void*, int,
@@ -2131,24 +2345,141 @@ static inline bool pk_is_g16(const aqlm_hip_packed_desc* d) { return d && d->sli
 #define PK_G16_FORWARD_IF(cond, call)
 #endif
 
+// ---- planning steps of the repack (host, pure functions) -----------------------------------------------------------------
+// Relabelling: deal the 65536 entries to the PK_S slices, heaviest first, each to the lightest slice that still has room
+// (longest-processing-time greedy with PK_SLICE_ENTRIES entries per slice): the slices end up with equal code counts unless a
+// single entry outweighs a slice's share.  Deterministic (ties: lower label, lower slice).  Within a slice the heaviest entries
+// take consecutive slots, i.e. distinct LDS bank groups.  Returns 0 (and leaves new_of_old alone) when the checkpoint's labels
+// already load the slices evenly: no permutation, no codebook image, the buffer of format v6.
+static int plan_relabel(const uint32_t* usage, uint16_t* new_of_old) {
+  unsigned long long mass0[PK_S] = {}, total = 0;
+  for (int c = 0; c < 65536; ++c) mass0[c >> PK_CODE_BITS] += usage[c];
+  unsigned long long mx = 0;
+  for (int s = 0; s < PK_S; ++s) {
+    total += mass0[s];
+    mx = std::max(mx, mass0[s]);
+  }
+  if (total == 0 || (double)mx * PK_S <= 1.02 * (double)total) return 0;
+  std::vector<uint32_t> order(65536);
+  for (uint32_t c = 0; c < 65536; ++c) order[c] = c;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return usage[x] > usage[y]; });
+  unsigned long long mass[PK_S] = {};
+  int cnt[PK_S] = {};
+  for (uint32_t i = 0; i < 65536; ++i) {
+    const uint32_t c = order[i];
+    int best = -1;
+    for (int s = 0; s < PK_S; ++s)
+      if (cnt[s] < PK_SLICE_ENTRIES && (best < 0 || mass[s] < mass[best])) best = s;
+    new_of_old[c] = (uint16_t)(best * PK_SLICE_ENTRIES + cnt[best]);
+    ++cnt[best];
+    mass[best] += usage[c];
+  }
+  return 1;
+}
+
+// Geometry: deal the PK_NST workgroups to the slices in proportion to their work (lane-steps + a quarter step per row for the
+// epilogue's hand-in): start from PK_MIN_GROUPS each, give the next workgroup to the slice whose groups are the longest.
+// Uniform unless that shortens the longest stream by more than 6 % (the variable-geometry kernel pays ~0.1 us of scalar
+// arithmetic in its prologue and serves single-layer launches only).  Returns 1 when groups[] is not uniform.
+static int plan_geometry(const unsigned long long* slice_steps, int M, int in_features, uint8_t* groups) {
+  for (int s = 0; s < PK_S; ++s) groups[s] = (uint8_t)PK_NG;
+  if (PK_G != 8 || M < PK_VG_MIN_ROWS || !packed_shape_ok(M, in_features, PK_G)) return 0;
+  const int in_groups = in_features / PK_G;
+  double w[PK_S], uni = 0.;
+  for (int s = 0; s < PK_S; ++s) {
+    w[s] = (double)slice_steps[s] + 0.25 * M;
+    uni = std::max(uni, w[s] / PK_NG);
+  }
+  const int mb_uniform = packed_max_batch(in_groups, (M + PK_NG - 1) / PK_NG);
+  for (int nmin = PK_MIN_GROUPS; nmin < PK_NG; ++nmin) {
+    int n[PK_S], left = PK_NST - nmin * PK_S, mn = PK_NG;
+    for (int s = 0; s < PK_S; ++s) n[s] = nmin;
+    while (left-- > 0) {
+      int best = 0;
+      for (int s = 1; s < PK_S; ++s)
+        if (w[s] / n[s] > w[best] / n[best]) best = s;
+      ++n[best];
+    }
+    double var = 0.;
+    bool uniform = true;
+    for (int s = 0; s < PK_S; ++s) {
+      var = std::max(var, w[s] / n[s]);
+      mn = std::min(mn, n[s]);
+      uniform = uniform && n[s] == PK_NG;
+      if (n[s] > 255) return 0;
+    }
+    if (uniform || var > 0.94 * uni) return 0;
+    // the bigger row groups of the lightest slices must not cost the layer its multi-row launches (up to 4 rows in one launch; 5
+    // and 6 rows may take two): else start from more groups per slice
+    if (packed_max_batch(in_groups, (M + mn - 1) / mn) < std::min(mb_uniform, 4)) continue;
+    for (int s = 0; s < PK_S; ++s) groups[s] = (uint8_t)n[s];
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" PK_API int aqlm_hip_packed_plan_relabel(const uint32_t* usage, int slices_log2, uint16_t* new_of_old) {
+#if AQLM_PK_G == 8
+  if (slices_log2 == 5) return aqlm_hip_g16_packed_plan_relabel(usage, slices_log2, new_of_old);
+#endif
+  if (!usage || !new_of_old || slices_log2 != PK_S_LOG) {
+    set_last_error("aqlm_hip_packed_plan_relabel: null pointer or slices_log2 not 4 / 5");
+    return AQLM_HIP_E_INVALID;
+  }
+  return plan_relabel(usage, new_of_old);
+}
+
+extern "C" PK_API int aqlm_hip_packed_plan_geometry(const uint64_t* slice_steps, int slices_log2, int out_features, int in_features,
+                                                    uint8_t* slice_groups) {
+#if AQLM_PK_G == 8
+  if (slices_log2 == 5) return aqlm_hip_g16_packed_plan_geometry(slice_steps, slices_log2, out_features, in_features, slice_groups);
+#endif
+  if (!slice_steps || !slice_groups || slices_log2 != PK_S_LOG) {
+    set_last_error("aqlm_hip_packed_plan_geometry: null pointer or slices_log2 not 4 / 5");
+    return AQLM_HIP_E_INVALID;
+  }
+  unsigned long long st[PK_S];
+  for (int s = 0; s < PK_S; ++s) st[s] = slice_steps[s];
+  return plan_geometry(st, out_features, in_features, slice_groups);
+}
+
+// scratch of the repack, kept in the tail of the caller's capacity: usage counts, the relabelling table, lane-steps per
+// (slice, row), lane-steps per slice
+struct PkScratch {
+  size_t off_hist, off_relabel, off_ls, off_steps, bytes;
+};
+static PkScratch pk_scratch(int M) {
+  PkScratch sc;
+  sc.off_hist = 0;
+  sc.off_relabel = sc.off_hist + (size_t)65536 * 4;
+  sc.off_ls = sc.off_relabel + (size_t)65536 * 2;
+  sc.off_steps = align_up(sc.off_ls + (size_t)PK_S * M * 2, 256);
+  sc.bytes = align_up(sc.off_steps + PK_S * 4, 1024);
+  return sc;
+}
+
 extern "C" PK_API size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size) {
   PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16_bytes(out_features, in_features, in_group_size));
   if (!packed_shape_ok(out_features, in_features, in_group_size)) return 0;
-  // capacity for codes that use the slices up to 25 % unevenly, plus the scratch of the repack (row starts);
+  // capacity for streams up to 1.5 x the balanced length (the repack balances the slices; what is left is the difference
+  // between the rows of one slice), plus the permutation + codebook image of a relabelled buffer and the repack's scratch;
   // the bytes actually used come back in the descriptor and the buffer may be trimmed to them
-  const size_t nst = (size_t)PK_NG * PK_S;
-  const size_t RG = (size_t)(out_features + PK_NG - 1) / PK_NG;
+  const size_t nst = (size_t)PK_NST;
+  const size_t M = (size_t)out_features;
+  const size_t RG2 = (M + PK_MIN_GROUPS - 1) / PK_MIN_GROUPS;                 // rows per group at most (variable geometry)
   const size_t in_groups = (size_t)in_features / PK_G;
-  const size_t lane_steps = RG * in_groups / (4 * PK_S) * 5 / 4 + RG + 64;   // per stream
+  const size_t fair = (M * in_groups / 4 + (size_t)PK_S * M) / nst;            // lane-steps per stream when all are equal
+  const size_t lane_steps = fair * 3 / 2 + RG2 + 64;                           // per stream
   const size_t ent = nst * (lane_steps * 16 + 16 * 1024);
-  const size_t meta = 4096 + nst * PK_MAX_NW * 16 + nst * (RG + 1) * 4 + (size_t)AQLM_HIP_MAX_GEMV_BATCH * out_features * 8;
+  const size_t meta = 4096 + nst * PK_MAX_NW * 16 + nst * (RG2 + 1) * 4 + (size_t)AQLM_HIP_MAX_GEMV_BATCH * out_features * 8;
+  const size_t image = (size_t)65536 * 2 + (size_t)65536 * PK_VB + 2048;
   // 3-byte entries: the repack builds the 4-byte layout in the tail of the buffer and squeezes it to the front
-  return align_up(meta + ent + ent * PK_WREG3 / 1024 + 4096, 1024);
+  return align_up(meta + ent + ent * PK_WREG3 / 1024 + image + pk_scratch(out_features).bytes + 4096, 1024);
 }
 
-extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
-                                     void* packed, size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream_) {
-  PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16(codes, out_features, in_features, in_group_size, packed, packed_bytes, desc, stream_));
+extern "C" PK_API int aqlm_hip_prepack_1x16_ex(const void* codes, int out_features, int in_features, int in_group_size,
+                                               void* packed, size_t packed_bytes, aqlm_hip_packed_desc* desc, int flags, void* stream_) {
+  PK_G16_FORWARD_IF(in_group_size == 16, aqlm_hip_g16_prepack_1x16_ex(codes, out_features, in_features, in_group_size, packed, packed_bytes, desc, flags, stream_));
   hipStream_t stream = (hipStream_t)stream_;
   if (!codes || !packed || !desc) {
     set_last_error("aqlm_hip_prepack_1x16: null pointer argument");
@@ -2165,19 +2496,63 @@ extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features,
     return AQLM_HIP_E_INVALID;
   }
   const int M = out_features, in_groups = in_features / PK_G;
-  const int RG = (M + PK_NG - 1) / PK_NG;
-  const size_t nst = (size_t)PK_NG * PK_S;
+  const size_t nst = (size_t)PK_NST;
   uint8_t* base = (uint8_t*)packed;
-  // the row starts are built in place (their offset does not depend on the wave count chosen later); the max stream
-  // length is read back from the header area
+  const PkScratch sc = pk_scratch(M);
+  const size_t work_end = (packed_bytes - sc.bytes) / 1024 * 1024;  // the layout (and the 4-byte working copy of 3-byte entries) stay below
+  uint8_t* scratch = base + work_end;
+  uint32_t* hist_d = (uint32_t*)(scratch + sc.off_hist);
+  uint16_t* relabel_d = (uint16_t*)(scratch + sc.off_relabel);
+  uint16_t* ls_d = (uint16_t*)(scratch + sc.off_ls);
+  uint32_t* steps_d = (uint32_t*)(scratch + sc.off_steps);
+  const int row_blocks = (M + 3) / 4;
+  // (1) usage counts -> relabelling plan
+  std::vector<uint16_t> new_of_old, old_of_new;
+  bool relabel = false;
+  if (!(flags & AQLM_HIP_PREPACK_NO_RELABEL)) {
+    std::vector<uint32_t> usage(65536);
+    if (int e = check_hip(hipMemsetAsync(hist_d, 0, (size_t)65536 * 4, stream), "prepack memset")) return e;
+    hipLaunchKernelGGL(pk_hist_kernel, dim3(2048), dim3(256), 0, stream, (const uint16_t*)codes, (size_t)M * in_groups, hist_d);
+    if (int e = check_hip(hipMemcpyAsync(usage.data(), hist_d, (size_t)65536 * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
+    if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
+    new_of_old.resize(65536);
+    relabel = plan_relabel(usage.data(), new_of_old.data()) == 1;
+    if (relabel) {
+      old_of_new.resize(65536);
+      for (uint32_t c = 0; c < 65536; ++c) old_of_new[new_of_old[c]] = (uint16_t)c;
+      if (int e = check_hip(hipMemcpyAsync(relabel_d, new_of_old.data(), (size_t)65536 * 2, hipMemcpyHostToDevice, stream), "prepack relabel table")) return e;
+    }
+  }
+  const uint16_t* rl = relabel ? relabel_d : nullptr;
+  // (2) lane-steps per (slice, row) and per slice -> geometry plan
+  if (int e = check_hip(hipMemsetAsync(steps_d, 0, PK_S * 4, stream), "prepack memset")) return e;
+  hipLaunchKernelGGL(pk_count_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, rl, ls_d, steps_d, M, in_groups);
+  uint32_t steps_h[PK_S];
+  if (int e = check_hip(hipMemcpyAsync(steps_h, steps_d, PK_S * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
+  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
+  uint8_t groups[32] = {};
+  unsigned long long steps64[PK_S];
+  for (int s = 0; s < PK_S; ++s) {
+    steps64[s] = steps_h[s];
+    groups[s] = (uint8_t)PK_NG;
+  }
+  if (!(flags & AQLM_HIP_PREPACK_UNIFORM_ONLY)) plan_geometry(steps64, M, in_features, groups);
+  // (3) row starts of every stream (built in place: their offset does not depend on the wave count chosen later); the max
+  // stream length is read back from the header area
   PackedLayout L0;
-  packed_layout(M, in_features, 1, 1, L0);
+  if (!packed_layout(M, in_features, 1, 1, L0, 1, 4, groups, relabel)) {
+    set_last_error("aqlm_hip_prepack_1x16: internal: geometry plan rejected");
+    return AQLM_HIP_E_INVALID;
+  }
+  const PkGeom G = L0.G;
   uint32_t* a = (uint32_t*)(base + L0.off_rowstart);
   uint32_t* maxL_d = (uint32_t*)(base + 128);
+  if (L0.off_ent > work_end) {
+    set_last_error("aqlm_hip_prepack_1x16: capacity too small for the row tables");
+    return AQLM_HIP_E_INVALID;
+  }
   if (int e = check_hip(hipMemsetAsync(base, 0, L0.off_ent, stream), "prepack memset")) return e;
-  const int row_blocks = (M + 3) / 4;
-  hipLaunchKernelGGL(pk_count_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, M, in_groups, RG);
-  hipLaunchKernelGGL(pk_scan_kernel, dim3((unsigned)nst), dim3(256), 0, stream, a, maxL_d, RG);
+  hipLaunchKernelGGL(pk_scan_kernel, dim3((unsigned)nst), dim3(256), 0, stream, ls_d, a, maxL_d, G);
   uint32_t maxL = 0;
   if (int e = check_hip(hipMemcpyAsync(&maxL, maxL_d, 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
   if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
@@ -2187,20 +2562,20 @@ extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features,
   // rotated copies of x: 1 by default -- with the row pools the x reads are already spread well, and up to 4 copies
   // measured within +-1 % (profiles/r02_mb_packed_variants.log); the knob keeps the mechanism testable
   int XC = 1;
-  if (AQLM_PK_XFIRST && PK_G == 8 && arrange && !packed_b1_slice_first(in_groups, RG) && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
+  if (AQLM_PK_XFIRST && PK_G == 8 && arrange && !packed_b1_slice_first(in_groups, G.RG) && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
   // 32-bit entries by default (1-3 % faster: two operations instead of four to form an entry's addresses); 24-bit entries
   // (-23 % bytes; wave ranges of at most 32 steps) are the compact choice for inference-only deployments
-  const int EB = (PK_G == 8 && tuning().packed_entry_bytes == 3 && T <= 32) ? 3 : 4;  // (the 3-byte form exists for 16-B vectors only)
+  const int EB = (PK_G == 8 && tuning().packed_entry_bytes == 3 && T <= 32 && !G.vg) ? 3 : 4;  // (the 3-byte form exists for 16-B vectors and uniform geometry only)
   PackedLayout L, L4;
-  if (!packed_layout(M, in_features, NW, T, L, XC, EB) || !packed_layout(M, in_features, NW, T, L4, XC, 4) ||
-      L.used + (EB == 3 ? L4.ent_bytes + 1024 : 0) > packed_bytes) {
-    set_last_error("aqlm_hip_prepack_1x16: codes too unevenly spread over the codebook slices for the packed format "
-                   "(longest stream %u lane-steps, %d steps per wave)", maxL, T);
+  if (!packed_layout(M, in_features, NW, T, L, XC, EB, groups, relabel) || !packed_layout(M, in_features, NW, T, L4, XC, 4, groups, relabel) ||
+      L.used + (EB == 3 ? L4.ent_bytes + 1024 : 0) > work_end) {
+    set_last_error("aqlm_hip_prepack_1x16: the rows of this layer use the codebook too differently from one another for the packed "
+                   "format (longest stream %u lane-steps after balancing, %d steps per wave)", maxL, T);
     return AQLM_HIP_E_UNSUPPORTED;
   }
   uint32_t* winfo = (uint32_t*)(base + L.off_winfo);
   // the 4-byte working layout: in place for 4-byte entries, else in the tail of the capacity
-  uint32_t* ent = EB == 4 ? (uint32_t*)(base + L.off_ent) : (uint32_t*)(base + (packed_bytes - L4.ent_bytes) / 1024 * 1024);
+  uint32_t* ent = EB == 4 ? (uint32_t*)(base + L.off_ent) : (uint32_t*)(base + (work_end - L4.ent_bytes) / 1024 * 1024);
   aqlm_hip_packed_desc d{};
   d.magic = PK_MAGIC;
   d.version = PK_VERSION;
@@ -2213,27 +2588,66 @@ extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features,
   d.used_bytes = L.used;
   d.x_copies = (uint32_t)XC;
   d.codebook_absmax = 0.f;  // unknown: the caller sets it (see include/aqlm_hip.h) to enable the fused finalize
+  d.flags = (relabel ? AQLM_HIP_PACKED_RELABELLED : 0u) | (G.vg ? AQLM_HIP_PACKED_VARGEOM : 0u);
+  d.rows_per_group = G.RG;
+  for (int s = 0; s < PK_S; ++s) d.slice_groups[s] = groups[s];
   if (int e = check_hip(hipMemcpyAsync(base, &d, sizeof(d), hipMemcpyHostToDevice, stream), "prepack header")) return e;
   const uint32_t null_entry = (uint32_t)in_groups << (16 + PK_VSH);
   hipLaunchKernelGGL(pk_fill_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4, null_entry);
-  hipLaunchKernelGGL(pk_scatter_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, a, ent, M, in_groups, RG, NW, T);
+  hipLaunchKernelGGL(pk_scatter_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, rl, a, ent, G, in_groups, NW, T);
   if (arrange)
     hipLaunchKernelGGL(pk_arrange_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * 1024 + (size_t)T * 256, stream, a,
-                       ent, M, in_groups, RG, NW, T, XC);
+                       ent, G, in_groups, NW, T, XC);
   // the local search on the greedy deal (1-3 % faster matvec) takes ~10x the greedy deal's time (27 -> 120 ms for a 29 M-code
   // layer): by default (1) only layers of <= 8 Mi codes get it -- a 70B model then prepacks in ~13 s instead of ~1 min --,
   // 3 = always, 2 = never
   if (arrange && (tuning().packed_arrange == 3 || (tuning().packed_arrange == 1 && (long)M * in_groups <= PK_IMPROVE_MAX_CODES)))
-    hipLaunchKernelGGL(pk_improve_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * (1024 + 512 + 256 + 32), stream, a, ent, M,
-                       in_groups, RG, NW, T);
+    hipLaunchKernelGGL(pk_improve_kernel, dim3((unsigned)nst, NW), dim3(64), (size_t)T * (1024 + 512 + 256 + 32), stream, a, ent, G,
+                       in_groups, NW, T);
   if (PK_PARITY_BITS) hipLaunchKernelGGL(pk_parity_kernel, dim3(2048), dim3(256), 0, stream, ent, L4.ent_bytes / 4);
-  hipLaunchKernelGGL(pk_flag_kernel, dim3((RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, M, RG, NW, T);
-  hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, M, RG, NW, T);
+  hipLaunchKernelGGL(pk_flag_kernel, dim3((G.RG + 255) / 256, (unsigned)nst), dim3(256), 0, stream, a, ent, G, NW, T);
+  hipLaunchKernelGGL(pk_column_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, a, ent, winfo, G, NW, T);
   if (EB == 3)
-    hipLaunchKernelGGL(pk_compress_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, ent, base + L.off_ent, winfo, M, RG, NW, T);
+    hipLaunchKernelGGL(pk_compress_kernel, dim3((unsigned)nst, NW), dim3(64), 0, stream, ent, base + L.off_ent, winfo, G, NW, T);
   if (int e = check_hip(hipGetLastError(), "prepack launch")) return e;
-  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;  // `d` is on the stack
+  if (relabel) {  // the permutation travels with the buffer: unpack and the codebook image are made from it
+    if (int e = check_hip(hipMemcpyAsync(base + L.off_perm, old_of_new.data(), (size_t)65536 * 2, hipMemcpyHostToDevice, stream), "prepack permutation")) return e;
+  }
+  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;  // `d` and the tables live on the host stack / heap
   *desc = d;
+  return 0;
+}
+
+extern "C" PK_API int aqlm_hip_prepack_1x16(const void* codes, int out_features, int in_features, int in_group_size,
+                                     void* packed, size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream_) {
+  return aqlm_hip_prepack_1x16_ex(codes, out_features, in_features, in_group_size, packed, packed_bytes, desc, 0, stream_);
+}
+
+// codebook image of a relabelled buffer: image[new] = codebook[old_of_new[new]], one 16-B piece per thread
+namespace aqlm {
+namespace PK_NS {
+__global__ __launch_bounds__(256) void pk_codebook_image_kernel(const uint16_t* old_of_new, const u32x4* codebook, u32x4* image) {
+  constexpr uint32_t PIECES = PK_VB / 16;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // < 65536 * PIECES
+  const uint32_t c = i / PIECES, h = i - c * PIECES;
+  image[i] = codebook[(uint32_t)old_of_new[c] * PIECES + h];
+}
+}  // namespace PK_NS
+}  // namespace aqlm
+
+extern "C" PK_API int aqlm_hip_packed_set_codebook(aqlm_hip_packed_desc* desc, void* packed, const void* codebook, void* stream_) {
+  PK_G16_FORWARD(desc, aqlm_hip_g16_packed_set_codebook(desc, packed, codebook, stream_));
+  PackedLayout L;
+  if (!packed || !codebook || !desc_layout(desc, L) || !aligned16(packed) || !aligned16(codebook)) {
+    set_last_error("aqlm_hip_packed_set_codebook: null / misaligned pointer or invalid descriptor");
+    return AQLM_HIP_E_INVALID;
+  }
+  if (!L.relabel) return 0;  // the kernels read the caller's codebook
+  uint8_t* base = (uint8_t*)packed;
+  hipLaunchKernelGGL(pk_codebook_image_kernel, dim3(65536u * (PK_VB / 16) / 256u), dim3(256), 0, (hipStream_t)stream_,
+                     (const uint16_t*)(base + L.off_perm), (const u32x4*)codebook, (u32x4*)(base + L.off_cb));
+  if (int e = check_hip(hipGetLastError(), "codebook image launch")) return e;
+  desc->flags |= AQLM_HIP_PACKED_HAS_CODEBOOK;
   return 0;
 }
 
@@ -2269,12 +2683,13 @@ extern "C" PK_API int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, con
     return AQLM_HIP_E_INVALID;
   }
   const uint8_t* base = (const uint8_t*)packed;
+  const uint16_t* perm = L.relabel ? (const uint16_t*)(base + L.off_perm) : nullptr;  // relabelled: back to the checkpoint's labels
   if (L.EB == 3)
     hipLaunchKernelGGL(pk_unpack3_kernel, dim3((unsigned)L.nst, L.NW), dim3(64), 0, stream, base + L.off_ent,
-                       (const uint32_t*)(base + L.off_winfo), (uint16_t*)codes, L.M, L.in_groups, L.RG, L.NW, L.T);
+                       (const uint32_t*)(base + L.off_winfo), perm, (uint16_t*)codes, L.G, L.in_groups, L.NW, L.T);
   else
     hipLaunchKernelGGL(pk_unpack_kernel, dim3((unsigned)L.nst, L.NW), dim3(64), 0, stream, (const uint32_t*)(base + L.off_ent),
-                       (const uint32_t*)(base + L.off_winfo), (uint16_t*)codes, L.M, L.in_groups, L.RG, L.NW, L.T);
+                       (const uint32_t*)(base + L.off_winfo), perm, (uint16_t*)codes, L.G, L.in_groups, L.NW, L.T);
   return check_hip(hipGetLastError(), "unpack launch");
 }
 
@@ -2319,7 +2734,7 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
   p.ent = (const uint32_t*)(base + L.off_ent);
   p.winfo = (const uint32_t*)(base + L.off_winfo);
   p.rowstart = (const uint32_t*)(base + L.off_rowstart);
-  p.codebook = (const uint8_t*)codebook;
+  p.codebook = L.relabel ? base + L.off_cb : (const uint8_t*)codebook;  // relabelled: the permuted image (aqlm_hip_packed_set_codebook)
   p.x = x;
   p.partial = (float*)workspace;
   if (fused.y || fused.pub) {
@@ -2387,6 +2802,58 @@ static int packed_launch_main(const PackedLayout& L, const void* packed, const v
     return check_hip(hipGetLastError(), "gemv_1x16_packed launch");
   };
   const bool sf = nb == 1 && packed_b1_slice_first(L.in_groups, L.RG);
+#if AQLM_PK_G == 8
+  if (L.G.vg) {  // variable geometry: its own kernels (4-byte entries, ring depth 3 / 4, no chain prefetch, no publish)
+    if (p.pub != nullptr || L.EB != 4) {
+      set_last_error("%s: a variable-geometry buffer runs on the single-layer matvec entries only (repack with "
+                     "AQLM_HIP_PREPACK_UNIFORM_ONLY for the publish form)", who);
+      return AQLM_HIP_E_UNSUPPORTED;
+    }
+    uint32_t ns[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < PK_S; ++i) ns[i >> 2] |= (uint32_t)L.G.first[i] << ((i & 3) * 8);  // first stream of every slice (< 256)
+    auto launch_vg = [&](auto kern, auto lds_map) -> int {
+      const size_t lds = decltype(lds_map)::total(L.in_groups, L.RG, 0);
+      if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+      PackedGemvRest rest{};
+      rest.winfo = p.winfo;
+      rest.partial = p.partial;
+      rest.x_row_stride = p.x_row_stride;
+      rest.acc = p.acc;
+      rest.cb_absmax = p.cb_absmax;
+      rest.scales = p.scales;
+      rest.bias = p.bias;
+      rest.y = p.y;
+      rest.y_row_stride = p.y_row_stride;
+#ifdef AQLM_PACKED_TRACE
+      rest.trace = p.trace;
+      rest.dbg = p.dbg;
+#endif
+      hipLaunchKernelGGL(kern, dim3(PK_NST), dim3(L.NW * 64), lds, stream, p.codebook, p.x, p.ent, (uint32_t)(L.off_ent - L.off_rowstart),
+                         (uint32_t)p.in_groups | ((uint32_t)p.RG << 12), (uint32_t)p.NW | ((uint32_t)p.XC << 8) | (rotate << 15) | ((uint32_t)p.T << 16),
+                         p.M, ns[0], ns[1], ns[2], ns[3], rest);
+      return check_hip(hipGetLastError(), "gemv_1x16_packed (variable geometry) launch");
+    };
+#define AQLM_PK_VG(TT, BB, PP, XW) launch_vg(gemv_1x16_packed_vg_kernel<TT, BB, PP, XW>, PackedLds<BB, XW>{})
+#define AQLM_PK_VG_CASE(BB) \
+  case BB:                  \
+    return dtype == AQLM_HIP_F16 ? AQLM_PK_VG(F16, BB, 4, PK_XWIN_FULL) : AQLM_PK_VG(BF16, BB, 4, PK_XWIN_FULL);
+    switch (nb) {
+      case 1:
+        if (sf) return dtype == AQLM_HIP_F16 ? AQLM_PK_VG(F16, 1, 3, 0u) : AQLM_PK_VG(BF16, 1, 3, 0u);
+        return dtype == AQLM_HIP_F16 ? AQLM_PK_VG(F16, 1, 3, PK_XWIN_FULL) : AQLM_PK_VG(BF16, 1, 3, PK_XWIN_FULL);
+      AQLM_PK_VG_CASE(2)
+      AQLM_PK_VG_CASE(3)
+      AQLM_PK_VG_CASE(4)
+      AQLM_PK_VG_CASE(5)
+      AQLM_PK_VG_CASE(6)
+      AQLM_PK_VG_CASE(7)
+      AQLM_PK_VG_CASE(8)
+    }
+#undef AQLM_PK_VG_CASE
+#undef AQLM_PK_VG
+    return AQLM_HIP_E_INVALID;
+  }
+#endif
   if (p.pub != nullptr) return dispatch_packed<PublishKernels>(dtype, nb, pick_pd(L), L.EB, sf, launch);
   return dispatch_packed<SingleKernels>(dtype, nb, pick_pd(L), L.EB, sf, launch);
 }
@@ -2409,6 +2876,11 @@ static int packed_check_args(const char* who, const aqlm_hip_packed_desc* desc, 
       (batch > 1 && x_row_stride % 8 != 0)) {
     set_last_error("%s: batch must be 1..%d and packed / codebook / x rows 16-B aligned (batch %d)", who,
                    AQLM_HIP_MAX_GEMV_BATCH, batch);
+    return AQLM_HIP_E_INVALID;
+  }
+  if (L.relabel && !(desc->flags & AQLM_HIP_PACKED_HAS_CODEBOOK)) {
+    set_last_error("%s: a relabelled buffer needs its codebook image: call aqlm_hip_packed_set_codebook first (and again whenever "
+                   "the codebook changes)", who);
     return AQLM_HIP_E_INVALID;
   }
   max_b = packed_max_batch(L.in_groups, L.RG);
@@ -2467,8 +2939,9 @@ extern "C" PK_API int aqlm_hip_gemv_1x16_packed_chain(const aqlm_hip_packed_desc
       return AQLM_HIP_E_INVALID;
     }
     next.ent = (const uint8_t*)next_packed + LN.off_ent;
-    next.codebook = (const uint8_t*)next_codebook;
+    next.codebook = LN.relabel ? (const uint8_t*)next_packed + LN.off_cb : (const uint8_t*)next_codebook;
     next.block_bytes = (uint32_t)(LN.ent_bytes / LN.nst);
+    if (LN.G.vg) next = PackedNext{};  // the hint assumes workgroup b of both layers sits on one XCD with the same slice: uniform geometry only
   }
   return gemv_1x16_packed_impl(desc, packed, codebook, scales, bias, x, y, batch, x_row_stride, y_row_stride, dtype, workspace,
                                workspace_bytes, stream_, next);
@@ -2612,6 +3085,35 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
                    AQLM_HIP_MAX_GEMV_BATCH, batch);
     return AQLM_HIP_E_INVALID;
   }
+  {  // a variable-geometry segment (format v7) runs on the single-layer kernels only: one launch per segment, same bits
+    bool any_vg = false;
+    for (int k = 0; k < num_segments; ++k) {
+      PackedLayout Lk;
+      any_vg = any_vg || (descs[k] && desc_layout(descs[k], Lk) && Lk.G.vg);
+    }
+    if (any_vg) {
+      size_t coff = 0;
+      for (int k = 0; k < num_segments; ++k) {
+        const aqlm_hip_segment& sg = segments[k];
+        if (!descs[k] || descs[k]->in_features != in_features || descs[k]->out_features != sg.out_features) {
+          set_last_error("aqlm_hip_gemv_1x16_packed_multi: segment %d: descriptor does not match in_features %d / out_features %d", k,
+                         in_features, sg.out_features);
+          return AQLM_HIP_E_INVALID;
+        }
+        const size_t cneed = (size_t)batch * sg.out_features * 8;
+        if (cells && coff + cneed > cells_bytes) {
+          set_last_error("aqlm_hip_gemv_1x16_packed_multi_cells: %zu bytes of cells required, got %zu", coff + cneed, cells_bytes);
+          return AQLM_HIP_E_INVALID;
+        }
+        if (int e = gemv_1x16_packed_impl(descs[k], const_cast<void*>(sg.codes), sg.codebook, sg.scales, sg.bias, x, sg.y, batch, x_row_stride,
+                                          sg.y_row_stride, dtype, workspace, workspace_bytes, stream_, PackedNext{},
+                                          cells ? (uint8_t*)cells + coff : nullptr, cells ? cneed : 0))
+          return e;
+        coff += cneed;
+      }
+      return 0;
+    }
+  }
   PackedMultiParams mp{};
   PackedFinalizeMultiParams fm{};
   mp.x = (const uint16_t*)x;
@@ -2652,7 +3154,12 @@ static int gemv_1x16_packed_multi_impl(const aqlm_hip_segment* segments, const a
     ps.ent = (const uint32_t*)(base + L.off_ent);
     ps.winfo = (const uint32_t*)(base + L.off_winfo);
     ps.rowstart = (const uint32_t*)(base + L.off_rowstart);
-    ps.codebook = (const uint8_t*)sg.codebook;
+    if (L.relabel && !(descs[k]->flags & AQLM_HIP_PACKED_HAS_CODEBOOK)) {
+      set_last_error("aqlm_hip_gemv_1x16_packed_multi: segment %d: a relabelled buffer needs its codebook image "
+                     "(aqlm_hip_packed_set_codebook)", k);
+      return AQLM_HIP_E_INVALID;
+    }
+    ps.codebook = L.relabel ? base + L.off_cb : (const uint8_t*)sg.codebook;
     ps.partial = fused ? nullptr : (float*)((uint8_t*)workspace + need);
     if (fused) {
       ps.acc = cells ? (unsigned long long*)((uint8_t*)cells + cells_off) : (unsigned long long*)(const_cast<uint8_t*>(base) + L.off_acc);

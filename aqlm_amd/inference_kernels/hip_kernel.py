@@ -147,9 +147,18 @@ class PackedCodes:
     def set_codebook_range(self, codebooks: torch.Tensor) -> None:
         """Record max |codebook entry| in the descriptor: it lets the kernel finalize in the same launch (the slice sums
         meet in fixed-point cells whose scale is derived from this bound and the input's magnitude; include/aqlm_hip.h).
-        One small reduction + a host read-back: load-time work, never issued while a hipGraph is being captured."""
+        One small reduction + a host read-back: load-time work, never issued while a hipGraph is being captured.
+        A relabelled buffer (format v7) also gets its permuted codebook image here (aqlm_hip_packed_set_codebook): the
+        kernels read the image, so it is rewritten whenever the codebook tensor changes -- same fingerprint, same moment."""
         absmax = float(codebooks.detach().abs().max().float().item())
         self.desc.codebook_absmax = absmax if absmax == absmax and absmax != float("inf") else 0.0
+        if self.desc.relabelled:
+            cb = _c(codebooks.detach())
+            with torch.cuda.device(self.buf.device):
+                rc = _lib.aqlm_hip_packed_set_codebook(ctypes.byref(self.desc), self.buf.data_ptr(), cb.data_ptr(),
+                                                       _stream_ptr(self.buf.device))
+            if rc:
+                _native.check(rc, "aqlm packed_set_codebook")
         self._ints = self.desc.as_ints()
         self._range_of = (codebooks.data_ptr(), _version(codebooks))
 
@@ -172,18 +181,26 @@ class PackedCodes:
     @classmethod
     def from_buffer(cls, buf: torch.Tensor) -> "PackedCodes":
         """Re-attach a descriptor to a packed buffer (e.g. one that was saved / moved): it is stored in its first bytes."""
-        head = bytes(buf[:64].cpu().numpy().tobytes())
+        head = bytes(buf[:128].cpu().numpy().tobytes())
         desc = _native.PackedDesc()
         raw = (ctypes.c_char * len(head)).from_buffer_copy(head)
         _native.check(_lib.aqlm_hip_packed_desc_read(ctypes.addressof(raw), len(head), ctypes.byref(desc)), "packed_desc_read")
         return cls(buf, desc)
 
 
-def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8, codebooks: Optional[torch.Tensor] = None) -> Optional[PackedCodes]:
+_UNPACKABLE_WARNED = set()
+
+
+def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8, codebooks: Optional[torch.Tensor] = None, *,
+                 relabel: bool = True, uniform_only: bool = False) -> Optional[PackedCodes]:
     """Repack 1x16 codes [out, in/g, 1] (int16; g = 8 or 16) into the slice-bucketed buffer of aqlm_hip_gemv_1x16_packed.
     Returns None when the packed path does not cover the layer.  One-off, at load / first use (the counterpart of the
     reference's load-time code permutation for its CPU kernel, inference.py:78-83).  With ``codebooks`` the descriptor
-    also gets the layer's codebook range (``PackedCodes.set_codebook_range``): single-kernel matvecs."""
+    also gets the layer's codebook range (``PackedCodes.set_codebook_range``): single-kernel matvecs.
+
+    The repack balances the codebook slices whatever the code histogram is (format v7: relabelling, and for entries that
+    outweigh a whole slice a variable row-group geometry; include/aqlm_hip.h).  ``relabel=False`` keeps the checkpoint's
+    labels, ``uniform_only=True`` keeps the 16 x 16 geometry (what the publish form of row-parallel shards needs)."""
     out_features, in_features = codes.shape[0], codes.shape[1] * in_group_size
     cap = _lib.aqlm_hip_prepack_1x16_bytes(out_features, in_features, in_group_size)
     if cap == 0:
@@ -191,11 +208,21 @@ def prepack_1x16(codes: torch.Tensor, in_group_size: int = 8, codebooks: Optiona
     codes = _c(codes)
     scratch = torch.empty((cap,), dtype=torch.uint8, device=codes.device)
     desc = _native.PackedDesc()
+    flags = (0 if relabel else _native.PREPACK_NO_RELABEL) | (_native.PREPACK_UNIFORM_ONLY if uniform_only else 0)
     with torch.cuda.device(codes.device):
-        rc = _lib.aqlm_hip_prepack_1x16(codes.data_ptr(), out_features, in_features, in_group_size, scratch.data_ptr(),
-                                        cap, ctypes.byref(desc), _stream_ptr(codes.device))
+        rc = _lib.aqlm_hip_prepack_1x16_ex(codes.data_ptr(), out_features, in_features, in_group_size, scratch.data_ptr(),
+                                           cap, ctypes.byref(desc), flags, _stream_ptr(codes.device))
     if rc == _native.E_UNSUPPORTED:
-        return None  # codes too unevenly spread over the codebook slices: the direct kernel serves this layer
+        # even the balanced streams do not fit (rows that differ wildly from one another): the direct kernel serves this layer,
+        # 2-3x slower -- say so once per shape instead of degrading silently
+        key = (out_features, in_features, in_group_size)
+        if key not in _UNPACKABLE_WARNED:
+            _UNPACKABLE_WARNED.add(key)
+            import warnings
+
+            warnings.warn(f"aqlm_amd: 1x16 g{in_group_size} layer {in_features} -> {out_features} cannot take the prepacked matvec "
+                          f"({_native.last_error()}); it runs on the direct kernel (about 2-3x slower at batch 1)", RuntimeWarning, stacklevel=2)
+        return None
     if rc:
         _native.check(rc, "aqlm prepack_1x16")
     packed = PackedCodes(scratch[: int(desc.used_bytes)].clone(), desc)  # keep only the bytes in use
@@ -310,6 +337,9 @@ def _refresh_range(packed: PackedCodes, codebooks: torch.Tensor) -> None:
     if torch.cuda.is_current_stream_capturing() or torch.compiler.is_compiling():
         if packed._range_of is not None:  # stale, not merely missing: do not trust it
             packed.desc.codebook_absmax = 0.0
+            # (a relabelled buffer's codebook image is stale too: the entry then refuses the call with a message that says
+            # what to do -- one eager forward after the codebook changed rewrites it)
+            packed.desc.flags &= ~_native.PACKED_HAS_CODEBOOK
             packed._ints = packed.desc.as_ints()
             packed._range_of = None
         return

@@ -192,7 +192,8 @@ class ShardedQuantizedLinear(nn.Module):
                 self._packed_fingerprint = self._codes_fingerprint()
                 if (tuple(self.codebooks.shape[:3]) == (1, 65536, 1) and self.codebooks.shape[3] == 8
                         and self.codes.shape[0] * self.codes.shape[1] >= inference.PREPACK_MIN_CODES):
-                    self._packed = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks)
+                    # (the publish form of the matvec exists for the 16 x 16 geometry only)
+                    self._packed = hip_kernel.prepack_1x16(self.codes, 8, codebooks=self.codebooks, uniform_only=True)
             ok = torch.tensor([1 if self._packed is not None else 0], device=xs.device)
             if dist.is_initialized() and dist.get_world_size(self.group) > 1:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 6
+#define AQLM_HIP_ABI_VERSION 7
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -167,25 +167,54 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
                             size_t workspace_bytes, void* stream);
 
 /*
- * Load-time repack of 1x16 codes (g 8 or 16) into the slice-bucketed format v6 consumed by aqlm_hip_gemv_1x16_packed (layout:
+ * Load-time repack of 1x16 codes (g 8 or 16) into the slice-bucketed format v7 consumed by aqlm_hip_gemv_1x16_packed (layout:
  * aqlm_amd/csrc/gemv_packed.hip, specification tests/packed_model.py; 4 bytes per code + ~6 bytes per (row, slice),
  * plus 64 bytes per output row of zero-at-rest accumulator cells for the fused finalize).
  * The reference does the analogous thing for its CPU kernel: a one-off permutation of `codes` at first use
  * (inference.py:78-83).
+ *
+ * The packed kernels give every workgroup one slice of the codebook (`code >> 12`) and the codes that fall into it, so their
+ * speed depends on how evenly the codes use the slices; the reference's kernels are data-oblivious (one warp per output row,
+ * cuda_kernel.cu:16-27, launcher :496-507), and real checkpoints (k-means + beam search, src/aq.py:286-356) are not uniform.
+ * Format v7 therefore balances at pack time, losslessly:
+ *   * RELABELLING (AQLM_HIP_PACKED_RELABELLED): the repack counts how often every codebook entry is used and deals the entries
+ *     to the slices so that the slices carry equal numbers of codes (longest-processing-time greedy, at most 65536 / slices
+ *     entries per slice).  The permutation is kept inside the buffer (aqlm_hip_unpack_1x16 undoes it: bit-exact codes), and the
+ *     kernels read a PERMUTED IMAGE of the codebook that also lives in the buffer: the caller writes it with
+ *     aqlm_hip_packed_set_codebook (again whenever the codebook changes) -- the `codebook` argument of the matvec entries is then
+ *     ignored.  Codes that already use the slices evenly (within 2 %) are not relabelled: no permutation, no image, and the
+ *     buffer is what format v6 held.
+ *   * VARIABLE GEOMETRY (AQLM_HIP_PACKED_VARGEOM; 16-byte vectors only): a single entry used by more than 1 / 16 of all codes
+ *     cannot be balanced by any labelling.  The 256 workgroups are then dealt to the slices in proportion to their work
+ *     (slice_groups[s] workgroups for slice s, each owning out_features / slice_groups[s] consecutive rows; >= 8 per slice), instead
+ *     of 16 row groups for every slice.  Every row still receives exactly one contribution per slice, so the finalize is
+ *     unchanged.  Such buffers run on the single-layer entries (the shared-input / chain / publish entries run them one layer per
+ *     launch or refuse with AQLM_HIP_E_UNSUPPORTED); AQLM_HIP_PREPACK_UNIFORM_ONLY asks the repack not to use it.
  *   aqlm_hip_prepack_1x16_bytes  capacity the caller must provide (0: shape not covered -- in_group_size not 8 or 16, more
  *                                input groups than an entry's 12 / 11-bit slot field addresses, or rows whose tables fit no LDS
  *                                image); more than the result needs: the repack uses the tail as scratch.
  *                                in_group_size 16 = the second instantiation (32 slices of 2048 x 32 B).
- *   aqlm_hip_prepack_1x16        fills `packed` and `*desc`; desc->used_bytes <= capacity is what has to be kept (the
+ *   aqlm_hip_prepack_1x16[_ex]   fills `packed` and `*desc`; desc->used_bytes <= capacity is what has to be kept (the
  *                                buffer may be trimmed / copied; the descriptor travels with it and is also stored in the
  *                                buffer's first bytes).  Synchronises `stream` (load-time call, not graph-capturable).
- *                                AQLM_HIP_E_UNSUPPORTED when the codes use the 16 codebook slices too unevenly.
+ *                                AQLM_HIP_E_UNSUPPORTED when even the balanced streams do not fit the capacity (rows that differ
+ *                                wildly from one another); `flags`: AQLM_HIP_PREPACK_* below (0 = everything allowed).
+ *   aqlm_hip_packed_set_codebook writes the permuted codebook image of a relabelled buffer (no-op for others) and sets
+ *                                AQLM_HIP_PACKED_HAS_CODEBOOK in `*desc`; stream-ordered, no synchronisation.
  *   aqlm_hip_packed_desc_read    descriptor from the first sizeof(desc) bytes of a packed buffer copied to the host.
  *   aqlm_hip_unpack_1x16         the inverse: canonical int16 codes [out][in/8] from a packed buffer (lossless).
+ *   aqlm_hip_packed_plan_*       the two host-side planning steps of the repack (pure functions, exposed for tests and tools).
  */
+#define AQLM_HIP_PACKED_RELABELLED 1u   /* codebook entries were dealt to the slices: permutation + codebook image inside the buffer */
+#define AQLM_HIP_PACKED_VARGEOM 2u      /* slice_groups[] is not uniform: the variable-geometry kernels serve the buffer */
+#define AQLM_HIP_PACKED_HAS_CODEBOOK 4u /* the codebook image has been written (aqlm_hip_packed_set_codebook) */
+
+#define AQLM_HIP_PREPACK_NO_RELABEL 1   /* keep the checkpoint's labelling (format v6 behaviour) */
+#define AQLM_HIP_PREPACK_UNIFORM_ONLY 2 /* 16 row groups for every slice (what the shared-input / publish kernels need) */
+
 typedef struct aqlm_hip_packed_desc {
-  uint32_t magic;   /* "AQP6" */
-  uint32_t version; /* 6 */
+  uint32_t magic;   /* "AQP7" */
+  uint32_t version; /* 7 */
   int32_t out_features, in_features;
   int32_t slices_log2; /* 4: 16 codebook slices of 4096 entries */
   int32_t waves;       /* wave ranges per stream = waves per workgroup of the gemv kernel */
@@ -202,13 +231,25 @@ typedef struct aqlm_hip_packed_desc {
                             the bound it was captured with -- re-capture (or capture with a generous bound) if the
                             codebook's range can grow afterwards.  A sum beyond the bound is not wrapped silently:
                             the row's result is NaN (the kernel checks |sum| <= 2 * bound). */
+  uint32_t flags;        /* AQLM_HIP_PACKED_* */
+  int32_t rows_per_group; /* most rows any workgroup owns (sizes the row tables; uniform geometry: ceil(out_features / row groups)) */
+  uint8_t slice_groups[32]; /* workgroups (= row groups) of every slice; their sum is 256 */
 } aqlm_hip_packed_desc;
 
 size_t aqlm_hip_prepack_1x16_bytes(int out_features, int in_features, int in_group_size);
 int aqlm_hip_prepack_1x16(const void* codes_i16, int out_features, int in_features, int in_group_size, void* packed,
                           size_t packed_bytes, aqlm_hip_packed_desc* desc, void* stream);
+int aqlm_hip_prepack_1x16_ex(const void* codes_i16, int out_features, int in_features, int in_group_size, void* packed,
+                             size_t packed_bytes, aqlm_hip_packed_desc* desc, int flags, void* stream);
+int aqlm_hip_packed_set_codebook(aqlm_hip_packed_desc* desc, void* packed, const void* codebook, void* stream);
 int aqlm_hip_packed_desc_read(const void* header_host, size_t header_bytes, aqlm_hip_packed_desc* desc);
 int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, void* codes_i16, void* stream);
+/* Host-side planning steps (no GPU work).  relabel: usage counts of the 65536 entries -> new_of_old[65536] (returns 1 and
+ * fills it when the entries should be re-dealt, 0 when the slices are already even within 2 %).  geometry: lane-steps
+ * (units of 4 entries) of every slice -> slice_groups[1 << slices_log2] (returns 1 when the result is not uniform). */
+int aqlm_hip_packed_plan_relabel(const uint32_t* usage, int slices_log2, uint16_t* new_of_old);
+int aqlm_hip_packed_plan_geometry(const uint64_t* slice_steps, int slices_log2, int out_features, int in_features,
+                                  uint8_t* slice_groups);
 
 /*
  * 1x16 g8 matvec for 1..AQLM_HIP_MAX_GEMV_BATCH input rows on prepacked codes: every CU keeps one 64 KiB slice of the

@@ -32,7 +32,7 @@ def test_header_and_binding_agree(native):
 
 
 def test_abi_version_and_error_string(native):
-    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 6
+    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 7
     assert isinstance(native.last_error(), str)
 
 
@@ -89,7 +89,7 @@ def test_segment_struct_and_multi_validation(native):
     rc = L.aqlm_hip_gemv_1x16_multi(segs, 2, p, 512, 8, 1, 512, 5, None)
     assert rc == native.E_UNSUPPORTED and "float16 and bfloat16" in native.last_error()
     # prepacked entry points: descriptors are validated before anything is launched
-    assert ctypes.sizeof(native.PackedDesc) == 48
+    assert ctypes.sizeof(native.PackedDesc) == 88
     assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 8) > 2 * 4096 * 512 * 2
     assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 16) > 2 * 4096 * 256 * 2   # 16-element vectors: the second instantiation
     assert L.aqlm_hip_prepack_1x16_bytes(4096, 4096, 32) == 0          # other group sizes are not packable
@@ -102,17 +102,30 @@ def test_segment_struct_and_multi_validation(native):
     assert rc == native.E_INVALID and "descriptor" in native.last_error()
     # 64 rows -> 4 per row group; winfo (sized for 16 waves) + row starts (256 x 5 u32) + the accumulator cells of the
     # fused finalize (8 x 64 u64) end at 74 KiB, then 256 x 4 x 1 KiB of entries
-    good = native.PackedDesc(0x36505141, 6, 64, 512, 4, 4, 1, 4, 1024 * (74 + 1024), 4, 1.5)   # ... 4 copies of x, |codebook| <= 1.5
+    uniform = (ctypes.c_uint8 * 32)(*([16] * 16))
+    good = native.PackedDesc(0x37505141, 7, 64, 512, 4, 4, 1, 4, 1024 * (74 + 1024), 4, 1.5, 0, 4, uniform)   # ... 4 copies of x, |codebook| <= 1.5
     back = native.PackedDesc.from_ints(good.as_ints())
     assert bytes(back) == bytes(good)
     rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(good), p, p, p, None, p, p, 9, 512, 64, native.F16, p, 1 << 20, None)
     assert rc == native.E_INVALID and "batch" in native.last_error()
     rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(good), p, p, p, None, p, p, 1, 512, 64, 7, p, 1 << 20, None)
     assert rc == native.E_UNSUPPORTED
-    hdr = ctypes.create_string_buffer(bytes(good), 64)
+    hdr = ctypes.create_string_buffer(bytes(good), 128)
     out = native.PackedDesc()
-    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(hdr), 64, ctypes.byref(out)) == 0 and bytes(out) == bytes(good)
-    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(buf), 64, ctypes.byref(out)) == native.E_INVALID
+    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(hdr), 128, ctypes.byref(out)) == 0 and bytes(out) == bytes(good)
+    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(hdr), 64, ctypes.byref(out)) == native.E_INVALID   # shorter than the descriptor
+    assert L.aqlm_hip_packed_desc_read(ctypes.addressof(buf), 128, ctypes.byref(out)) == native.E_INVALID
+    # format v7: a relabelled buffer refuses to run before its codebook image has been written
+    relab = native.PackedDesc.from_ints(good.as_ints())
+    relab.flags = native.PACKED_RELABELLED
+    relab.used_bytes = 1024 * (74 + 1024) + 65536 * 2 + 65536 * 16
+    rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(relab), p, p, p, None, p, p, 1, 512, 64, native.F16, p, 1 << 20, None)
+    assert rc == native.E_INVALID and "aqlm_hip_packed_set_codebook" in native.last_error()
+    # ... and a descriptor whose row groups do not add up to the 256 workgroups is not a descriptor
+    odd = native.PackedDesc.from_ints(good.as_ints())
+    odd.slice_groups[3] = 17
+    rc = L.aqlm_hip_gemv_1x16_packed(ctypes.byref(odd), p, p, p, None, p, p, 1, 512, 64, native.F16, p, 1 << 20, None)
+    assert rc == native.E_INVALID and "descriptor" in native.last_error()
 
 
 def test_workspace_bytes(native):

@@ -484,13 +484,14 @@ def test_raw_c_abi_strided_rows(hk):
     assert (ybuf[:, 128:] == 7.0).all()
 
 
-# ------------------------------------------------------------------ prepacked (slice-bucketed) 1x16 path, format v6
+# ------------------------------------------------------------------ prepacked (slice-bucketed) 1x16 path, format v7
 @pytest.mark.parametrize("entry_bytes", [3, 4])
 @pytest.mark.parametrize("fin,fout", [(512, 96), (4096, 300), (11008, 64), (64, 40), (14336, 80), (1024, 2000)])
 def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
-    """Integer / byte work: the packed buffer (24-bit and 32-bit entries) is held to the numpy model of format v6 --
+    """Integer / byte work: the packed buffer (24-bit and 32-bit entries) is held to the numpy model of format v7 --
     tables and bookkeeping bit for bit, the entries up to the order inside a row and the x copy they name, which are the
-    repack's bank-aware choice -- and unpacking it must give the codes back."""
+    repack's bank-aware choice -- and unpacking it must give the codes back.  Small layers use the slices unevenly by
+    chance: the repack relabels them, and the relabelling must be the model's (same greedy, same ties)."""
     from aqlm_amd import _native
     from tests import packed_model as pm
 
@@ -504,11 +505,19 @@ def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
     finally:
         _native.set_tuning("packed_entry_bytes", 0)
     assert packed is not None
-    P = pm.pack(cu)
     d = packed.desc
-    assert (d.magic, d.version, d.out_features, d.in_features, d.slices_log2, d.entry_bytes) == (pm.MAGIC, 6, fout, fin, 4, entry_bytes)
-    assert (d.waves, d.steps) == (P["NW"], P["T"])
-    G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), entry_bytes)
+    groups = list(d.slice_groups)[:16]
+    new_of_old = pm.plan_relabel(np.bincount(cu.ravel(), minlength=65536))
+    assert d.relabelled == (new_of_old is not None)
+    assert d.variable_geometry == (groups != [16] * 16)
+    if d.variable_geometry:
+        entry_bytes = 4  # (the variable geometry exists for 4-byte entries only)
+    P = pm.pack(cu, groups=groups, new_of_old=new_of_old)
+    assert (d.magic, d.version, d.out_features, d.in_features, d.slices_log2, d.entry_bytes) == (pm.MAGIC, pm.VERSION, fout, fin, 4, entry_bytes)
+    assert (d.waves, d.steps, d.rows_per_group) == (P["NW"], P["T"], P["RG"])
+    G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), entry_bytes, groups, d.relabelled)
+    if d.relabelled:  # the permutation travels with the buffer
+        np.testing.assert_array_equal(G["old_of_new"], P["old_of_new"])
     np.testing.assert_array_equal(G["winfo"][:, :, :3], P["winfo"][:, :, :3])
     np.testing.assert_array_equal(G["rowstart"], P["rowstart"])
     # bookkeeping (row-end flags, start rows): position-based -> equal to the model's
@@ -528,6 +537,12 @@ def test_prepack_matches_the_format_model(hk, fin, fout, entry_bytes):
         rng = np.random.default_rng(5)
         cb, xx = rng.standard_normal((65536, 8)), rng.standard_normal((1, fin))
         np.testing.assert_allclose(pm.simulate(Pg, cb, xx), xx @ cb[cu].reshape(fout, fin).T, rtol=0, atol=1e-9)
+    if d.relabelled:  # the codebook image the kernels read: written by set_codebook_range, entry `new` = entry old_of_new[new]
+        cbk = torch.randn(1, 65536, 1, 8, dtype=torch.float16, device=DEV)
+        packed.set_codebook_range(cbk)
+        assert packed.desc.flags & _native.PACKED_HAS_CODEBOOK
+        img = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), entry_bytes, groups, True)["codebook_image"]
+        np.testing.assert_array_equal(img, cbk.view(torch.int16).cpu().numpy().view(np.uint16).reshape(65536, 8)[P["old_of_new"]])
     # and it must pay off: fewer LDS bank-group collisions per 16-lane service group than the ascending-j order has
     got = pm.conflict_cycles(dict(P, ent=((G["slot"] + pm.XB) << 16) | G["code"]))
     assert got <= pm.conflict_cycles(P) + 0.02, (got, pm.conflict_cycles(P))
@@ -555,7 +570,7 @@ def test_prepack_local_search_lowers_bank_conflicts(hk):
     try:
         for arrange in (2, 1):
             _native.set_tuning("packed_arrange", arrange)
-            packed = hk.prepack_1x16(codes)
+            packed = hk.prepack_1x16(codes, relabel=False)
             d = packed.desc
             G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), int(d.entry_bytes))
             P = dict(ent=((G["slot"].astype(np.int64) + pm.XB) << 16) | G["code"], in_groups=fin // 8, NW=int(d.waves), winfo=G["winfo"])
@@ -566,6 +581,127 @@ def test_prepack_local_search_lowers_bank_conflicts(hk):
     print(f"LDS cycles per service group and read: greedy {cycles[2]:.3f}, greedy + local search {cycles[1]:.3f}")
     assert cycles[2] < 2.1 and cycles[1] < 0.86 * cycles[2], cycles
 
+
+
+def zipf_codes(fout, in_groups, alpha, sorted_labels, seed):
+    """Codes as k-means + beam search leave them (src/aq.py:286-356 of the reference: not uniform): entry of rank r is used
+    with probability ~ (r + 1)^-alpha; labels sorted by frequency, or shuffled."""
+    rng = np.random.default_rng(seed)
+    p = np.arange(1, 65537, dtype=np.float64) ** (-alpha)
+    p /= p.sum()
+    labels = np.arange(65536) if sorted_labels else rng.permutation(65536)
+    return labels[rng.choice(65536, size=(fout, in_groups), p=p)].astype(np.int64)
+
+
+@pytest.mark.parametrize("alpha,sorted_labels", [(0.8, False), (0.8, True), (1.2, False), (1.2, True)])
+def test_prepack_balances_skewed_code_histograms_like_the_model(hk, alpha, sorted_labels):
+    """Format v7 against its numpy model on codes that use the codebook unevenly: the relabelling is the model's LPT deal, the
+    geometry (workgroups per slice) is what the descriptor says and shortens the longest stream, tables / bookkeeping are
+    bit-exact, the buffer unpacks to the codes, and the model's kernel walk on the permuted codebook gives W x."""
+    from aqlm_amd import _native
+    from tests import packed_model as pm
+
+    fin, fout = 2048, 1536
+    cu = zipf_codes(fout, fin // 8, alpha, sorted_labels, 7)
+    codes = torch.from_numpy(orc.pack_int_data(cu[:, :, None], 16)).to(DEV)
+    packed = hk.prepack_1x16(codes)
+    assert packed is not None
+    d = packed.desc
+    groups = list(d.slice_groups)[:16]
+    new_of_old = pm.plan_relabel(np.bincount(cu.ravel(), minlength=65536))
+    assert new_of_old is not None and d.relabelled
+    steps = pm.slice_steps(new_of_old[cu])
+    assert sum(groups) == 256 and min(groups) >= 8
+    if alpha >= 1.2:  # one entry outweighs a slice: labels alone cannot balance it
+        assert d.variable_geometry and groups == pm.plan_geometry(steps, fout, min(groups) if min(groups) > 8 else 8)
+    else:
+        assert not d.variable_geometry
+    P = pm.pack(cu, groups=groups, new_of_old=new_of_old)
+    assert (d.waves, d.steps, d.rows_per_group, d.entry_bytes) == (P["NW"], P["T"], P["RG"], 4)
+    # the balanced layout is what it is for: the longest stream within 15 % of the mean one (format v6 on these codes: 2-14x)
+    ls, a = pm.lane_steps(new_of_old[cu], P["geom"])
+    totals = a[:, -1]
+    assert totals.max() <= 1.15 * totals.mean() + 8, (int(totals.max()), float(totals.mean()))
+    _, a6 = pm.lane_steps(cu)
+    print(f"longest / mean stream: v7 {totals.max() / totals.mean():.2f}, labels as they are {a6[:, -1].max() / a6[:, -1].mean():.2f}; groups {groups}")
+    G = pm.decode_device_buffer(packed.buf.cpu().numpy(), fout, fin, int(d.waves), int(d.steps), 4, groups, True)
+    np.testing.assert_array_equal(G["old_of_new"], P["old_of_new"])
+    np.testing.assert_array_equal(G["winfo"][:, :, :3], P["winfo"][:, :, :3])
+    np.testing.assert_array_equal(G["rowstart"], P["rowstart"])
+    np.testing.assert_array_equal(G["mask"], P["mask"])
+    np.testing.assert_array_equal(G["frow"], P["frow"])
+    Pg = dict(P, ent=((G["j"] + pm.XB) << 16) | G["code"])
+    np.testing.assert_array_equal(pm.unpack(Pg), cu)
+    assert torch.equal(hk.unpack_1x16(packed), codes)
+    assert torch.equal(hk.unpack_1x16(hk.PackedCodes.from_buffer(packed.buf.clone())), codes)
+    rng = np.random.default_rng(5)
+    cb, xx = rng.standard_normal((65536, 8)), rng.standard_normal((1, fin))
+    np.testing.assert_allclose(pm.simulate(Pg, cb, xx), xx @ cb[cu].reshape(fout, fin).T, rtol=0, atol=1e-9)
+    # the two opt-outs: labels as they are (format v6 behaviour), and relabelling on the 16 x 16 geometry
+    v6 = hk.prepack_1x16(codes, relabel=False, uniform_only=True)
+    assert v6 is None or (not v6.desc.relabelled and not v6.desc.variable_geometry and torch.equal(hk.unpack_1x16(v6), codes))
+    uni = hk.prepack_1x16(codes, uniform_only=True)
+    assert uni is not None and uni.desc.relabelled and not uni.desc.variable_geometry and torch.equal(hk.unpack_1x16(uni), codes)
+
+
+@pytest.mark.parametrize("alpha,sorted_labels", [(0.5, False), (0.5, True), (0.8, False), (0.8, True), (1.0, False), (1.0, True),
+                                                 (1.2, False), (1.2, True)])
+def test_gemv_1x16_packed_on_skewed_code_histograms(hk, alpha, sorted_labels):
+    """A full-size layer (4096 -> 4096) whose codes follow a Zipf law: every case takes the prepacked kernel (format v6 left
+    alpha >= 0.8 and every frequency-sorted labelling to the direct kernel), unpacks losslessly and meets the oracle -- 1 and
+    4 rows, rows bit-identical to single-row launches, shared-input launches bit-identical to separate ones."""
+    fin, fout = 4096, 4096
+    L = orc.make_layer(5000 + int(alpha * 10), fin, fout, 1, 16, 8, batch=4, bias=True)
+    cu = zipf_codes(fout, fin // 8, alpha, sorted_labels, 11 + int(alpha * 10))[:, :, None]
+    L = dict(L, codes=orc.pack_int_data(cu, 16), codes_unsigned=cu)
+    T = to_dev(L, torch.float16)
+    packed = hk.prepack_1x16(T["codes"], codebooks=T["codebooks"])
+    assert packed is not None, "a skewed layer fell off the packed path"
+    assert packed.desc.relabelled or (alpha <= 0.5 and not sorted_labels)
+    assert packed.desc.variable_geometry == (alpha >= 1.0)
+    assert torch.equal(hk.unpack_1x16(packed), T["codes"])
+    ref = c_oracle.DequantGemv(L["codebooks"], L["codes"], L["scales"], L["bias"], 16, nthreads=0)
+    y1 = hk.code1x16_matmat_packed(T["x"][:1], packed, T["codebooks"], T["scales"], T["bias"])
+    check_close(y1[0].float().cpu().numpy(), ref(L["x"][0]).copy(), torch.float16, f"zipf {alpha} sorted={sorted_labels}")
+    y4 = hk.code1x16_matmat_packed(T["x"], packed, T["codebooks"], T["scales"], T["bias"])
+    for b in range(4):
+        check_close(y4[b].float().cpu().numpy(), ref(L["x"][b]).copy(), torch.float16, f"zipf {alpha} row {b}")
+    assert torch.equal(y4[0], y1[0])
+    for _ in range(5):
+        assert torch.equal(y1, hk.code1x16_matmat_packed(T["x"][:1], packed, T["codebooks"], T["scales"], T["bias"]))
+    yz = hk.code1x16_matmat_packed(torch.zeros_like(T["x"][:1]), packed, T["codebooks"], T["scales"], T["bias"])
+    assert torch.equal(yz[0], T["bias"])
+    # a retrained codebook: the image follows the tensor (set_codebook_range is keyed on its version)
+    cb2 = (T["codebooks"].float() * 0.5).half()
+    y_half = hk.code1x16_matmat_packed(T["x"][:1], packed, cb2, T["scales"], None)
+    y_full = hk.code1x16_matmat_packed(T["x"][:1], packed, T["codebooks"], T["scales"], None)
+    check_close(y_half.float().cpu().numpy() * 2.0, y_full.float().cpu().numpy().astype(np.float64), torch.float16, "codebook image follows the tensor")
+    # shared-input launch next to a uniform layer: bit-identical to separate launches
+    L2 = orc.make_layer(77, fin, 1024, 1, 16, 8, batch=1, bias=False)
+    T2 = to_dev(L2, torch.float16)
+    pk2 = hk.prepack_1x16(T2["codes"], codebooks=T2["codebooks"])
+    for B in (1, 2):
+        outs = hk.code1x16_matmat_packed_multi(T["x"][:B], [packed, pk2], [T["codebooks"], T2["codebooks"]],
+                                               [T["scales"], T2["scales"]], [T["bias"], None])
+        assert torch.equal(outs[0], y4[:B])
+        assert torch.equal(outs[1], hk.code1x16_matmat_packed(T["x"][:B], pk2, T2["codebooks"], T2["scales"], None))
+    # the module: same layer through QuantizedLinear (prepacks itself, fast lane and all), hipGraph replay included
+    from aqlm import QuantizedLinear
+
+    m = QuantizedLinear(fin, fout, 8, 1, 1, 16, bias=True, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        m.codes.copy_(T["codes"]); m.codebooks.copy_(T["codebooks"]); m.scales.copy_(T["scales"].reshape(m.scales.shape)); m.bias.copy_(T["bias"])
+        ym = m(T["x"][:1])
+        assert m._packed_codes is not None and torch.equal(ym, y1)
+        ym2 = m(T["x"][:1])
+        assert torch.equal(ym2, y1)
+        g = torch.cuda.CUDAGraph()
+        sx = T["x"][:1].clone()
+        with torch.cuda.graph(g):
+            yg = m(sx)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, y1)
 
 
 PACKED_SHAPES = [

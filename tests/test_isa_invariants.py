@@ -21,7 +21,7 @@ def check_asm(text):
     """-> (kernels checked, [(kernel, loads behind the last LDS-DMA, count of the first wait)] that disagree)"""
     name, loads, seen_dma, done, n, bad = None, 0, False, False, 0, []
     for line in text.split("\n"):
-        m = re.match(r"^(_ZN4aqlm\w+gemv_1x16_packed(?:_multi)?_kernel\w+):", line)
+        m = re.match(r"^(_ZN4aqlm\w+gemv_1x16_packed(?:_multi|_vg)?_kernel\w+):", line)
         if m:
             name, loads, seen_dma, done = m.group(1), 0, False, False
             continue

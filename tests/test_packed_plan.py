@@ -1,0 +1,130 @@
+"""CPU-only: the two host-side planning steps of the format-v7 repack (aqlm_hip_packed_plan_relabel / _geometry, pure
+functions of libaqlm_hip.so) against their numpy statement in tests/packed_model.py, on code histograms from uniform to
+Zipf 1.2 -- what real checkpoints (k-means + beam search, src/aq.py:286-356 of the reference) and the bench's
+`code_histograms` cases look like.  The GPU side (the repack kernels, the variable-geometry matvec) is tested in
+tests/test_hip_parity.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import packed_model as pm
+
+
+@pytest.fixture(scope="module")
+def native():
+    from aqlm_amd import _native
+
+    return _native
+
+
+def zipf_usage(alpha, sorted_labels, n_codes, seed=0):
+    rng = np.random.default_rng(seed)
+    p = np.arange(1, 65537, dtype=np.float64) ** (-alpha) if alpha > 0 else np.ones(65536)
+    p /= p.sum()
+    usage = rng.multinomial(n_codes, p)
+    return usage if sorted_labels else usage[rng.permutation(65536)]
+
+
+def c_relabel(native, usage, slices_log2=4):
+    u = np.ascontiguousarray(usage, dtype=np.uint32)
+    out = np.zeros(65536, dtype=np.uint16)
+    rc = native.lib.aqlm_hip_packed_plan_relabel(u.ctypes.data, slices_log2, out.ctypes.data)
+    assert rc in (0, 1), native.last_error()
+    return out.astype(np.int64) if rc == 1 else None
+
+
+def c_geometry(native, steps, M, in_features, slices_log2=4):
+    st = np.ascontiguousarray(steps, dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint8)
+    rc = native.lib.aqlm_hip_packed_plan_geometry(st.ctypes.data, slices_log2, M, in_features, out.ctypes.data)
+    assert rc in (0, 1), native.last_error()
+    return rc, [int(v) for v in out[:1 << slices_log2]]
+
+
+@pytest.mark.parametrize("alpha,sorted_labels", [(0.0, False), (0.5, False), (0.5, True), (0.8, False), (0.8, True), (1.0, False),
+                                                 (1.0, True), (1.2, False), (1.2, True)])
+def test_relabel_plan_equals_the_model_and_balances_the_slices(native, alpha, sorted_labels):
+    n = 4096 * 512
+    usage = zipf_usage(alpha, sorted_labels, n)
+    got, want = c_relabel(native, usage), pm.plan_relabel(usage)
+    if alpha == 0.0:
+        assert got is None and want is None          # evenly used codebooks keep their labels (and need no codebook image)
+        return
+    assert got is not None and want is not None
+    np.testing.assert_array_equal(got, want)
+    assert sorted(got.tolist()) == list(range(65536))  # a permutation: every entry keeps exactly one slot
+    mass = np.bincount(got >> 12, weights=usage.astype(np.float64), minlength=16)
+    before = usage.reshape(16, 4096).sum(axis=1)
+    # the slices carry equal shares unless a single entry outweighs a share (then that entry's slice holds it and the rarest entries)
+    top = usage.max()
+    assert mass.max() <= max(1.002 * n / 16, top + 4096 * np.sort(usage)[4095]) + 1
+    assert mass.max() <= before.max()
+    if alpha <= 0.8:
+        assert mass.max() / mass.mean() < 1.002 and (sorted_labels is False or before.max() / before.mean() > 2.0)
+
+
+def test_relabel_plan_32_slices(native):
+    usage = zipf_usage(0.8, True, 4096 * 256)
+    got = c_relabel(native, usage, slices_log2=5)
+    assert got is not None and sorted(got.tolist()) == list(range(65536))
+    mass = np.bincount(got >> 11, weights=usage.astype(np.float64), minlength=32)
+    assert mass.max() / mass.mean() < 1.01
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.8, 1.0, 1.2])
+@pytest.mark.parametrize("M,in_features", [(4096, 4096), (11008, 4096), (28672, 8192)])
+def test_geometry_plan(native, alpha, M, in_features):
+    """Workgroups per slice from the lane-steps per slice (relabelled Zipf codes, expectation values): uniform while labels
+    balance the slices, proportional to the work when one entry outweighs a slice; the model's greedy where nothing else binds."""
+    G = in_features // 8
+    usage = zipf_usage(alpha, False, M * G).astype(np.float64)
+    new = pm.plan_relabel(usage.astype(np.int64))
+    share = usage / usage.sum()
+    slice_share = (share.reshape(16, 4096).sum(axis=1) if new is None else np.bincount(new >> 12, weights=share, minlength=16))
+    steps = [int(M * max(1.0, s * G / 4 + 0.4)) for s in slice_share]   # ~ lane-steps: codes / 4 + padding, at least one per row
+    rc, groups = c_geometry(native, steps, M, in_features)
+    assert sum(groups) == 256 and min(groups) >= 8
+    if alpha <= 0.8:
+        assert rc == 0 and groups == [16] * 16
+        return
+    assert rc == 1
+    w = [s + 0.25 * M for s in steps]
+    longest = max(w[s] / groups[s] for s in range(16))
+    assert longest < 0.94 * max(w) / 16 and longest < 1.12 * sum(w) / 256
+    if min(groups) > 8 or groups == pm.plan_geometry(steps, M):
+        assert groups == pm.plan_geometry(steps, M, min(groups) if min(groups) > 8 else 8)
+    # 32-slice build (16-element vectors): no variable geometry
+    rc32, groups32 = c_geometry(native, steps + steps, M, in_features, slices_log2=5)
+    assert rc32 == 0 and groups32 == [8] * 32
+
+
+def test_geometry_plan_small_or_odd_layers_stay_uniform(native):
+    steps = [9000] + [1000] * 15
+    assert c_geometry(native, steps, 256, 4096)[1] == [16] * 16     # fewer rows than the variable geometry takes
+    assert c_geometry(native, steps, 4096, 8 * 4095)[1] == [16] * 16  # a shape the packed format does not cover at all
+    rc, groups = c_geometry(native, steps, 4096, 4096)
+    assert rc == 1 and groups[0] > 60 and sum(groups) == 256 and min(groups) >= 8
+
+
+def test_model_round_trip_with_relabelling_and_variable_geometry():
+    """The numpy model by itself: pack -> walk -> unpack gives the codes back and the kernel walk gives W x, uniform and
+    variable geometry, with and without relabelling (the GPU tests hold the device buffer to this model)."""
+    rng = np.random.default_rng(3)
+    M, G = 640, 64
+    p = np.arange(1, 65537, dtype=np.float64) ** -1.2
+    p /= p.sum()
+    codes = rng.permutation(65536)[rng.choice(65536, size=(M, G), p=p)]
+    usage = np.bincount(codes.ravel(), minlength=65536)
+    new = pm.plan_relabel(usage)
+    groups = pm.plan_geometry(pm.slice_steps(new[codes]), M)
+    assert groups != [16] * 16 and sum(groups) == 256
+    cb, x = rng.standard_normal((65536, 8)), rng.standard_normal((2, G * 8))
+    ref = x @ cb[codes].reshape(M, G * 8).T
+    for kw in ({}, {"new_of_old": new}, {"groups": groups, "new_of_old": new}, {"groups": groups}):
+        P = pm.pack(codes, **kw)
+        np.testing.assert_array_equal(pm.unpack(P), codes)
+        np.testing.assert_allclose(pm.simulate(P, cb, x), ref, rtol=0, atol=1e-9)
+    _, a6 = pm.lane_steps(codes)
+    _, a7 = pm.lane_steps(new[codes], pm.Geometry(M, groups))
+    assert a7[:, -1].max() < 0.6 * a6[:, -1].max()

@@ -342,6 +342,53 @@ static void bench_stream() {
   CK(hipFree(buf)); CK(hipFree(out));
 }
 
+// Zipf-distributed codes (what k-means + beam search leaves behind is not uniform: src/aq.py:286-356 of the reference):
+// rank r is drawn with probability ~ (r + 1)^-alpha (inverse CDF, binary search), label = perm[rank] (identity: labels
+// sorted by frequency; a random permutation otherwise).
+__global__ void fill_zipf(uint16_t* codes, size_t n, const float* cdf, const uint16_t* perm, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + seed * 0x9e3779b9u;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    int lo = 0, hi = 65535;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    codes[i] = perm[lo];
+  }
+}
+static double g_zipf = -1.0;       // < 0: uniform codes (fill_u32)
+static bool g_zipf_sorted = false;  // labels sorted by frequency
+static int g_prepack_flags = 0;     // AQLM_HIP_PREPACK_*
+static float* g_zipf_cdf = nullptr;
+static uint16_t* g_zipf_perm = nullptr;
+static void zipf_setup(double alpha, bool sorted_labels) {
+  g_zipf = alpha;
+  g_zipf_sorted = sorted_labels;
+  if (!g_zipf_cdf) { CK(hipMalloc(&g_zipf_cdf, 65536 * 4)); CK(hipMalloc(&g_zipf_perm, 65536 * 2)); }
+  if (alpha < 0) return;
+  std::vector<double> p(65536);
+  double z = 0;
+  for (int k = 0; k < 65536; ++k) { p[k] = pow((double)(k + 1), -alpha); z += p[k]; }
+  std::vector<float> cdf(65536);
+  double run = 0;
+  for (int k = 0; k < 65536; ++k) { run += p[k] / z; cdf[k] = (float)run; }
+  cdf[65535] = 2.0f;
+  std::vector<uint16_t> perm(65536);
+  for (int k = 0; k < 65536; ++k) perm[k] = (uint16_t)k;
+  if (!sorted_labels) {
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    for (int k = 65535; k > 0; --k) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      const int j = (int)((st >> 33) % (uint64_t)(k + 1));
+      std::swap(perm[k], perm[j]);
+    }
+  }
+  CK(hipMemcpy(g_zipf_cdf, cdf.data(), 65536 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(g_zipf_perm, perm.data(), 65536 * 2, hipMemcpyHostToDevice));
+}
+
 // ---------------------------------------------------------------- library kernels through the C ABI
 struct Layer {
   void *codes, *cb, *scales, *x, *y;
@@ -431,7 +478,10 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     Layer& L = v[i];
     CK(hipMalloc(&L.codes, code_bytes)); CK(hipMalloc(&L.cb, cb_bytes)); CK(hipMalloc(&L.scales, (size_t)out * 2));
     CK(hipMalloc(&L.x, (size_t)batch * in * 2)); CK(hipMalloc(&L.y, (size_t)batch * out * 2));
-    hipLaunchKernelGGL(fill_u32, dim3(1024), dim3(256), 0, 0, (uint32_t*)L.codes, code_bytes / 4, 17u * i + 1);
+    if (g_zipf >= 0 && s.nbits == 16)
+      hipLaunchKernelGGL(fill_zipf, dim3(1024), dim3(256), 0, 0, (uint16_t*)L.codes, code_bytes / 2, g_zipf_cdf, g_zipf_perm, 17u * i + 1);
+    else
+      hipLaunchKernelGGL(fill_u32, dim3(1024), dim3(256), 0, 0, (uint32_t*)L.codes, code_bytes / 4, 17u * i + 1);
     hipLaunchKernelGGL(fill_half, dim3(256), dim3(256), 0, 0, (uint32_t*)L.cb, cb_bytes / 4, 31u * i + 2);
     hipLaunchKernelGGL(fill_half, dim3(64), dim3(256), 0, 0, (uint32_t*)L.x, (size_t)batch * in / 2, 7u * i + 3);
     hipLaunchKernelGGL(fill_one_half, dim3(64), dim3(256), 0, 0, (uint16_t*)L.scales, (size_t)out);
@@ -449,10 +499,17 @@ static std::vector<Layer> make_layers(const Scheme& s, int in, int out, int batc
     const size_t pb = aqlm_hip_prepack_1x16_bytes(out, in, s.g);
     for (auto& L : v) {
       CK(hipMalloc(&L.packed, pb));
-      if (int rc = aqlm_hip_prepack_1x16(L.codes, out, in, s.g, L.packed, pb, &L.desc, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
+      if (int rc = aqlm_hip_prepack_1x16_ex(L.codes, out, in, s.g, L.packed, pb, &L.desc, g_prepack_flags, nullptr)) { fprintf(stderr, "prepack rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
       L.desc.codebook_absmax = 1.0f;  // fill_half draws from [-1, 1): the fused finalize may rely on it
+      if (int rc = aqlm_hip_packed_set_codebook(&L.desc, L.packed, L.cb, nullptr)) { fprintf(stderr, "set_codebook rc=%d %s\n", rc, aqlm_hip_last_error()); exit(4); }
     }
     CK(hipDeviceSynchronize());
+    {
+      int mn = 255, mx = 0;
+      for (int k = 0; k < (1 << v[0].desc.slices_log2); ++k) { mn = std::min(mn, (int)v[0].desc.slice_groups[k]); mx = std::max(mx, (int)v[0].desc.slice_groups[k]); }
+      printf("# packed %d->%d: flags %u (1 relabelled, 2 variable geometry), workgroups per slice %d..%d, rows per group <= %d\n", in, out,
+             v[0].desc.flags, mn, mx, v[0].desc.rows_per_group);
+    }
     printf("# packed %d->%d: waves %d steps %d entry bytes %d x copies %d, %.3f B per code (capacity %.1f MB, used %.1f MB)\n", in, out,
            v[0].desc.waves, v[0].desc.steps, v[0].desc.entry_bytes, (int)v[0].desc.x_copies, (double)v[0].desc.used_bytes / ((double)out * (in / s.g)), pb * 1e-6, v[0].desc.used_bytes * 1e-6);
   }
@@ -760,6 +817,64 @@ static void check_packed(const Scheme& s, const Layer& L, int in, int out, const
   }
 }
 
+// The prepacked 1x16 matvec on skewed code histograms (round 5): Zipf-distributed codes, random and frequency-sorted labels,
+// with (a) the format v6 behaviour (no relabelling: packs only while the slices stay within the capacity), (b) relabelling
+// alone, (c) relabelling + variable geometry (the default).  Cold protocol of `mb gemv` (hipGraph over distinct layers).
+static void bench_skew(int only_out) {
+  g_ws_bytes = (size_t)32 * 8 * 32768 * 4 + (1u << 22);
+  CK(hipMalloc(&g_ws, g_ws_bytes));
+  const Scheme S1x16P{"1x16g8P", 1, 16, 8, false, true};
+  struct Shape { int in, out; };
+  const Shape shapes[] = {{4096, 4096}, {4096, 11008}, {8192, 28672}};
+  printf("%-6s %6s %6s %-8s %-7s %-26s %9s %8s %6s %s\n", "scheme", "in", "out", "alpha", "labels", "mode", "cold_us", "GB/s", "flags", "groups");
+  for (const Shape& sh : shapes) {
+    if (only_out && sh.out != only_out) continue;
+    const size_t ab1 = algo_bytes(sh.in, sh.out, S1x16P, 1);
+    int n = (int)((600u << 20) / ab1) + 1;
+    n = std::min(std::max(n, 8), sh.out > 20000 ? 12 : 64);
+    for (double alpha : {-1.0, 0.5, 0.8, 1.0, 1.2}) {
+      for (int srt = 0; srt < (alpha < 0 ? 1 : 2); ++srt) {
+        zipf_setup(alpha, srt != 0);
+        struct Mode { const char* name; int flags; };
+        const Mode modes[] = {{"relabel+vargeom (default)", 0}, {"relabel, uniform geometry", AQLM_HIP_PREPACK_UNIFORM_ONLY},
+                              {"v6: labels as they are", AQLM_HIP_PREPACK_NO_RELABEL | AQLM_HIP_PREPACK_UNIFORM_ONLY}};
+        for (const Mode& m : modes) {
+          if (alpha < 0 && m.flags != 0) continue;
+          g_prepack_flags = m.flags;
+          // probe: does one layer pack at all?
+          {
+            void *codes, *packed;
+            const size_t code_bytes = (size_t)sh.out * (sh.in / 8) * 2, pb = aqlm_hip_prepack_1x16_bytes(sh.out, sh.in, 8);
+            CK(hipMalloc(&codes, code_bytes)); CK(hipMalloc(&packed, pb));
+            hipLaunchKernelGGL(fill_zipf, dim3(1024), dim3(256), 0, 0, (uint16_t*)codes, code_bytes / 2, g_zipf_cdf, g_zipf_perm, 1u);
+            aqlm_hip_packed_desc d;
+            const int rc = alpha < 0 ? 0 : aqlm_hip_prepack_1x16_ex(codes, sh.out, sh.in, 8, packed, pb, &d, m.flags, nullptr);
+            hipFree(codes); hipFree(packed);
+            if (rc) {
+              printf("%-6s %6d %6d %-8.1f %-7s %-26s %9s %8s  -> does not pack (rc %d): direct kernel\n", "1x16g8", sh.in, sh.out, alpha,
+                     srt ? "sorted" : "random", m.name, "-", "-", rc);
+              continue;
+            }
+          }
+          auto layers = make_layers(S1x16P, sh.in, sh.out, 8, n);
+          check_packed(S1x16P, layers[0], sh.in, sh.out);
+          CK(hipMemset(g_ws, 0, g_ws_bytes));
+          const double us = time_graph(S1x16P, layers, sh.in, sh.out, 1, 20);
+          int mn = 255, mx = 0;
+          for (int k = 0; k < 16; ++k) { mn = std::min(mn, (int)layers[0].desc.slice_groups[k]); mx = std::max(mx, (int)layers[0].desc.slice_groups[k]); }
+          printf("%-6s %6d %6d %-8.1f %-7s %-26s %9.2f %8.0f %6u %d..%d  (waves %d steps %d, %.2f B/code)\n", "1x16g8", sh.in, sh.out, alpha,
+                 alpha < 0 ? "-" : (srt ? "sorted" : "random"), m.name, us, ab1 / us * 1e-3, layers[0].desc.flags, mn, mx, layers[0].desc.waves,
+                 layers[0].desc.steps, (double)layers[0].desc.used_bytes / ((double)sh.out * (sh.in / 8)));
+          fflush(stdout);
+          free_layers(layers);
+        }
+      }
+    }
+  }
+  g_prepack_flags = 0;
+  zipf_setup(-1.0, false);
+}
+
 // ---------------------------------------------------------------- large-batch ops through the C ABI
 static void bench_gemm(bool nosync) {
   const int in = 4096, out = 4096;
@@ -992,6 +1107,7 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "lut_trace")) bench_lut_trace(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 4096, argc > 4 ? atoi(argv[4]) : 32, argc > 5 && !strcmp(argv[5], "planar"));
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
   if (!strcmp(what, "multi")) bench_multi();
+  if (!strcmp(what, "skew")) bench_skew(argc > 2 ? atoi(argv[2]) : 0);
   if (!strcmp(what, "trace")) {
     g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
     CK(hipMalloc(&g_ws, g_ws_bytes));
