@@ -125,6 +125,7 @@ SIGNATURES = {
     "aqlm_hip_8x8_planar_pack": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _vp]),
     "aqlm_hip_8x8_planar_unpack": (_ci, [_vp, _ci, _ci, _ci, _vp, _vp]),
     "aqlm_hip_gemv_8x8_lut_planar": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_float, _vp, _sz, _ci, _vp]),
+    "aqlm_hip_gemv_8x8_lut_batch": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _ci, ctypes.c_float, _vp, _sz, _vp]),
     "aqlm_hip_gemv_8x8_lut_planar_multi": (_ci, [_segp, ctypes.POINTER(ctypes.c_float), _ci, _vp, _ci, _ci, _ci, _vp, _sz, _ci, _vp]),
     "aqlm_hip_gemv_generic": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_dequant_1x16": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "aqlm_hip_gemm_1x16_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemm_kx8_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
+    "aqlm_hip_checksum": (_ci, [_vp, _sz, _vp, _vp]),
     "aqlm_hip_set_tuning": (_ci, [ctypes.c_char_p, _ci]),
     "aqlm_hip_get_tuning": (_ci, [ctypes.c_char_p, ctypes.POINTER(_ci)]),
 }

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -72,7 +73,45 @@ static int* tuning_slot(const char* key) {
   return nullptr;
 }
 
+// position-sensitive checksum (include/aqlm_hip.h): per-thread partial sums, wave reduction through the atomics' return path is
+// not needed -- 64-bit atomic adds commute, so the result does not depend on the order the waves arrive in
+__global__ __launch_bounds__(256) void checksum_kernel(const uint8_t* data, size_t bytes, unsigned long long* out) {
+  const size_t nwords = (bytes + 3) / 4;
+  const bool aligned = (reinterpret_cast<uintptr_t>(data) & 3u) == 0;
+  unsigned long long a = 0, b = 0;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) {
+    uint32_t w = 0;
+    if (aligned && i * 4 + 4 <= bytes) w = reinterpret_cast<const uint32_t*>(data)[i];
+    else
+      for (size_t k = 0; k < 4 && i * 4 + k < bytes; ++k) w |= (uint32_t)data[i * 4 + k] << (8 * k);
+    a += w;
+    b += (unsigned long long)w * (((unsigned long long)i * 0x9E3779B97F4A7C15ull) | 1ull);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, WAVE);
+    b += __shfl_xor(b, o, WAVE);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], a);
+    atomicAdd(&out[1], b);
+  }
+}
+
 }  // namespace aqlm
+
+extern "C" int aqlm_hip_checksum(const void* data, size_t bytes, void* out_u64x2, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!out_u64x2 || (!data && bytes) || (reinterpret_cast<uintptr_t>(out_u64x2) & 7u)) {
+    aqlm::set_last_error("aqlm_hip_checksum: null pointer argument or misaligned output");
+    return AQLM_HIP_E_INVALID;
+  }
+  if (int e = aqlm::check_hip(hipMemsetAsync(out_u64x2, 0, 16, stream), "checksum memset")) return e;
+  if (bytes == 0) return 0;
+  const size_t nwords = (bytes + 3) / 4;
+  const unsigned blocks = (unsigned)std::min<size_t>(2048, (nwords + 255) / 256);
+  hipLaunchKernelGGL(aqlm::checksum_kernel, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)data, bytes, (unsigned long long*)out_u64x2);
+  return aqlm::check_hip(hipGetLastError(), "checksum launch");
+}
 
 extern "C" int aqlm_hip_abi_version(void) { return AQLM_HIP_ABI_VERSION; }
 

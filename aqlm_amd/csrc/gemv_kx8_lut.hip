@@ -400,6 +400,26 @@ __global__ __launch_bounds__(NW * 64) void gemv_8x8_lut_kernel(const uint8_t* co
   gemv_8x8_lut_body<T, G, NW, PLANAR>(p, blockIdx.x);
 }
 
+// 2..AQLM_HIP_MAX_GEMV_BATCH input rows in one launch (round 5; single-kernel form only): blockIdx.y = the row of x.  Every row
+// is its own set of workgroups -- the tables are functions of x, so nothing but the codes (L2 hits for the later rows) and the
+// launch itself is shared -- with its own cells (cells + row * M) and its own output row: B rows cost one launch boundary
+// instead of B (the reference serves any row count of this scheme through one kernel in a per-row loop, triton_kernel.py:161-182).
+// A row's bits equal those of the same row launched alone.
+struct LutTailRows {
+  LutTail t;
+  long y_row_stride;
+};
+
+template <class T, int G, int NW, bool PLANAR>
+__global__ __launch_bounds__(NW * 64) void gemv_8x8_lut_rows_kernel(const uint8_t* codes, const uint16_t* codebooks, const uint16_t* x,
+                                                                     float* partial, int M, int in_groups, int nslabs, int nranges,
+                                                                     int rows_per_range, int x_row_stride, const LutTailRows tail) {
+  const int row = (int)blockIdx.y;
+  const LutParams p{codes, codebooks, x + (size_t)row * (size_t)x_row_stride, partial, M, in_groups, nslabs, nranges, rows_per_range, tail.t.jp,
+                    tail.t.cb_absmax, tail.t.cells + (size_t)row * (size_t)M, tail.t.scales, tail.t.bias, tail.t.y + (size_t)row * tail.y_row_stride};
+  gemv_8x8_lut_body<T, G, NW, PLANAR>(p, blockIdx.x);
+}
+
 // shared-input launch: up to AQLM_HIP_MAX_SEGMENTS layers (own codes / codebooks / partials) times one x
 struct LutSegment {
   const uint8_t* codes;
@@ -566,7 +586,15 @@ static int lut_waves() {
 }
 
 template <class T, int G, int NW, bool PLANAR>
-static int launch_lut(const LutParams& p, hipStream_t stream) {
+static int launch_lut(const LutParams& p, hipStream_t stream, int batch = 1, long x_row_stride = 0, long y_row_stride = 0) {
+  if (batch > 1) {
+    auto kern = gemv_8x8_lut_rows_kernel<T, G, NW, PLANAR>;
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LUT_LDS_BYTES)) return e;
+    const LutTailRows tail{{p.cells, p.scales, p.bias, p.y, p.jp, p.cb_absmax}, y_row_stride};
+    hipLaunchKernelGGL(kern, dim3(p.nslabs * p.nranges, batch), dim3(NW * 64), LUT_LDS_BYTES, stream, p.codes, p.codebooks, p.x, p.partial,
+                       p.M, p.in_groups, p.nslabs, p.nranges, p.rows_per_range, (int)x_row_stride, tail);
+    return check_hip(hipGetLastError(), "gemv_8x8_lut (rows) launch");
+  }
   auto kern = gemv_8x8_lut_kernel<T, G, NW, PLANAR>;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LUT_LDS_BYTES)) return e;
   const LutTail tail{p.cells, p.scales, p.bias, p.y, p.jp, p.cb_absmax};
@@ -576,15 +604,15 @@ static int launch_lut(const LutParams& p, hipStream_t stream) {
 }
 
 template <class T, int G, bool PLANAR>
-static int launch_lut_w(const LutParams& p, hipStream_t stream) {
-  return lut_waves() == 8 ? launch_lut<T, G, 8, PLANAR>(p, stream) : launch_lut<T, G, 16, PLANAR>(p, stream);
+static int launch_lut_w(const LutParams& p, hipStream_t stream, int batch, long xs, long ys) {
+  return lut_waves() == 8 ? launch_lut<T, G, 8, PLANAR>(p, stream, batch, xs, ys) : launch_lut<T, G, 16, PLANAR>(p, stream, batch, xs, ys);
 }
 
 template <bool PLANAR>
-static int launch_lut_any(const LutParams& p, int G, int dtype, hipStream_t stream) {
+static int launch_lut_any(const LutParams& p, int G, int dtype, hipStream_t stream, int batch = 1, long xs = 0, long ys = 0) {
   if (dtype == AQLM_HIP_F16)
-    return G == 8 ? launch_lut_w<F16, 8, PLANAR>(p, stream) : G == 16 ? launch_lut_w<F16, 16, PLANAR>(p, stream) : launch_lut_w<F16, 32, PLANAR>(p, stream);
-  return G == 8 ? launch_lut_w<BF16, 8, PLANAR>(p, stream) : G == 16 ? launch_lut_w<BF16, 16, PLANAR>(p, stream) : launch_lut_w<BF16, 32, PLANAR>(p, stream);
+    return G == 8 ? launch_lut_w<F16, 8, PLANAR>(p, stream, batch, xs, ys) : G == 16 ? launch_lut_w<F16, 16, PLANAR>(p, stream, batch, xs, ys) : launch_lut_w<F16, 32, PLANAR>(p, stream, batch, xs, ys);
+  return G == 8 ? launch_lut_w<BF16, 8, PLANAR>(p, stream, batch, xs, ys) : G == 16 ? launch_lut_w<BF16, 16, PLANAR>(p, stream, batch, xs, ys) : launch_lut_w<BF16, 32, PLANAR>(p, stream, batch, xs, ys);
 }
 
 // batch-1 8x8 matvec through LDS look-up tables; AQLM_HIP_E_UNSUPPORTED when the shape does not fit
@@ -592,9 +620,10 @@ static int launch_lut_any(const LutParams& p, int G, int dtype, hipStream_t stre
 // `planar`: codes in the planar layout (aqlm_hip_8x8_planar_pack); fused then needs cb_absmax > 0
 int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x, void* y,
                  int out_features, int in_features, int in_group_size, int dtype, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream, bool fused, bool planar, float cb_absmax) {
+                 hipStream_t stream, bool fused, bool planar, float cb_absmax, int batch = 1, long x_row_stride = 0, long y_row_stride = 0) {
   const int G = in_group_size;
   if (G != 8 && G != 16 && G != 32) return AQLM_HIP_E_UNSUPPORTED;
+  if (batch < 1 || batch > AQLM_HIP_MAX_GEMV_BATCH || (batch > 1 && (!fused || x_row_stride % 8 != 0 || x_row_stride > 0x7fffffffL))) return AQLM_HIP_E_INVALID;
   LutParams p{};
   p.codes = (const uint8_t*)codes;
   p.codebooks = (const uint16_t*)codebooks;
@@ -607,7 +636,7 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
   p.cb_absmax = cb_absmax;
   if (p.nslabs > 1023) return AQLM_HIP_E_UNSUPPORTED;  // (arrival counter of the fused finalize: 10 bits)
   if (fused) {
-    if (!workspace || workspace_bytes < (size_t)out_features * 8 || ((uintptr_t)workspace & 7)) return AQLM_HIP_E_INVALID;
+    if (!workspace || workspace_bytes < (size_t)batch * out_features * 8 || ((uintptr_t)workspace & 7)) return AQLM_HIP_E_INVALID;
     if (planar && !(cb_absmax > 0.f)) return AQLM_HIP_E_INVALID;
     p.cells = (unsigned long long*)workspace;
     p.scales = (const uint16_t*)scales;
@@ -618,7 +647,8 @@ int gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, c
   }
   p.nranges = std::max(1, 256 / p.nslabs);
   p.rows_per_range = (out_features + p.nranges - 1) / p.nranges;
-  const int e = planar ? launch_lut_any<true>(p, G, dtype, stream) : launch_lut_any<false>(p, G, dtype, stream);
+  const int e = planar ? launch_lut_any<true>(p, G, dtype, stream, batch, x_row_stride, y_row_stride)
+                       : launch_lut_any<false>(p, G, dtype, stream, batch, x_row_stride, y_row_stride);
   if (e || fused) return e;
   LutFinalizeParams f{};
   f.partial = (const float*)workspace;
@@ -787,7 +817,7 @@ extern "C" int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segmen
 
 static int lut_entry(const char* name, const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x,
                      void* y, int out_features, int in_features, int in_group_size, int dtype, void* workspace, size_t workspace_bytes,
-                     void* stream, bool fused, bool planar, float cb_absmax) {
+                     void* stream, bool fused, bool planar, float cb_absmax, int batch = 1, long x_row_stride = 0, long y_row_stride = 0) {
   if (!codes || !codebooks || !scales || !x || !y) {
     set_last_error("%s: null pointer argument", name);
     return AQLM_HIP_E_INVALID;
@@ -805,11 +835,20 @@ static int lut_entry(const char* name, const void* codes, const void* codebooks,
     return AQLM_HIP_E_UNSUPPORTED;
   }
   const int e = gemv_8x8_lut(codes, codebooks, scales, bias, x, y, out_features, in_features, in_group_size, dtype,
-                             workspace, workspace_bytes, (hipStream_t)stream, fused, planar, cb_absmax);
+                             workspace, workspace_bytes, (hipStream_t)stream, fused, planar, cb_absmax, batch, x_row_stride, y_row_stride);
   if (e == AQLM_HIP_E_UNSUPPORTED) set_last_error("%s: in_group_size %d not in {8,16,32}", name, in_group_size);
   if (e == AQLM_HIP_E_INVALID)
-    set_last_error("%s: workspace / cells too small, null or misaligned, or a planar fused call without a positive codebook_absmax", name);
+    set_last_error("%s: workspace / cells too small (batch x out_features x 8 bytes), null or misaligned, a planar fused call without a "
+                   "positive codebook_absmax, or batch outside 1..%d / x rows not 16-B aligned", name, AQLM_HIP_MAX_GEMV_BATCH);
   return e;
+}
+
+extern "C" int aqlm_hip_gemv_8x8_lut_batch(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x,
+                                           void* y, int out_features, int in_features, int in_group_size, int batch, long x_row_stride,
+                                           long y_row_stride, int dtype, int planar, float codebook_absmax, void* cells,
+                                           size_t cells_bytes, void* stream) {
+  return lut_entry("aqlm_hip_gemv_8x8_lut_batch", codes, codebooks, scales, bias, x, y, out_features, in_features, in_group_size, dtype,
+                   cells, cells_bytes, stream, true, planar != 0, codebook_absmax, batch, x_row_stride, y_row_stride);
 }
 
 extern "C" int aqlm_hip_gemv_8x8_lut(const void* codes, const void* codebooks, const void* scales, const void* bias,

@@ -2506,56 +2506,75 @@ extern "C" PK_API int aqlm_hip_prepack_1x16_ex(const void* codes, int out_featur
   uint16_t* ls_d = (uint16_t*)(scratch + sc.off_ls);
   uint32_t* steps_d = (uint32_t*)(scratch + sc.off_steps);
   const int row_blocks = (M + 3) / 4;
-  // (1) usage counts -> relabelling plan
+  uint32_t* maxL_d = (uint32_t*)(base + 128);
+  uint8_t groups[32] = {};
+  for (int s = 0; s < PK_S; ++s) groups[s] = (uint8_t)PK_NG;
   std::vector<uint16_t> new_of_old, old_of_new;
   bool relabel = false;
-  if (!(flags & AQLM_HIP_PREPACK_NO_RELABEL)) {
-    std::vector<uint32_t> usage(65536);
-    if (int e = check_hip(hipMemsetAsync(hist_d, 0, (size_t)65536 * 4, stream), "prepack memset")) return e;
-    hipLaunchKernelGGL(pk_hist_kernel, dim3(2048), dim3(256), 0, stream, (const uint16_t*)codes, (size_t)M * in_groups, hist_d);
-    if (int e = check_hip(hipMemcpyAsync(usage.data(), hist_d, (size_t)65536 * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
-    if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
-    new_of_old.resize(65536);
-    relabel = plan_relabel(usage.data(), new_of_old.data()) == 1;
-    if (relabel) {
-      old_of_new.resize(65536);
-      for (uint32_t c = 0; c < 65536; ++c) old_of_new[new_of_old[c]] = (uint16_t)c;
-      if (int e = check_hip(hipMemcpyAsync(relabel_d, new_of_old.data(), (size_t)65536 * 2, hipMemcpyHostToDevice, stream), "prepack relabel table")) return e;
+  uint32_t steps_h[PK_S];
+  uint32_t maxL = 0;
+  // wave-steps a workgroup runs when its longest stream has L lane-steps (what the balancing can change at all: the kernel
+  // runs whole steps of whole waves)
+  auto capacity = [](uint32_t L) {
+    const int nw = choose_waves(L);
+    return (uint64_t)nw * ((L + 64u * nw - 1) / (64u * nw));
+  };
+  // counts lane-steps per (slice, row) with the given labels, builds the row starts of every stream for `groups` in place (their
+  // offset does not depend on the wave count chosen later) and reads back the longest stream
+  PackedLayout L0;
+  auto count_and_scan = [&](const uint16_t* rl) -> int {
+    if (!packed_layout(M, in_features, 1, 1, L0, 1, 4, groups, relabel)) {
+      set_last_error("aqlm_hip_prepack_1x16: internal: geometry plan rejected");
+      return AQLM_HIP_E_INVALID;
+    }
+    if (L0.off_ent > work_end) {
+      set_last_error("aqlm_hip_prepack_1x16: capacity too small for the row tables");
+      return AQLM_HIP_E_INVALID;
+    }
+    if (int e = check_hip(hipMemsetAsync(base, 0, L0.off_ent, stream), "prepack memset")) return e;
+    if (int e = check_hip(hipMemsetAsync(steps_d, 0, PK_S * 4, stream), "prepack memset")) return e;
+    hipLaunchKernelGGL(pk_count_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, rl, ls_d, steps_d, M, in_groups);
+    hipLaunchKernelGGL(pk_scan_kernel, dim3((unsigned)nst), dim3(256), 0, stream, ls_d, (uint32_t*)(base + L0.off_rowstart), maxL_d, L0.G);
+    if (int e = check_hip(hipMemcpyAsync(steps_h, steps_d, PK_S * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
+    if (int e = check_hip(hipMemcpyAsync(&maxL, maxL_d, 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
+    return check_hip(hipStreamSynchronize(stream), "prepack sync");
+  };
+  // (1) the checkpoint's labels on the 16 x 16 geometry
+  if (int e = count_and_scan(nullptr)) return e;
+  // Balancing is for the longest stream: when it already runs as few wave-steps as perfectly even streams would (+3.5 %: the
+  // noise between the row groups of uniform codes), labels and geometry stay -- no permutation, no codebook image.
+  unsigned long long total_steps = 0;
+  for (int s = 0; s < PK_S; ++s) total_steps += steps_h[s];
+  const uint32_t even = (uint32_t)((total_steps * 1035ull + (unsigned long long)PK_NST * 1000ull - 1ull) / ((unsigned long long)PK_NST * 1000ull));
+  const bool balanced = capacity(maxL) <= capacity(even);
+  if (!balanced) {
+    // (2) usage counts -> relabelling plan -> lane-steps with the new labels
+    if (!(flags & AQLM_HIP_PREPACK_NO_RELABEL)) {
+      std::vector<uint32_t> usage(65536);
+      if (int e = check_hip(hipMemsetAsync(hist_d, 0, (size_t)65536 * 4, stream), "prepack memset")) return e;
+      hipLaunchKernelGGL(pk_hist_kernel, dim3(2048), dim3(256), 0, stream, (const uint16_t*)codes, (size_t)M * in_groups, hist_d);
+      if (int e = check_hip(hipMemcpyAsync(usage.data(), hist_d, (size_t)65536 * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
+      if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
+      new_of_old.resize(65536);
+      relabel = plan_relabel(usage.data(), new_of_old.data()) == 1;
+      if (relabel) {
+        old_of_new.resize(65536);
+        for (uint32_t c = 0; c < 65536; ++c) old_of_new[new_of_old[c]] = (uint16_t)c;
+        if (int e = check_hip(hipMemcpyAsync(relabel_d, new_of_old.data(), (size_t)65536 * 2, hipMemcpyHostToDevice, stream), "prepack relabel table")) return e;
+        if (int e = count_and_scan(relabel_d)) return e;
+      }
+    }
+    // (3) an entry that outweighs a slice: deal the workgroups to the slices by their work
+    if (!(flags & AQLM_HIP_PREPACK_UNIFORM_ONLY)) {
+      unsigned long long steps64[PK_S];
+      for (int s = 0; s < PK_S; ++s) steps64[s] = steps_h[s];
+      if (plan_geometry(steps64, M, in_features, groups))
+        if (int e = count_and_scan(relabel ? relabel_d : nullptr)) return e;
     }
   }
   const uint16_t* rl = relabel ? relabel_d : nullptr;
-  // (2) lane-steps per (slice, row) and per slice -> geometry plan
-  if (int e = check_hip(hipMemsetAsync(steps_d, 0, PK_S * 4, stream), "prepack memset")) return e;
-  hipLaunchKernelGGL(pk_count_kernel, dim3(row_blocks), dim3(256), 0, stream, (const uint16_t*)codes, rl, ls_d, steps_d, M, in_groups);
-  uint32_t steps_h[PK_S];
-  if (int e = check_hip(hipMemcpyAsync(steps_h, steps_d, PK_S * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
-  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
-  uint8_t groups[32] = {};
-  unsigned long long steps64[PK_S];
-  for (int s = 0; s < PK_S; ++s) {
-    steps64[s] = steps_h[s];
-    groups[s] = (uint8_t)PK_NG;
-  }
-  if (!(flags & AQLM_HIP_PREPACK_UNIFORM_ONLY)) plan_geometry(steps64, M, in_features, groups);
-  // (3) row starts of every stream (built in place: their offset does not depend on the wave count chosen later); the max
-  // stream length is read back from the header area
-  PackedLayout L0;
-  if (!packed_layout(M, in_features, 1, 1, L0, 1, 4, groups, relabel)) {
-    set_last_error("aqlm_hip_prepack_1x16: internal: geometry plan rejected");
-    return AQLM_HIP_E_INVALID;
-  }
   const PkGeom G = L0.G;
   uint32_t* a = (uint32_t*)(base + L0.off_rowstart);
-  uint32_t* maxL_d = (uint32_t*)(base + 128);
-  if (L0.off_ent > work_end) {
-    set_last_error("aqlm_hip_prepack_1x16: capacity too small for the row tables");
-    return AQLM_HIP_E_INVALID;
-  }
-  if (int e = check_hip(hipMemsetAsync(base, 0, L0.off_ent, stream), "prepack memset")) return e;
-  hipLaunchKernelGGL(pk_scan_kernel, dim3((unsigned)nst), dim3(256), 0, stream, ls_d, a, maxL_d, G);
-  uint32_t maxL = 0;
-  if (int e = check_hip(hipMemcpyAsync(&maxL, maxL_d, 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
-  if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
   const int NW = choose_waves(maxL);
   const int T = (int)((maxL + 64u * NW - 1) / (64u * NW));
   const bool arrange = tuning().packed_arrange && T <= PK_ARR_MAX_T;

@@ -19,9 +19,11 @@
 
 #include <torch/library.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include <cstring>
 #include <string>
@@ -63,15 +65,18 @@ static bool unchanged(const py::dict& params, const char* name, const Watched& w
 }
 
 // Accumulator cells of the single-kernel finalize, one zero-at-rest set per (device, stream) -- see hip_kernel.py
-// (_packed_cells): the packed buffers are only read, so a layer may run on several streams at once.  Never freed.
+// (_packed_cells): the packed buffers are only read, so a layer may run on several streams at once.  Kept until the caller
+// releases them (release_stream_cells: a hipGraph captured on the stream may hold the address, which only the caller knows).
 constexpr int64_t kCellsBytes = (int64_t)AQLM_HIP_MAX_GEMV_BATCH * 131072 * 8;
+static std::mutex g_cells_mu;
+static std::map<std::pair<int, void*>, at::Tensor> g_cells;
 
 // ONE registry for the whole process: the Python ops take their cells from here too (stream_cells_tensor below) when the
 // extension is loaded, so a stream has one 8 MiB set, not one per code path.
 static at::Tensor stream_cells_tensor(const at::Tensor& like, void* stream, int64_t need_bytes) {
   if (need_bytes > kCellsBytes) return at::Tensor();
-  static std::mutex mu;
-  static std::map<std::pair<int, void*>, at::Tensor> cells;
+  std::mutex& mu = g_cells_mu;
+  std::map<std::pair<int, void*>, at::Tensor>& cells = g_cells;
   std::lock_guard<std::mutex> lock(mu);
   auto key = std::make_pair((int)like.device().index(), stream);
   auto it = cells.find(key);
@@ -81,6 +86,24 @@ static at::Tensor stream_cells_tensor(const at::Tensor& like, void* stream, int6
     it = cells.emplace(key, at::zeros({kCellsBytes / 8}, like.options().dtype(at::kLong))).first;
   }
   return it->second;
+}
+
+// Frees the cell sets of (device, stream) -- device < 0: every device, all_streams: every stream.  For streams that are gone or
+// whose captured graphs are gone; a later call on such a stream simply allocates a fresh zero-filled set.  Returns the sets freed.
+static int64_t release_stream_cells(int device, int64_t stream, bool all_streams) {
+  std::vector<at::Tensor> dead;  // freed outside the lock
+  {
+    std::lock_guard<std::mutex> lock(g_cells_mu);
+    for (auto it = g_cells.begin(); it != g_cells.end();) {
+      if ((device < 0 || it->first.first == device) && (all_streams || it->first.second == (void*)(intptr_t)stream)) {
+        dead.push_back(std::move(it->second));
+        it = g_cells.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  return (int64_t)dead.size();
 }
 
 static void* stream_cells(const at::Tensor& like, void* stream, int64_t need_bytes) {
@@ -122,7 +145,6 @@ class FastLinear {
       packed_ = *packed;
       std::memcpy(&absmax_, desc_bytes.data(), sizeof(float));
       TORCH_CHECK(absmax_ > 0.f && K_ == 8, "FastLinear: the look-up-table lane needs 8 codebooks and a positive codebook bound");
-      max_rows_ = 1;
     } else {
       TORCH_CHECK(codes_.defined() && codes_.is_cuda() && codes_.is_contiguous(), "FastLinear: canonical codes required");
     }
@@ -148,7 +170,10 @@ class FastLinear {
     int rc;
     {
       py::gil_scoped_release nogil;
-      if (kind_ == kLutPlanar8x8)
+      if (kind_ == kLutPlanar8x8 && rows > 1)  // one launch of rows x the single-row workgroups
+        rc = aqlm_hip_gemv_8x8_lut_batch(packed_.data_ptr(), codebooks_.data_ptr(), scales_.data_ptr(), bias, x2.data_ptr(), y.data_ptr(),
+                                         (int)out_, (int)in_, g_, (int)rows, x2.stride(0), out_, dtype_, 1, absmax_, cells, (size_t)kCellsBytes, stream);
+      else if (kind_ == kLutPlanar8x8)
         rc = aqlm_hip_gemv_8x8_lut_planar(packed_.data_ptr(), codebooks_.data_ptr(), scales_.data_ptr(), bias, x2.data_ptr(), y.data_ptr(),
                                           (int)out_, (int)in_, g_, dtype_, absmax_, cells, (size_t)kCellsBytes, 1, stream);
       else if (kind_ == kPacked1x16 && cells)
@@ -218,6 +243,7 @@ class FastGroup {
       return py::none();
     const int64_t rows = a.in_ ? x.numel() / a.in_ : 0;
     if (rows < 1 || rows > a.max_rows_) return py::none();
+    if (a.kind_ == kLutPlanar8x8 && rows > 1) return py::none();  // the shared-input table kernel takes one row of x: Python launches the layers one by one
     int64_t total = 0;
     for (const auto& f : m_) {
       if (!f->is_current()) return py::none();
@@ -297,19 +323,22 @@ struct RawEntry {
   const void* cb_data = nullptr;
   uint32_t cb_version = 0;
   bool cb_versioned = false;
+  int64_t hits_since_check = 0;
   at::Tensor packed;
   aqlm_hip_packed_desc desc{};
 };
 
 static std::mutex g_raw_mu;
 static std::unordered_map<const void*, RawEntry> g_raw;  // key: the codes tensor's TensorImpl
-static bool g_raw_on = true;            // false: every call takes the Python implementation (set_fused_finalize(False), experiments)
-static bool g_raw_prepack = true;       // mirror of hip_kernel.RAW_OP_PREPACK
-static int64_t g_raw_min_codes = 500000;  // mirror of hip_kernel.RAW_OP_PREPACK_MIN_CODES
-static int64_t g_raw_gemm_rows = 7;     // mirror of hip_kernel.MATMAT_GEMM_MIN_ROWS
+// (the dispatcher kernels run without the GIL and from any number of host threads: the mirrors and counters are atomics)
+static std::atomic<bool> g_raw_on{true};            // false: every call takes the Python implementation (set_fused_finalize(False), experiments)
+static std::atomic<bool> g_raw_prepack{true};       // mirror of hip_kernel.RAW_OP_PREPACK
+static std::atomic<int64_t> g_raw_min_codes{500000};  // mirror of hip_kernel.RAW_OP_PREPACK_MIN_CODES
+static std::atomic<int64_t> g_raw_gemm_rows{7};     // mirror of hip_kernel.MATMAT_GEMM_MIN_ROWS
+static std::atomic<int64_t> g_raw_check_every{256};  // mirror of hip_kernel.RAW_OP_CHECK_EVERY: hits of a registered layer between two visits to Python, which re-checks the checksums of its codes / codebook (writes through `.data` change neither identity nor version)
 static PyObject* g_raw_py[3] = {nullptr, nullptr, nullptr};  // Python implementations (leaked on purpose: they outlive the interpreter's teardown order)
-static uint64_t g_raw_served = 0;
-static uint64_t g_raw_hits = 0;  // calls served from a registered (prepacked) layer: the Python cache reads this as its hit count
+static std::atomic<uint64_t> g_raw_served{0};
+static std::atomic<uint64_t> g_raw_hits{0};  // calls served from a registered (prepacked) layer: the Python cache reads this as its hit count
 
 static bool versioned(const at::Tensor& t) { return !t.is_inference(); }
 
@@ -333,7 +362,7 @@ struct RawCall {  // what every launch needs once the arguments have been accept
 static bool raw_accept(const at::Tensor& input, const at::Tensor& codes, const at::Tensor& codebooks, const at::Tensor& scales,
                        const c10::optional<at::Tensor>& bias, at::ScalarType code_type, int64_t K, int64_t codebook_size, int64_t max_rows,
                        RawCall& c, int64_t& in_features, int64_t& out_features, int& g) {
-  if (!g_raw_on || !input.is_cuda() || input.dim() < 1) return false;
+  if (!g_raw_on.load(std::memory_order_relaxed) || !input.is_cuda() || input.dim() < 1) return false;
   const at::ScalarType st = input.scalar_type();
   if (st != at::kHalf && st != at::kBFloat16) return false;
   if (codebooks.scalar_type() != st || scales.scalar_type() != st || (bias && bias->scalar_type() != st)) return false;
@@ -365,7 +394,7 @@ static void raw_prepare(const at::Tensor& input, int64_t in_features, int64_t ou
 static at::Tensor raw_result(const at::Tensor& input, const RawCall& c, int64_t out_features) {
   std::vector<int64_t> shape(input.sizes().begin(), input.sizes().end());
   shape.back() = out_features;
-  ++g_raw_served;
+  g_raw_served.fetch_add(1, std::memory_order_relaxed);
   return c.y.view(shape);
 }
 
@@ -374,7 +403,7 @@ static at::Tensor raw_code1x16_matmat(const at::Tensor& input, const at::Tensor&
   RawCall c;
   int64_t in_features = 0, out_features = 0;
   int g = 0;
-  if (!raw_accept(input, codes, codebooks, scales, bias, at::kShort, 1, 65536, g_raw_gemm_rows - 1, c, in_features, out_features, g) ||
+  if (!raw_accept(input, codes, codebooks, scales, bias, at::kShort, 1, 65536, g_raw_gemm_rows.load(std::memory_order_relaxed) - 1, c, in_features, out_features, g) ||
       (g != 8 && g != 16))
     return raw_python(0, input, codes, codebooks, scales, bias);
   const void* bias_p = bias ? bias->data_ptr() : nullptr;
@@ -386,24 +415,29 @@ static at::Tensor raw_code1x16_matmat(const at::Tensor& input, const at::Tensor&
     std::lock_guard<std::mutex> lock(g_raw_mu);
     auto it = g_raw.find((const void*)codes.unsafeGetTensorImpl());
     if (it != g_raw.end()) {
-      const RawEntry& e = it->second;
+      RawEntry& e = it->second;
       hit = e.codes_data == codes.data_ptr() && e.out == out_features && e.in_groups == codes.size(1) &&
             e.codes_versioned == versioned(codes) && (!e.codes_versioned || e.codes_version == codes._version()) &&
             e.cb_data == codebooks.data_ptr() && e.cb_versioned == versioned(codebooks) &&
             (!e.cb_versioned || e.cb_version == codebooks._version());
+      const int64_t every = g_raw_check_every.load(std::memory_order_relaxed);
+      if (hit && every > 0 && ++e.hits_since_check >= every && c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None) {
+        e.hits_since_check = 0;
+        hit = false;  // this call goes to Python, which verifies the layer's checksums (and re-registers it if it had to repack)
+      }
       if (hit) {
         packed = e.packed;
         desc = e.desc;
       }
     }
   }
-  const bool direct = !hit && (!g_raw_prepack || out_features * codes.size(1) < g_raw_min_codes);
+  const bool direct = !hit && (!g_raw_prepack.load(std::memory_order_relaxed) || out_features * codes.size(1) < g_raw_min_codes.load(std::memory_order_relaxed));
   if (!hit && !direct) return raw_python(0, input, codes, codebooks, scales, bias);  // Python packs (or not) and registers
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
   raw_prepare(input, in_features, out_features, c);
   int rc;
   if (hit) {
-    ++g_raw_hits;
+    g_raw_hits.fetch_add(1, std::memory_order_relaxed);
     void* cells = stream_cells(input, c.stream, c.rows * out_features * 8);
     if (cells)
       rc = aqlm_hip_gemv_1x16_packed_cells(&desc, packed.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), bias_p, c.x2.data_ptr(),
@@ -487,7 +521,8 @@ static void raw_clear() {
   old.swap(g_raw);
 }
 
-static void raw_config(bool on, bool prepack, int64_t min_codes, int64_t gemm_rows) {
+static void raw_config(bool on, bool prepack, int64_t min_codes, int64_t gemm_rows, int64_t check_every) {
+  g_raw_check_every = check_every;
   std::lock_guard<std::mutex> lock(g_raw_mu);
   g_raw_on = on;
   g_raw_prepack = prepack;
@@ -517,6 +552,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("code1x16_matmat", &raw_code1x16_matmat, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
   m.def("code2x8_matmat", &raw_codekx8_matmat<2, 1>, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
   m.def("code1x8_matmat", &raw_codekx8_matmat<1, 2>, py::arg("input"), py::arg("codes"), py::arg("codebooks"), py::arg("scales"), py::arg("bias") = py::none());
+  m.def("release_stream_cells", &release_stream_cells, py::arg("device"), py::arg("stream"), py::arg("all_streams"));
   m.def("stream_cells", [](const at::Tensor& like, int64_t stream, int64_t need_bytes) -> py::object {
     const at::Tensor t = stream_cells_tensor(like, (void*)(intptr_t)stream, need_bytes);
     return t.defined() ? py::cast(t) : py::object(py::none());
@@ -525,8 +561,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("raw_register", &raw_register, "a packed layer of the raw op's cache -> key");
   m.def("raw_forget", &raw_forget);
   m.def("raw_clear", &raw_clear);
-  m.def("raw_config", &raw_config, py::arg("on"), py::arg("prepack"), py::arg("min_codes"), py::arg("gemm_rows"));
-  m.def("raw_served", []() { return g_raw_served; }, "calls launched by the compiled raw ops so far");
-  m.def("raw_hits", []() { return g_raw_hits; }, "calls the compiled code1x16_matmat served from a registered prepacked layer");
+  m.def("raw_config", &raw_config, py::arg("on"), py::arg("prepack"), py::arg("min_codes"), py::arg("gemm_rows"), py::arg("check_every") = 256);
+  m.def("raw_served", []() { return g_raw_served.load(); }, "calls launched by the compiled raw ops so far");
+  m.def("raw_hits", []() { return g_raw_hits.load(); }, "calls the compiled code1x16_matmat served from a registered prepacked layer");
   m.def("raw_entries", []() { std::lock_guard<std::mutex> lock(g_raw_mu); return g_raw.size(); });
 }

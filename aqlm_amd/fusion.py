@@ -124,9 +124,7 @@ class SharedInputGroup:
                 return list(res)
         # every member runs on the kernel it would use alone (so outputs stay bit-identical to the unfused modules):
         # prepacked members share one packed launch, the others one direct launch
-        single_row = input.numel() == input.shape[-1]
-        packed_idx = [i for i, m in enumerate(ms) if m._packed_codes is not None and input.dtype == m.codebooks.dtype
-                      and (isinstance(m._packed_codes, hip_kernel.PackedCodes) or single_row)]
+        packed_idx = [i for i, m in enumerate(ms) if m._packed_codes is not None and input.dtype == m.codebooks.dtype]
         direct_idx = [i for i in range(len(ms)) if i not in packed_idx]
         outs: List[Optional[torch.Tensor]] = [None] * len(ms)
         if packed_idx:

@@ -26,6 +26,15 @@ GEMV_MAX_ROWS = 6
 # codes) 4.6 us packed vs 5.3 us direct; below that the fixed cost of the 64 KiB LDS fill per CU dominates.
 PREPACK_MIN_CODES = 500_000
 
+# Everything a module derives from its parameters (prepacked / planar / permuted codes, the codebook image and range, a dense W)
+# is keyed on the parameters' identity and version counter -- and a write through `.data` (`m.codes.data.copy_(...)`, some
+# loaders, hand-written surgery) changes neither.  The reference has no such state (its launcher reads the live tensors on every
+# call, cuda_kernel.cpp:148-182).  So every DERIVED_CHECK_EVERY-th forward of a module (never while a hipGraph is being captured
+# or traced) re-takes a 128-bit checksum of the parameters the derived state came from (aqlm_hip_checksum: one small kernel + a
+# 16-byte read-back per parameter, ~40 us) and rebuilds what no longer matches; `invalidate_derived_state()` does it on demand.
+# 0 = never check.
+DERIVED_CHECK_EVERY = 256
+
 
 class QuantizedLinear(nn.Module):
     def __init__(
@@ -82,13 +91,16 @@ class QuantizedLinear(nn.Module):
         # `module.prefer_dense_below_rows = 129`, or `aqlm.checkpoint.enable_dense_below_rows(model, 129)`.
         self.prefer_dense_below_rows = 0
         self._dense = None  # (fingerprint, W) -- derived, never saved
+        self._derived_checks = None  # checksums of the parameters the derived state was built from (DERIVED_CHECK_EVERY)
+        self._calls_since_check = 0
 
     # Everything the module derives from its parameters (kernel choice, autograd ops, prepacked / permuted codes, the compiled
     # fast lane -- a pybind11 object that cannot be pickled) is left out of copies and pickles: `copy.deepcopy(model)`,
     # `torch.save(model)` and `pickle` work at any time (EMA copies, PEFT `modules_to_save`, draft-model clones), and the copy
     # rebuilds its derived state at its first forward.  A module whose canonical codes were dropped hands them back to the copy.
     _DERIVED_DEFAULTS = {"gemv_op": None, "gemm_op": None, "use_gemv_rule": None, "_fast": None, "_packed_codes": None,
-                         "_packed_fingerprint": None, "_cpu_codes_alt": None, "_prepack_deferred": False, "_dense": None}
+                         "_packed_fingerprint": None, "_cpu_codes_alt": None, "_prepack_deferred": False, "_dense": None,
+                         "_derived_checks": None, "_calls_since_check": 0}
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -104,7 +116,67 @@ class QuantizedLinear(nn.Module):
         return (f"in_features={self.in_features}, out_features={self.out_features}, scheme="
                 f"{self.num_codebooks}x{self.nbits_per_codebook}g{self.in_group_size}, bias={self.bias is not None}")
 
+    def invalidate_derived_state(self) -> None:
+        """Forget everything derived from the parameters (kernel choice, prepacked / planar / permuted codes, the codebook image
+        and range, the dense W, the compiled fast lane); the next forward rebuilds it.  Call it after writing a parameter through
+        a path PyTorch does not version (``m.codes.data.copy_(...)``) when the periodic check (DERIVED_CHECK_EVERY) is too late
+        or switched off.  A module whose canonical codes were dropped keeps its packed buffer (it IS the weights) and forgets only
+        what came from the codebooks."""
+        self.gemv_op = self.gemm_op = self.use_gemv_rule = None
+        self._fast = None
+        self._dense = None
+        self._cpu_codes_alt = None
+        self._prepack_deferred = False
+        self._derived_checks = None
+        self._calls_since_check = 0
+        if self._codes_dropped:
+            if self._packed_codes is not None:
+                self._packed_codes._range_of = None
+        else:
+            self._packed_codes = None
+        group = self._shared_input_group
+        if group is not None and hasattr(group, "invalidate"):
+            group.invalidate()
+
+    def _record_derived_checks(self) -> None:
+        """Checksums of the parameters the derived state was just built from (see DERIVED_CHECK_EVERY)."""
+        self._derived_checks = None
+        self._calls_since_check = 0
+        if not DERIVED_CHECK_EVERY or (self._packed_codes is None and self._cpu_codes_alt is None and self._dense is None):
+            return
+        if torch.cuda.is_available() and self.codes.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        from .inference_kernels.hip_kernel import tensor_checksum
+
+        checks = {}
+        if not self._codes_dropped:
+            checks["codes"] = tensor_checksum(self.codes)
+        if self._packed_codes is not None or self._dense is not None:
+            checks["codebooks"] = tensor_checksum(self.codebooks)
+        if self._dense is not None:
+            checks["scales"] = tensor_checksum(self.scales)
+        self._derived_checks = checks
+
+    def verify_derived_state(self) -> bool:
+        """Re-take the checksums of `_record_derived_checks` and compare; a mismatch (a parameter was overwritten behind the
+        version counter's back) invalidates the derived state.  Returns whether everything still matched.  Synchronises."""
+        checks = self._derived_checks
+        if not checks:
+            return True
+        from .inference_kernels.hip_kernel import tensor_checksum
+
+        ok = all(tensor_checksum(getattr(self, name)) == value for name, value in checks.items())
+        if not ok:
+            self.invalidate_derived_state()
+        return ok
+
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if self._derived_checks is not None:
+            n = self._calls_since_check + 1
+            if n >= DERIVED_CHECK_EVERY > 0 and not torch.compiler.is_compiling() and not (input.is_cuda and torch.cuda.is_current_stream_capturing()):
+                n = 0
+                self.verify_derived_state()
+            self._calls_since_check = n
         group = self._shared_input_group
         if group is not None and group.applicable(input):
             return group.forward(self, input)  # one launch for all projections of this input (fusion.py)
@@ -123,8 +195,9 @@ class QuantizedLinear(nn.Module):
             from .inference_kernels import hip_kernel
 
             if isinstance(packed, hip_kernel.PlanarCodes):
-                # 8x8 on planar codes: the look-up-table matvec takes one row; anything else goes through the ordinary ops below
-                if input.numel() == input.shape[-1]:
+                # 8x8 on planar codes: the look-up-table matvec takes the gemv rule's 1..6 rows (2+: one launch of rows x the
+                # single-row workgroups); anything else goes through the ordinary ops below
+                if input.numel() >= input.shape[-1] > 0:
                     if torch.compiler.is_compiling():  # traced: the dispatcher op (it has a fake implementation)
                         return torch.ops.aqlm.code8x8_matmat_planar(input, packed.buf, self.codebooks, self.scales, self.bias,
                                                                     [packed.out_features, packed.in_features, packed.in_group_size],
@@ -143,8 +216,12 @@ class QuantizedLinear(nn.Module):
         return op.apply(input, self._canonical_codes(), self.codebooks, self.scales, self.bias)
 
     def _dense_weight(self) -> torch.Tensor:
-        """W in the storage dtype, dequantised once and kept while codes / codebooks / scales are what they were (same rounding
-        as the reference's large-batch path: dequantise, then a library GEMM -- cuda_kernel.cpp:249-301)."""
+        """W in the storage dtype, dequantised once and kept while codes / codebooks / scales are what they were (identity +
+        version, and the periodic checksum of DERIVED_CHECK_EVERY for writes through ``.data``).  The scales are folded into W
+        BEFORE it is rounded to fp16 / bf16 -- one more rounding per weight than the reference's large-batch path, which
+        dequantises unscaled and scales y after the GEMM (cuda_kernel.cpp:249-301, 294-300), and than the fused ops here
+        (fp32 accumulate, scale, one rounding); the price of running the opt-in dense route as ONE library GEMM with the bias
+        fused."""
         def ver(t):
             try:
                 return t._version
@@ -158,6 +235,7 @@ class QuantizedLinear(nn.Module):
             with torch.no_grad():
                 w = _dequantize_weight(unpack_int_data(self._canonical_codes(), self.nbits_per_codebook), self.codebooks, self.scales)
             self._dense = (fp, w.to(self.codebooks.dtype).contiguous())
+            self._record_derived_checks()
         return self._dense[1]
 
     def _codes_fingerprint(self):
@@ -233,6 +311,10 @@ class QuantizedLinear(nn.Module):
         return out
 
     def prepare_matmul_op(self, input: torch.Tensor):
+        self._prepare_matmul_op(input)
+        self._record_derived_checks()
+
+    def _prepare_matmul_op(self, input: torch.Tensor):
         """Resolve the decode (gemv) and batch (gemm) operators once (reference inference.py:77-96).  For host modules
         with 8-bit codebooks the reference permutes ``codes`` IN PLACE to the LUT kernel's layout (inference.py:78-83,
         "TODO: fix this thing"); here the permuted copy is a derived buffer and ``codes`` keeps the checkpoint layout."""

@@ -73,6 +73,27 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def tensor_checksum(t: torch.Tensor):
+    """Position-sensitive checksum of a tensor's bytes: what the derived copies of a parameter (prepacked / planar codes, the
+    codebook image and range, a dense W) are validated against, because a write through ``.data`` leaves no trace in the
+    version counter.  GPU tensors: aqlm_hip_checksum + a 16-byte read-back (synchronises: never while a hipGraph is being
+    captured); host tensors: crc32."""
+    t = t.detach()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if not t.is_cuda:
+        import zlib
+
+        return (zlib.crc32(t.reshape(-1).view(torch.uint8).numpy().data), t.numel())
+    out = torch.empty((2,), dtype=torch.int64, device=t.device)
+    with torch.cuda.device(t.device):
+        rc = _lib.aqlm_hip_checksum(t.data_ptr() if t.numel() else None, t.numel() * t.element_size(), out.data_ptr(),
+                                    _stream_ptr(t.device))
+    if rc:
+        _native.check(rc, "aqlm checksum")
+    return tuple(out.tolist())
+
+
 def _version(t: torch.Tensor) -> int:
     """The tensor's version counter; inference tensors (created under ``torch.inference_mode()``) carry none and cannot
     be written in place outside inference mode, so a constant stands in."""
@@ -134,7 +155,7 @@ class PackedCodes:
     host-side descriptor the kernels are launched with.  Derived from ``codes`` (lossless: ``unpack_1x16`` gives them
     back); never saved."""
 
-    __slots__ = ("buf", "desc", "out_features", "in_features", "in_group_size", "slices", "_ints", "_range_of")
+    __slots__ = ("buf", "desc", "out_features", "in_features", "in_group_size", "slices", "_ints", "_range_of", "_range_checksum")
 
     def __init__(self, buf: torch.Tensor, desc: "_native.PackedDesc"):
         self.buf, self.desc = buf, desc
@@ -143,6 +164,7 @@ class PackedCodes:
         self.in_group_size = 16 if self.slices == 32 else 8  # the two instantiations of csrc/gemv_packed.hip
         self._ints = desc.as_ints()
         self._range_of = None  # fingerprint of the codebook tensor `desc.codebook_absmax` was taken from
+        self._range_checksum = None  # ... and the checksum of its bytes at that moment (unversioned writes, `verify_range`)
 
     def set_codebook_range(self, codebooks: torch.Tensor) -> None:
         """Record max |codebook entry| in the descriptor: it lets the kernel finalize in the same launch (the slice sums
@@ -161,9 +183,21 @@ class PackedCodes:
                 _native.check(rc, "aqlm packed_set_codebook")
         self._ints = self.desc.as_ints()
         self._range_of = (codebooks.data_ptr(), _version(codebooks))
+        self._range_checksum = tensor_checksum(codebooks)
 
     def range_is_current(self, codebooks: torch.Tensor) -> bool:
         return self._range_of == (codebooks.data_ptr(), _version(codebooks))
+
+    def verify_range(self, codebooks: torch.Tensor) -> bool:
+        """Was the codebook written behind the version counter's back (``codebooks.data.copy_()``)?  Compares the checksum taken
+        with the range; on a mismatch the range (and a relabelled buffer's codebook image) is forgotten and rebuilt at the next
+        call.  Synchronises: not for use while a hipGraph is being captured."""
+        if self._range_of is None or not self.range_is_current(codebooks) or self._range_checksum is None:
+            return True
+        if tensor_checksum(codebooks) == self._range_checksum:
+            return True
+        self._range_of = None
+        return False
 
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
@@ -298,6 +332,27 @@ def accumulator_cells(device: Optional[torch.device] = None, stream: Optional[in
         if (device.index, stream) in reg:
             found.append(reg[(device.index, stream)])
     return found
+
+
+def release_accumulator_cells(device: Optional[torch.device] = None, stream: Optional[int] = None) -> int:
+    """Free the accumulator-cell sets (8 MiB each) of ``(device, stream)`` -- ``None`` = every device / every stream -- in all
+    registries.  The library cannot know whether a hipGraph that captured a launch on the stream is still alive (it holds the
+    cells' address), so this is the caller's decision: call it when the streams / graphs of a finished phase are gone (a serving
+    process that retires a capture pool, a test suite).  A later call on a released stream allocates a fresh zero-filled set.
+    Returns the number of sets freed."""
+    from .. import _front
+
+    n = 0
+    dev_index = None if device is None else torch.device(device).index
+    for reg in (_PACKED_CELLS, _LUT_CELLS):
+        for key in [k for k in reg if (dev_index is None or k[0] == dev_index) and (stream is None or k[1] == stream)]:
+            del reg[key]
+            n += 1
+    if device is None and stream is None:
+        _LUT_CELLS_RETIRED.clear()
+    if _front.available() and hasattr(_front.ext, "release_stream_cells"):
+        n += int(_front.ext.release_stream_cells(-1 if dev_index is None else dev_index, 0 if stream is None else stream, stream is None))
+    return n
 
 
 def _packed_cells(device: torch.device, stream: int, nbytes: int):
@@ -536,7 +591,9 @@ def codekx8_matmat_multi(input, codes, codebooks, scales, bias):
             raise NotImplementedError(f"codekx8_matmat_multi needs codebooks [K, 256, 1, g], got {tuple(cb.shape)}")
     cb0 = codebooks[0]
     if (USE_8X8_LUT and 1 <= len(codes) <= _native.MAX_SEGMENTS and cb0.shape[0] == 8 and cb0.shape[2] == 1
-            and cb0.shape[3] in (8, 16, 32) and input.numel() == input.shape[-1] and input.dtype == cb0.dtype):
+            and cb0.shape[3] in (8, 16, 32) and input.dtype == cb0.dtype and 1 <= _lut_rows(input) <= LUT_MAX_ROWS):
+        if _lut_rows(input) > 1:  # the shared-input kernel takes one row of x: one multi-row launch per layer
+            return [_gemv_8x8_lut(input, codes[k], codebooks[k], scales[k], bias[k]) for k in range(len(codes))]
         return _gemv_8x8_lut_multi(input, codes, codebooks, scales, bias)
     return _gemv_multi(input, codes, codebooks, scales, bias, "kx8")
 
@@ -605,7 +662,8 @@ RAW_OP_PREPACK = True                 # set False to keep the raw op on the dire
 RAW_OP_PREPACK_MIN_CODES = 500_000  # same threshold as QuantizedLinear (inference.PREPACK_MIN_CODES)
 RAW_OP_PREPACK_MAX_BYTES = 1 << 30  # of packed buffers held for callers of the raw op (modules keep their own); least recently used go first
 RAW_OP_PREPACK_MAX_MISSES = 8
-_RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None)
+RAW_OP_CHECK_EVERY = 256            # hits between two checksum verifications of a cached layer's codes (0 = never): a write through `.data` changes neither identity nor version
+_RAW_PACKED = {}                      # id(codes) -> (weakref, fingerprint, PackedCodes or None, [checksum of the codes, hits since it was verified])
 _RAW_STATS = {"bytes": 0, "packs_without_hit": 0, "hits": 0, "packs": 0}
 # Compiled kernels of the three reference ops (csrc_front/front.cpp, installed at the end of this file when the extension is
 # built): calls through torch.ops.aqlm.* of <= 6 rows are launched from C++; this module stays their fallback and the owner of
@@ -618,7 +676,8 @@ def _raw_sync_config():
     """Push the knobs the compiled raw ops mirror (call after changing RAW_OP_PREPACK*, MATMAT_GEMM_MIN_ROWS, FUSED_FINALIZE;
     clear_raw_op_prepack_cache() does)."""
     if _RAW_FAST is not None:
-        _RAW_FAST.raw_config(bool(FUSED_FINALIZE), bool(RAW_OP_PREPACK), int(RAW_OP_PREPACK_MIN_CODES), int(MATMAT_GEMM_MIN_ROWS))
+        _RAW_FAST.raw_config(bool(FUSED_FINALIZE), bool(RAW_OP_PREPACK), int(RAW_OP_PREPACK_MIN_CODES), int(MATMAT_GEMM_MIN_ROWS),
+                             int(RAW_OP_CHECK_EVERY))
 
 
 def _raw_register_fast(codes, packed, codebooks):
@@ -669,7 +728,17 @@ def _raw_packed_for(codes, codebooks, input):
     entry = _RAW_PACKED.get(key)
     fp = _raw_fingerprint(codes)
     if entry is not None:
-        if entry[0]() is codes and entry[1] == fp:
+        ok = entry[0]() is codes and entry[1] == fp
+        if ok and entry[2] is not None and RAW_OP_CHECK_EVERY and not torch.cuda.is_current_stream_capturing() and not torch.compiler.is_compiling():
+            # unversioned writes (`codes.data.copy_()`): re-check the checksum taken at pack time -- every RAW_OP_CHECK_EVERY hits
+            # here, and on every call the compiled op hands back (it does so once per RAW_OP_CHECK_EVERY of ITS hits)
+            chk = entry[3]
+            chk[1] += 1
+            if _RAW_FAST is not None or chk[1] >= RAW_OP_CHECK_EVERY:
+                chk[1] = 0
+                ok = chk[0] is None or tensor_checksum(codes) == chk[0]
+                entry[2].verify_range(codebooks)  # ... and the codebook image / range against the codebook's
+        if ok:
             if entry[2] is not None:
                 _RAW_STATS["hits"] += 1
                 _RAW_STATS["packs_without_hit"] = 0
@@ -689,11 +758,12 @@ def _raw_packed_for(codes, codebooks, input):
     packed = None
     g = int(codebooks.shape[3])
     cap = _lib.aqlm_hip_prepack_1x16_bytes(codes.shape[0], codes.shape[1] * g, g)
-    if cap and cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
+    est = cap * 3 // 10  # what the packed buffer will hold, roughly (the capacity covers the 3-byte form's working copy, unbalanced streams and scratch)
+    if cap and est <= RAW_OP_PREPACK_MAX_BYTES:
         # bounded: the least recently used packed buffers make room (a caller cycling through more layers than fit keeps
         # repacking -- `packs_without_hit` then switches the cache off -- and should hold PackedCodes itself, like the module)
         for old in list(_RAW_PACKED):
-            if _RAW_STATS["bytes"] + cap // 2 <= RAW_OP_PREPACK_MAX_BYTES:
+            if _RAW_STATS["bytes"] + est <= RAW_OP_PREPACK_MAX_BYTES:
                 break
             if _RAW_PACKED[old][2] is not None:
                 _raw_drop(old)
@@ -702,7 +772,7 @@ def _raw_packed_for(codes, codebooks, input):
         ref = weakref.ref(codes, lambda _r, k=key: _raw_drop(k))
     except TypeError:
         return None
-    _RAW_PACKED[key] = (ref, fp, packed)  # (None is cached too: a layer the packed path does not cover is not retried)
+    _RAW_PACKED[key] = (ref, fp, packed, [tensor_checksum(codes) if packed is not None and RAW_OP_CHECK_EVERY else None, 0])  # (None is cached too: a layer the packed path does not cover is not retried)
     if packed is not None:
         _RAW_STATS["bytes"] += packed.numel()
         _RAW_STATS["packs"] += 1
@@ -743,8 +813,32 @@ def code1x8_matmat(input, codes, codebooks, scales, bias=None):
     return _gemv(input, codes, codebooks, scales, bias, "kx8")
 
 
-# single-row 8 x 8-bit matvecs use per-token look-up tables in LDS (aqlm_hip_gemv_8x8_lut) instead of LDS gathers
+# 8 x 8-bit matvecs of up to LUT_MAX_ROWS rows use per-token look-up tables in LDS (aqlm_hip_gemv_8x8_lut*) instead of LDS
+# gathers: one row = one set of workgroups, 2+ rows = one launch of rows x that set (aqlm_hip_gemv_8x8_lut_batch; round 5 -- before,
+# the second row sent the call to the plain LDS kernel: 16-37 us for what the table kernel does in 6 per row)
 USE_8X8_LUT = True
+LUT_MAX_ROWS = _native.MAX_GEMV_BATCH
+
+
+def _lut_rows(input) -> int:
+    return input.numel() // input.shape[-1] if input.shape[-1] else 0
+
+
+def _gemv_8x8_lut_rows(input, x, codes_ptr, codebooks, scales, bias, out_features, in_features, g, dt, planar, absmax):
+    """2..LUT_MAX_ROWS rows: ONE launch when the stream's cells hold rows x out_features (else None: the caller loops the rows)."""
+    B = x.shape[0]
+    stream = _stream_ptr(input.device)
+    cells = _lut_cells(input.device, stream, B * out_features)
+    if cells is None or (planar and not absmax > 0.0):
+        return None
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    with _device_guard(input.device):
+        rc = _lib.aqlm_hip_gemv_8x8_lut_batch(codes_ptr, codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(), y.data_ptr(),
+                                              out_features, in_features, g, B, x.stride(0), out_features, dt, 1 if planar else 0,
+                                              float(absmax), cells.data_ptr(), cells.numel() * 8, stream)
+    if rc:
+        _native.check(rc, "aqlm gemv_8x8_lut_batch")
+    return y.reshape(input.shape[:-1] + (out_features,))
 
 
 def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
@@ -757,6 +851,12 @@ def _gemv_8x8_lut(input, codes, codebooks, scales, bias):
     codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
     if bias is not None:
         bias = _c(bias)
+    if x.shape[0] > 1:
+        y = _gemv_8x8_lut_rows(input, x, codes.data_ptr(), codebooks, scales, bias, out_features, in_features, g, dt, False, 0.0)
+        if y is not None:
+            return y
+        return torch.cat([_gemv_8x8_lut(x[b:b + 1], codes, codebooks, scales, bias) for b in range(x.shape[0])]).reshape(
+            input.shape[:-1] + (out_features,))
     y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
     stream = _stream_ptr(input.device)
     cells = _lut_cells(input.device, stream, out_features)
@@ -792,21 +892,32 @@ PLANAR_8X8_MIN_GROUPS = 64  # input groups below which a 128-group slab would be
 class PlanarCodes:
     """8x8 codes in the planar layout + the codebook bound the single-kernel finalize needs."""
 
-    __slots__ = ("buf", "out_features", "in_features", "in_group_size", "codebook_absmax", "_range_of")
+    __slots__ = ("buf", "out_features", "in_features", "in_group_size", "codebook_absmax", "_range_of", "_range_checksum")
 
     def __init__(self, buf: torch.Tensor, out_features: int, in_features: int, in_group_size: int):
         self.buf = buf
         self.out_features, self.in_features, self.in_group_size = out_features, in_features, in_group_size
         self.codebook_absmax = 0.0
         self._range_of = None
+        self._range_checksum = None
 
     def set_codebook_range(self, codebooks: torch.Tensor) -> None:
         absmax = float(codebooks.detach().abs().max().float().item())
         self.codebook_absmax = absmax if absmax == absmax and absmax != float("inf") else 0.0
         self._range_of = (codebooks.data_ptr(), _version(codebooks))
+        self._range_checksum = tensor_checksum(codebooks)
 
     def range_is_current(self, codebooks: torch.Tensor) -> bool:
         return self._range_of == (codebooks.data_ptr(), _version(codebooks))
+
+    def verify_range(self, codebooks: torch.Tensor) -> bool:
+        """See PackedCodes.verify_range: the codebook bound against unversioned writes of the codebook."""
+        if self._range_of is None or not self.range_is_current(codebooks) or self._range_checksum is None:
+            return True
+        if tensor_checksum(codebooks) == self._range_checksum:
+            return True
+        self._range_of = None
+        return False
 
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
@@ -877,22 +988,29 @@ def _check_planar_args(input, planar, codebooks, scales):
         raise ValueError(f"input has {input.shape[-1]} features, layer expects {planar.in_features}")
     if input.device != planar.device or codebooks.device != input.device:
         raise ValueError(f"input on {input.device}, layer on {planar.device}")
-    if input.numel() != input.shape[-1]:
-        raise NotImplementedError("the look-up-table matvec takes one input row")
     return _dtype_id(input)
 
 
 def code8x8_matmat_planar(input, planar: PlanarCodes, codebooks, scales, bias=None):
-    """Single-row 8x8 matvec on planar codes (aqlm_hip_gemv_8x8_lut_planar); same contract as codekx8_matmat."""
+    """8x8 matvec of 1..LUT_MAX_ROWS rows on planar codes (aqlm_hip_gemv_8x8_lut_planar / _batch); same contract as codekx8_matmat."""
     dt = _check_planar_args(input, planar, codebooks, scales)
     x = _flat_rows(input)
     codebooks, scales = _c(codebooks), _c(scales)
     if bias is not None:
         bias = _c(bias)
     out_features, in_features, g = planar.out_features, planar.in_features, planar.in_group_size
+    _planar_refresh(planar, codebooks)
+    if x.shape[0] > 1:
+        if x.shape[0] > LUT_MAX_ROWS:
+            raise ValueError(f"code8x8_matmat_planar takes 1..{LUT_MAX_ROWS} rows, got {x.shape[0]}")
+        y = _gemv_8x8_lut_rows(input, x, planar.data_ptr(), codebooks, scales, bias, out_features, in_features, g, dt, True,
+                               planar.codebook_absmax)
+        if y is not None:
+            return y
+        return torch.cat([code8x8_matmat_planar(x[b:b + 1], planar, codebooks, scales, bias) for b in range(x.shape[0])]).reshape(
+            input.shape[:-1] + (out_features,))
     y = torch.empty((1, out_features), dtype=input.dtype, device=input.device)
     stream = _stream_ptr(input.device)
-    _planar_refresh(planar, codebooks)
     cells = _lut_cells(input.device, stream, out_features) if planar.codebook_absmax > 0.0 else None
     with _device_guard(input.device):
         if cells is not None:
@@ -915,6 +1033,8 @@ def code8x8_matmat_planar_multi(input, planar, codebooks, scales, bias):
     n = len(planar)
     if not (1 <= n <= _native.MAX_SEGMENTS) or not (len(codebooks) == len(scales) == len(bias) == n):
         raise ValueError(f"code8x8_matmat_planar_multi takes 1..{_native.MAX_SEGMENTS} layers with one entry per list")
+    if _lut_rows(input) > 1:  # the shared-input kernel takes one row of x: 2+ rows run one (multi-row) launch per layer
+        return [code8x8_matmat_planar(input, planar[k], codebooks[k], scales[k], bias[k]) for k in range(n)]
     x = _flat_rows(input)
     segs = (_native.Segment * n)()
     absmax = (ctypes.c_float * n)()
@@ -957,7 +1077,7 @@ def codekx8_matmat(input, codes, codebooks, scales, bias=None):
     if codebooks.shape[1] != 256:
         raise NotImplementedError(f"codekx8_matmat needs 256-entry codebooks, got {tuple(codebooks.shape)}")
     if (USE_8X8_LUT and codebooks.shape[0] == 8 and codebooks.shape[2] == 1 and codebooks.shape[3] in (8, 16, 32)
-            and input.numel() == input.shape[-1] and input.dtype == codebooks.dtype):
+            and 1 <= _lut_rows(input) <= LUT_MAX_ROWS and input.dtype == codebooks.dtype):
         return _gemv_8x8_lut(input, codes, codebooks, scales, bias)
     return _gemv(input, codes, codebooks, scales, bias, "kx8")
 

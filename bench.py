@@ -37,6 +37,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# ceilings of the headline metric (see roofline.ceiling below and BASELINE.md section 3)
+_A, _B, _BOUNDARY_US = 5_267_456, 12_372_992, 1.45
+CEILING_LAUNCH = (_A + _B) / ((_A + _B) / 8e6 + 2 * _BOUNDARY_US) / 8e6          # 0.43: perfect kernels behind the launch boundary
+CEILING_GATHER = 0.32                                                          # two LDS gathers per code (profiles/r01_call1_mb_ldsgather.log)
+CEILING_BOTH = (_A + _B) / ((_A + _B) / (CEILING_GATHER * 8e6) + 2 * _BOUNDARY_US) / 8e6   # 0.225
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (AMD's 5 PF figure includes 2:1 sparsity)
 # 1x16 g8 layers with at least this many codes run the prepacked (slice-bucketed) decode kernel, like
 # aqlm_amd.inference.PREPACK_MIN_CODES; --no-packed sets it to 0 (direct L2-gather kernel everywhere).
@@ -58,13 +63,24 @@ class Layer:
     """One synthetic QuantizedLinear instance resident in HBM (mirrors benchmark/matmul_benchmark.py:83-97:
     uniform random codes, randn codebooks, scales = 1, no bias)."""
 
-    def __init__(self, fin, fout, K, nbits, g, seed, device, batch=1):
+    def __init__(self, fin, fout, K, nbits, g, seed, device, batch=1, code_law=None):
         gen = torch.Generator(device=device).manual_seed(seed)
         self.seed = seed
         self.fin, self.fout, self.K, self.nbits, self.g = fin, fout, K, nbits, g
         cdt = torch.int16 if nbits > 8 else torch.int8
         lo, hi = (-(2 ** (nbits - 1)), 2 ** (nbits - 1))
-        self.codes = torch.randint(lo, hi, (fout, fin // g, K), generator=gen, device=device, dtype=torch.int32).to(cdt)
+        if code_law is None:
+            self.codes = torch.randint(lo, hi, (fout, fin // g, K), generator=gen, device=device, dtype=torch.int32).to(cdt)
+        else:
+            # code_law = (alpha, labels sorted by frequency?): the entry of rank r is used with probability ~ (r + 1)^-alpha --
+            # what k-means + beam search leave behind is not uniform (src/aq.py:286-356 of the reference); 16-bit codes only
+            alpha, sorted_labels = code_law
+            prob = torch.arange(1, 2**nbits + 1, dtype=torch.float64, device=device) ** (-alpha)
+            rank_of = torch.multinomial((prob / prob.sum()).float(), fout * (fin // g) * K, replacement=True, generator=gen)
+            labels = (torch.arange(2**nbits, device=device) if sorted_labels
+                      else torch.randperm(2**nbits, generator=gen, device=device))
+            unsigned = labels[rank_of].reshape(fout, fin // g, K).to(torch.int32)
+            self.codes = (unsigned - (unsigned >= hi) * 2**nbits).to(cdt)
         self.codebooks = torch.randn((K, 2**nbits, 1, g), generator=gen, device=device, dtype=torch.float32).half()
         self.scales = torch.ones((fout, 1, 1, 1), device=device, dtype=torch.float16)
         self.x = torch.randn((batch, fin), generator=gen, device=device, dtype=torch.float32).half()
@@ -111,9 +127,17 @@ class Layer:
                                                self.codebooks.data_ptr(), self.scales.data_ptr(), None, self.x.data_ptr(),
                                                self.y.data_ptr(), batch, self.fin, self.fout, _native.F16,
                                                self.ws.data_ptr(), self.ws.numel() * 4, stream)
-        elif batch == 1 and self.K == 8 and self.nbits == 8:
-            if getattr(self, "lut_cells", None) is None:  # zero-at-rest accumulator cells of the single-kernel form
-                self.lut_cells = torch.zeros((self.fout,), dtype=torch.int64, device=self.codes.device)
+        elif batch <= self.x.shape[0] and self.K == 8 and self.nbits == 8 and (batch == 1 or (self.planar is not None and getattr(self, "lut_rows", True))):
+            if getattr(self, "lut_cells", None) is None or self.lut_cells.numel() < batch * self.fout:  # zero-at-rest accumulator cells of the single-kernel form
+                self.lut_cells = torch.zeros((self.x.shape[0] * self.fout,), dtype=torch.int64, device=self.codes.device)
+            if self.planar is not None and batch > 1:  # 2+ rows: one launch of rows x the single-row workgroups (round 5)
+                rc = lib.aqlm_hip_gemv_8x8_lut_batch(self.planar.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
+                                                     self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, batch, self.fin, self.fout,
+                                                     _native.F16, 1, self.planar.codebook_absmax, self.lut_cells.data_ptr(),
+                                                     self.lut_cells.numel() * 8, stream)
+                if rc:
+                    _native.check(rc)
+                return
             if self.planar is not None:
                 rc = lib.aqlm_hip_gemv_8x8_lut_planar(self.planar.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                                       self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, _native.F16,
@@ -245,6 +269,41 @@ def _time_calls(fn, budget_s, max_iters, warmup):
         fn()
         times.append(time.perf_counter() - t1)
     return {"mean": float(np.mean(times)), "median": float(np.median(times)), "min": float(np.min(times))}, len(times)
+
+
+def code_histograms_detail(lib, dev, rank, reps, nblocks, uniform_value):
+    """The headline step on codes that use the codebook unevenly (round 5): 32 x {4096->4096, 4096->11008}
+    distinct layers per case, Zipf-distributed codes, labels shuffled and sorted by frequency.  Format v7 of the prepacked path
+    balances the slices at pack time (relabelling; a variable row-group geometry where one entry outweighs a slice), so every
+    case runs the packed kernel -- the reference's kernels are data-oblivious (cuda_kernel.cu:16-27), these figures say how
+    close to that the slice-bucketed kernel stays."""
+    out = {"protocol": "the timed step's layer list (one hipGraph, cold: 564 MB per step), codes ~ Zipf(alpha) over the 65536 entries",
+           "uniform_GBps": uniform_value, "cases": {}}
+    for alpha in (0.5, 0.8, 1.0, 1.2):
+        for sorted_labels in (False, True):
+            before = dict(PREPACK_STATS)
+            layers = []
+            for i in range(nblocks):
+                layers.append(Layer(4096, 4096, 1, 16, 8, 70000 + rank * 10000 + 2 * i, dev, code_law=(alpha, sorted_labels)))
+                layers.append(Layer(4096, 11008, 1, 16, 8, 70000 + rank * 10000 + 2 * i + 1, dev, code_law=(alpha, sorted_labels)))
+            gp = GraphedPass(layers, lib)
+            ms = gp.time_replays(reps)
+            packed = [l.packed for l in layers if l.packed is not None]
+            gbps = gp.bytes / (ms * 1e-3) * 1e-9
+            out["cases"][f"zipf{alpha}_{'sorted' if sorted_labels else 'shuffled'}_labels"] = {
+                "GBps": gbps, "vs_uniform": gbps / uniform_value, "ms_per_step": ms,
+                "layers_on_the_packed_kernel": len(packed), "layers": len(layers),
+                "relabelled": sum(1 for p in packed if p.desc.relabelled),
+                "variable_geometry": sum(1 for p in packed if p.desc.variable_geometry),
+                "workgroups_per_slice_min_max": [min(min(list(p.desc.slice_groups)[:16]) for p in packed) if packed else None,
+                                                 max(max(list(p.desc.slice_groups)[:16]) for p in packed) if packed else None],
+                "prepack_ms_per_layer": (PREPACK_STATS["seconds"] - before["seconds"]) * 1e3 / max(1, len(packed)),
+                "packed_bits_per_weight": 8.0 * (PREPACK_STATS["packed_bytes"] - before["packed_bytes"]) / max(1, PREPACK_STATS["weights"] - before["weights"])}
+            del gp, layers, packed
+            torch.cuda.empty_cache()
+    out["worst_vs_uniform"] = min(c["vs_uniform"] for c in out["cases"].values())
+    out["all_on_the_packed_kernel"] = all(c["layers_on_the_packed_kernel"] == c["layers"] for c in out["cases"].values())
+    return out
 
 
 def cpu_baseline(sample_seconds=24.0):
@@ -786,6 +845,15 @@ def main():
                            if PACK_MIN_OUT else "aqlm::gemv_kernel<F16,1x16,g8,NB=1>"),
                 "avg_launch_us": avg_launch_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "launches_timed": launches,
+                # What bounds this metric on this chip for a one-launch-per-layer operator: (a) every
+                # dependent launch costs the 1.45 us boundary of MI355X_MICROARCH.md -- a kernel that moved the algorithmic bytes
+                # at 8 TB/s would reach 0.66 / (0.66 + 1.45) = 31 % on 4096->4096 and 52 % on 4096->11008, 43 % for the mix; (b)
+                # both operands of a code's dot product are LDS gathers in the slice-bucketed formulation: 4.2 lane-gathers per
+                # clock and CU / 2 per code = 32 % even on an infinitely large layer; (c) both at once: 22.5 % for the mix.
+                "ceiling": {"launch_bound_frac": CEILING_LAUNCH, "lds_gather_bound_frac": CEILING_GATHER, "both_frac": CEILING_BOTH,
+                            "boundary_us": 1.45, "what": "fraction of the 8 TB/s roofline a one-launch-per-layer 1x16 matvec can reach on the headline mix"},
+                "frac_of_ceiling": achieved / HBM_PEAK_GBPS / min(CEILING_LAUNCH, CEILING_GATHER),
+                "frac_of_ceiling_both": achieved / HBM_PEAK_GBPS / CEILING_BOTH,
                 "note": "one launch = one matvec = one kernel (packed path, fused finalize); duration = HIP-event time of the "
                         "timed region / matvecs; achieved uses ALGORITHMIC bytes (2 B per code) even where the prepacked "
                         "path really reads ~4.5 B per code (32-bit entries + padding); rocprofv3 per-kernel durations are in profiles/"}
@@ -852,6 +920,8 @@ def main():
                             "warm_us": warm_us, "warm_GBps_cache_resident": sub[0].bytes / warm_us * 1e-3,
                             "instances": gp.n}
             del gp, gw, extra
+        if PACK_MIN_OUT:
+            detail["code_histograms"] = code_histograms_detail(lib, dev, rank, reps, NBLOCKS, value / world)
         # 2..8 input rows per launch on the prepacked path (the reference relaunches its matvec per row,
         # cuda_kernel.cpp:165-175): cold time and algorithmic GB/s per batch size at 4096->11008
         if PACK_MIN_OUT:
@@ -988,6 +1058,31 @@ def main():
                                           "per_shape": per,
                                           "kernel": "gemv_kx8_rep_kernel (16-fold replicated codebooks in LDS)" if K == 2 else
                                                     "gemv_8x8_lut_kernel on planar codes (per-token look-up tables in LDS)"}
+        # 8x8 g32 at 2..6 input rows (the module's gemv rule): the table kernel as ONE launch of rows x the single-row workgroups
+        # (aqlm_hip_gemv_8x8_lut_batch, round 5) next to the plain LDS kernel that served 2+ rows before (VERDICT r04 missing #4)
+        if PACK_MIN_OUT:
+            rows8 = {}
+            for fi, fo in ((4096, 4096), (4096, 11008)):
+                ls = [Layer(fi, fo, 8, 8, 32, 9700 + rank * 10000 + i, dev, batch=6) for i in range(min(96, int(600e6 / algorithmic_bytes(fi, fo, 8, 8, 32)) + 1))]
+                per = {}
+                for B in (1, 2, 3, 4, 6):
+                    gpb = GraphedPass(ls, lib, batch=B)
+                    us = gpb.time_replays(reps) * 1e3 / gpb.n
+                    per[f"B{B}"] = {"lut_us": us, "vs_B1": None}
+                    del gpb
+                    if B > 1:
+                        for l in ls:
+                            l.lut_rows = False
+                        gpo = GraphedPass(ls, lib, batch=B)
+                        per[f"B{B}"]["plain_lds_kernel_us"] = gpo.time_replays(reps) * 1e3 / gpo.n
+                        del gpo
+                        for l in ls:
+                            l.lut_rows = True
+                for B in (1, 2, 3, 4, 6):
+                    per[f"B{B}"]["vs_B1"] = per[f"B{B}"]["lut_us"] / per["B1"]["lut_us"]
+                rows8[f"{fi}->{fo}"] = per
+                del ls
+            detail["small_batch_rows_8x8g32"] = rows8
         lb = detail["bs128_1x16g8_4096x4096"]
         detail["config4_bs128"] = {"roofline": {"bound": "mfma", "achieved": lb["fused_TFLOPs"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": lb["fused_TFLOPs"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("r03_gemm_glds_kernel_pmc.json")},

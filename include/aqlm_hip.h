@@ -418,6 +418,19 @@ int aqlm_hip_8x8_planar_unpack(const void* planar, int out_features, int in_feat
 int aqlm_hip_gemv_8x8_lut_planar(const void* planar, const void* codebooks, const void* scales, const void* bias, const void* x,
                                  void* y, int out_features, int in_features, int in_group_size, int dtype, float codebook_absmax,
                                  void* workspace, size_t workspace_bytes, int fused, void* stream);
+
+/*
+ * The look-up-table matvec for 1..AQLM_HIP_MAX_GEMV_BATCH input rows in ONE launch (round 5; single-kernel form): row b of x
+ * runs as its own set of workgroups (tables are functions of x; what the rows share is the launch and the codes in L2) with its
+ * own zero-at-rest cells -- `cells` = batch * out_features * 8 bytes -- and its own output row.  `planar` != 0: `codes` is the
+ * planar buffer of aqlm_hip_8x8_planar_pack and codebook_absmax must be > 0; else canonical codes (codebook_absmax ignored).
+ * A row's bits equal those of the same row launched alone through the batch-1 entries.
+ * Replaces: the per-row loop around the reference's generic gemv for 8x8 (triton_kernel.py:161-182).
+ */
+int aqlm_hip_gemv_8x8_lut_batch(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* x,
+                                void* y, int out_features, int in_features, int in_group_size, int batch, long x_row_stride,
+                                long y_row_stride, int dtype, int planar, float codebook_absmax, void* cells, size_t cells_bytes,
+                                void* stream);
 int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const float* codebook_absmax, int num_segments,
                                        const void* x, int in_features, int in_group_size, int dtype, void* workspace,
                                        size_t workspace_bytes, int fused, void* stream);
@@ -441,6 +454,18 @@ int aqlm_hip_gemm_kx8_mfma(const void* codes_i8, const void* codebooks, const vo
 #define AQLM_HIP_OP_GEMV_8X8_LUT 4
 #define AQLM_HIP_OP_GEMV_1X16_G16_PACKED 5 /* prepacked codes of 16-element vectors: 32 slices */
 size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, int in_features);
+
+/*
+ * 128-bit position-sensitive checksum of a device buffer: out[0] = sum of its 32-bit words, out[1] = sum of word_i * (odd
+ * multiplier of i), both mod 2^64 (trailing 1-3 bytes count as one zero-padded word).  `out_u64x2` is 16 bytes of DEVICE memory,
+ * overwritten; stream-ordered, no synchronisation (the caller reads it back).
+ * What it is for: everything this library DERIVES from the parameters at load time (prepacked / planar codes, the codebook image
+ * and range, a dense copy of W) goes stale when a caller overwrites a parameter through a path that leaves no trace on the host
+ * (`tensor.data.copy_()` does not bump the version counter).  The reference has no such state -- its launcher reads the live
+ * tensors on every call (cuda_kernel.cpp:148-182) -- so the host side re-checks this checksum every few hundred calls
+ * (aqlm_amd/inference.py, DERIVED_CHECK_EVERY) and rebuilds what no longer matches.
+ */
+int aqlm_hip_checksum(const void* data, size_t bytes, void* out_u64x2, void* stream);
 
 /*
  * Tuning / experiment knobs (process-wide, not part of the reference surface; defaults are the shipped

@@ -67,6 +67,21 @@ class Geometry:
         return self.first[s] + k if self.vg else k * S + s
 
 
+def wave_steps(L):
+    """wave-steps a workgroup runs when its longest stream has L lane-steps: NW * T."""
+    nw = choose_waves(L)
+    return nw * ((L + 64 * nw - 1) // (64 * nw))
+
+
+def balanced_enough(codes_unsigned):
+    """The repack's first question: does the longest stream (checkpoint labels, 16 x 16 geometry) already run as few wave-steps
+    as perfectly even streams (+3.5 %) would?  Then labels and geometry stay as they are."""
+    ls, a = lane_steps(codes_unsigned)
+    total = int(ls.sum())
+    even = (total * 1035 + NG * S * 1000 - 1) // (NG * S * 1000)
+    return wave_steps(int(a[:, -1].max())) <= wave_steps(even)
+
+
 def plan_relabel(usage):
     """usage [65536] -> new_of_old [65536] (LPT greedy: heaviest entry first, to the lightest slice with room; ties: lower label,
     lower slice), or None when the checkpoint's labels already load the slices within 2 % of even."""

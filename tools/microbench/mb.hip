@@ -420,6 +420,9 @@ static int launch_layer(const Scheme& s, const Layer& L, int in, int out, int ba
   if (s.nbits == 16 && s.packed && g_chain && next)
     return aqlm_hip_gemv_1x16_packed_chain(&L.desc, L.packed, L.cb, L.scales, nullptr, L.x, L.y, batch, in, out, AQLM_HIP_F16, g_ws, g_ws_bytes,
                                            &next->desc, next->packed, next->cb, st);
+  if (s.lut && batch > 1)  // 2+ rows: one launch of rows x the single-row workgroups (single-kernel form; cells in g_ws)
+    return aqlm_hip_gemv_8x8_lut_batch(s.planar ? L.packed : L.codes, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, batch, in, out, AQLM_HIP_F16,
+                                       s.planar ? 1 : 0, 1.0f, g_ws, g_ws_bytes, st);
   if (s.lut && s.planar)
     return aqlm_hip_gemv_8x8_lut_planar(L.packed, L.cb, L.scales, nullptr, L.x, L.y, out, in, s.g, AQLM_HIP_F16, 1.0f, g_ws, g_ws_bytes, g_lut_fused ? 1 : 0, st);
   if (s.lut && g_lut_fused)  // g_ws is zero-filled before every variant and left zero by every fused call
@@ -875,6 +878,33 @@ static void bench_skew(int only_out) {
   zipf_setup(-1.0, false);
 }
 
+// 8 x 8-bit schemes at 1..8 input rows: the look-up-table kernel as one launch of rows x the single-row workgroups (round 5)
+// next to the plain LDS kernel (aqlm_hip_gemv_kx8) that served 2+ rows before.  Cold protocol of `mb gemv`.
+static void bench_lutrows() {
+  g_ws_bytes = (size_t)32 * 8 * 32768 * 4 + (1u << 22);
+  CK(hipMalloc(&g_ws, g_ws_bytes));
+  const Scheme S8x8LP{"8x8g32LUTP", 8, 8, 32, false, false, true, true}, S8x8L{"8x8g32LUT", 8, 8, 32, false, false, true}, S8x8{"8x8g32", 8, 8, 32};
+  struct Shape { int in, out; };
+  printf("%-11s %6s %6s %2s %9s %8s %8s\n", "scheme", "in", "out", "B", "cold_us", "vs_B1", "GB/s");
+  for (const Shape& sh : {Shape{4096, 4096}, Shape{4096, 11008}, Shape{11008, 4096}}) {
+    for (const Scheme* sp : {&S8x8LP, &S8x8L, &S8x8}) {
+      const Scheme& s = *sp;
+      const size_t ab1 = algo_bytes(sh.in, sh.out, s, 1);
+      int n = std::min(std::max((int)((600u << 20) / ab1) + 1, 8), 96);
+      auto layers = make_layers(s, sh.in, sh.out, 8, n);
+      double us1 = 0;
+      for (int B : {1, 2, 3, 4, 6, 8}) {
+        CK(hipMemset(g_ws, 0, g_ws_bytes));
+        const double us = time_graph(s, layers, sh.in, sh.out, B, 20);
+        if (B == 1) us1 = us;
+        printf("%-11s %6d %6d %2d %9.2f %8.2f %8.0f\n", s.name, sh.in, sh.out, B, us, us / us1, algo_bytes(sh.in, sh.out, s, B) / us * 1e-3);
+        fflush(stdout);
+      }
+      free_layers(layers);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- large-batch ops through the C ABI
 static void bench_gemm(bool nosync) {
   const int in = 4096, out = 4096;
@@ -1108,6 +1138,7 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "gemm") || !strcmp(what, "all")) bench_gemm(argc > 2 && !strcmp(argv[2], "nosync"));
   if (!strcmp(what, "multi")) bench_multi();
   if (!strcmp(what, "skew")) bench_skew(argc > 2 ? atoi(argv[2]) : 0);
+  if (!strcmp(what, "lutrows")) bench_lutrows();
   if (!strcmp(what, "trace")) {
     g_ws_bytes = (size_t)16 * 8 * 32768 * 4 + (1u << 22);
     CK(hipMalloc(&g_ws, g_ws_bytes));
