@@ -2582,8 +2582,11 @@ extern "C" PK_API int aqlm_hip_prepack_1x16_ex(const void* codes, int out_featur
   // measured within +-1 % (profiles/r02_mb_packed_variants.log); the knob keeps the mechanism testable
   int XC = 1;
   if (AQLM_PK_XFIRST && PK_G == 8 && arrange && !packed_b1_slice_first(in_groups, G.RG) && tuning().packed_xcopies >= 1 && tuning().packed_xcopies <= 4) XC = std::min(pk_max_x_copies(in_groups), tuning().packed_xcopies);
-  // 32-bit entries by default (1-3 % faster: two operations instead of four to form an entry's addresses); 24-bit entries
-  // (-23 % bytes; wave ranges of at most 32 steps) are the compact choice for inference-only deployments
+  // 32-bit entries by default (two operations instead of four to form an entry's addresses); 24-bit entries (-23 % bytes; wave
+  // ranges of at most 32 steps) are the compact choice for inference-only deployments.  Re-measured per shape in round 5 (profiles/r05_entry_bytes_3_vs_4.md, A/B/A/B on one box): 24-bit
+  // entries cost 5.8 % on 4096 x 4096, 3.3 % on 4096 -> 11008, 3.2 % on 4096 -> 1024, 2.3 % on 8192 x 8192 and 1.3-1.4 % on
+  // 4096 <-> 14336; layers of more than 32 steps per wave (the 70B MLP) cannot take them at all.  They also keep a shared-input group
+  // off the pipelined kernel (4-byte entries only).  So they stay the opt-in compact form (tuning key 3, `prepack_model(compact=True)`).
   const int EB = (PK_G == 8 && tuning().packed_entry_bytes == 3 && T <= 32 && !G.vg) ? 3 : 4;  // (the 3-byte form exists for 16-B vectors and uniform geometry only)
   PackedLayout L, L4;
   if (!packed_layout(M, in_features, NW, T, L, XC, EB, groups, relabel) || !packed_layout(M, in_features, NW, T, L4, XC, 4, groups, relabel) ||

@@ -211,10 +211,10 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
     # (2) batch consistency: a row of the batched launch == the same row launched alone (bit-exact)
     T1 = dict(T, x=T["x"][2:3].contiguous())
     y_single = run_forward(hk, K, nbits, g, T1)[0]
-    if K == 8:  # single rows of 8x8 schemes take the look-up-table kernel: same maths, different summation order
-        check_close(y_single.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "lut vs batched")
-        with_gather = hk._gemv(T1["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "kx8")[0]
-        assert torch.equal(with_gather, y[2])
+    if K == 8:  # 1..8 rows of 8x8 schemes take the look-up-table kernel (round 5: one launch of rows x the single-row workgroups)
+        assert torch.equal(y_single, y[2])
+        with_gather = hk._gemv(T1["x"], T["codes"], T["codebooks"], T["scales"], T["bias"], "kx8")[0]  # same maths, different summation order
+        check_close(with_gather.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "lut vs LDS-gather kernel")
     elif nbits == 8:
         # single rows of big 1x8 / 2x8 layers take the replicated-LDS kernel (another reduction tree): close to the
         # batched result, and the plain LDS kernel (forced) reproduces the batched row bit for bit
@@ -1444,15 +1444,25 @@ def test_gemv_8x8_lut_rows(hk, g, fin, fout, dt):
     assert torch.equal(outs[0][2], alone_p[2][0]) and outs[1].shape == (3, fout)
     outs = hk.codekx8_matmat_multi(T["x"][:3], [T["codes"]] * 2, [T["codebooks"]] * 2, [T["scales"]] * 2, [T["bias"], None])
     assert torch.equal(outs[0][2], alone_c[2][0])
-    # under hipGraph capture on a stream whose cells exist: the multi-row launch is captured
+    # under hipGraph capture on a stream whose cells exist (one eager call on it): the multi-row launch itself is captured
     sx = T["x"][:4].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
     g_ = torch.cuda.CUDAGraph()
-    hk.code8x8_matmat_planar(sx, planar, T["codebooks"], T["scales"], T["bias"])
-    with torch.cuda.graph(g_):
-        yg = hk.code8x8_matmat_planar(sx, planar, T["codebooks"], T["scales"], T["bias"])
+    with torch.cuda.stream(side):
+        hk.code8x8_matmat_planar(sx, planar, T["codebooks"], T["scales"], T["bias"])
+        with torch.cuda.graph(g_, stream=side):
+            yg = hk.code8x8_matmat_planar(sx, planar, T["codebooks"], T["scales"], T["bias"])
     g_.replay()
     torch.cuda.synchronize()
     assert all(torch.equal(yg[b], alone_p[b][0]) for b in range(4))
+    # ... and on a stream without cells the capture takes the two-kernel form row by row: same values to fp32 rounding
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        yg2 = hk.code8x8_matmat_planar(sx, planar, T["codebooks"], T["scales"], T["bias"])
+    g2.replay()
+    torch.cuda.synchronize()
+    check_close(yg2.float().cpu().numpy(), y64[:4], dtype, "captured without cells")
     assert all(int(c.abs().max()) == 0 for c in hk.accumulator_cells()), "cells must be zero when the kernels have finished"
 
 
