@@ -56,6 +56,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "kx8_replicas")) return &t.kx8_replicas;
   if (!strcmp(key, "gemm_variant")) return &t.gemm_variant;
   if (!strcmp(key, "kx8_mfma_min_rows")) return &t.kx8_mfma_min_rows;
+  if (!strcmp(key, "kx8_xres")) return &t.kx8_xres;
   if (!strcmp(key, "gemm_debug")) return &t.gemm_debug;
   if (!strcmp(key, "gemm_store_nt")) return &t.gemm_store_nt;
   if (!strcmp(key, "force_generic")) return &t.force_generic;

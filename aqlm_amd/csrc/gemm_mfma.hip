@@ -20,6 +20,8 @@
 // (~1 lane/clk/CU) take ~2x the MFMA time, so this kernel is L2-gather bound like the gemv.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "aqlm_common.h"
 
 namespace aqlm {
@@ -1244,6 +1246,169 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   return need;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// K x 8-bit schemes at <= 16 batch rows (round 5): X RESIDENT in LDS.  The 16-row kernel above streams all of X through every
+// block's L1 and LDS (128 KiB per 16 output rows at 4096 features) behind one barrier per step; traced at 16 rows it spent its
+// time in that chain (8.1 us for ~1 us of bytes on 4096 x 4096, 18 us on 4096 -> 11008: 688 blocks x 128 KiB of X).  For the
+// batches that matter most here -- the 3..8 rows of a decode call, a 16-row speculative verify -- X is SMALL: B rows x K x 2 bytes
+// (<= 128 KiB) fit the LDS next to the codebooks.  So a workgroup loads X ONCE (LDS-DMA, all 8 waves), then walks its 16-row
+// output tiles (tile = blockIdx.x, += gridDim.x) with NOTHING left to synchronise inside a tile: the 8 waves split K, each runs
+// code (8 B per lane: its row's 4 consecutive groups = 4 k-steps) -> 2 K codebook gathers + 1 X fragment per k-step -> MFMA chains
+// on two accumulators, the partial tiles meet in LDS (double-buffered: one barrier per tile) and wave 0 scales, adds the bias,
+// rounds once and stores while the others are already in the next tile.  The k-step -> group mapping is the lane's own
+// (k-step j of quad q = groups 16 q + 4 kg + j for lane piece kg): A and B fragments only have to agree on it.
+// X image: [64-k chunk][row b < B][8 pieces of 16 B], piece index XOR-ed with s(b) = ((b >> 1) & 7) ^ ((b & 8) >> 1): the 16 lanes
+// of every LDS service group read 16 distinct bank groups (rows >= B read row B - 1: same address, broadcast).
+// Numerics: exact products, fp32 sums (per wave over its quads in order, then the 8 waves in wave order): a row's bits do not
+// depend on the other rows of the call, nor on B.
+constexpr int KR_NW = 8;
+
+struct KrParams {
+  const uint8_t* codes;      // [M][in_groups][K] u8
+  const uint8_t* codebooks;  // [K][256][8] halfs
+  const uint16_t* X;         // [B][xs]
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* Y;
+  long xs, ys;
+  int M, B, in_groups, ntiles;
+};
+
+template <int K>
+struct KrLds {
+  static constexpr uint32_t CB = 0;                                  // [K][256][16 B]
+  static constexpr uint32_t RED = (uint32_t)K * 4096u;               // [2][KR_NW][64 lanes][16 B] fp32 partial tiles
+  static constexpr uint32_t X = RED + 2u * KR_NW * 1024u;            // the X image, rounded up to whole KiB (DMA granularity)
+  static size_t total(int B, int in_features) { return (size_t)X + (((size_t)B * in_features * 2 + 1023) & ~(size_t)1023); }
+};
+
+__device__ __forceinline__ uint32_t kr_swz(uint32_t b) { return ((b >> 1) & 7u) ^ ((b & 8u) >> 1); }
+
+template <class T, int K>
+__global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParams p) {
+  using LDS = KrLds<K>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int arow = lane & 15, kg = lane >> 4;
+  const uint32_t B = (uint32_t)p.B;
+  const int nquads = p.in_groups >> 4;  // 128 k each (host: in_features % 128 == 0)
+
+  // ---- prologue: codebooks and the whole of X by LDS-DMA; the first tile's codes are requested before anything is waited for
+  if (wave < K * 4)
+    __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebooks + (size_t)wave * 1024 + lane * 16),
+                                     (glds_void_ptr)(size_t)(LDS::CB + (uint32_t)wave * 1024u), 16, 0, 0);
+  {
+    const uint32_t ppc = B * 8u;                                  // pieces per chunk
+    const uint32_t npieces = (uint32_t)(p.in_groups >> 3) * ppc;  // chunks x rows x 8
+    for (uint32_t q0 = (uint32_t)wave * 64u; q0 < npieces; q0 += KR_NW * 64u) {
+      uint32_t q = q0 + (uint32_t)lane;
+      q = q < npieces ? q : npieces - 1u;  // (the last KiB may be partly padding: any valid source will do)
+      const uint32_t c = q / ppc, r = q - c * ppc;
+      const uint32_t b = r >> 3, sl = r & 7u;
+      const uint16_t* src = p.X + (size_t)b * p.xs + (size_t)c * 64 + (size_t)(sl ^ kr_swz(b)) * 8;
+      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)src, (glds_void_ptr)(size_t)(LDS::X + q0 * 16u), 16, 0, 0);
+    }
+  }
+  const uint32_t brow = (uint32_t)arow < B ? (uint32_t)arow : B - 1u;  // batch column of this lane's B fragments
+  const uint32_t bsw = kr_swz(brow);
+  typedef typename std::conditional<K == 2, u32x2, uint32_t>::type code_t;
+  auto code_ptr = [&](int tile, int quad) -> const code_t* {
+    int r = tile * 16 + arow;
+    r = r < p.M ? r : p.M - 1;
+    return reinterpret_cast<const code_t*>(p.codes + ((size_t)r * p.in_groups + (size_t)quad * 16 + (size_t)kg * 4) * K);
+  };
+  int tile = (int)blockIdx.x;
+  code_t cnext{};
+  if (tile < p.ntiles && wave < nquads) cnext = *code_ptr(tile, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // X and the codebooks are in LDS, for good
+
+  int buf = 0;
+  for (; tile < p.ntiles; tile += (int)gridDim.x) {
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int quad = wave; quad < nquads; quad += KR_NW) {
+      const code_t cw = cnext;
+      // the next code word of this wave: the next quad of the tile, else the first quad of its next tile
+      {
+        int nq = quad + KR_NW, nt = tile;
+        if (nq >= nquads) { nq = wave; nt = tile + (int)gridDim.x; }
+        if (nt < p.ntiles && nq < nquads) cnext = *code_ptr(nt, nq);
+      }
+      uint32_t cwords[2];
+      if constexpr (K == 2) { cwords[0] = cw.x; cwords[1] = cw.y; } else { cwords[0] = cw; cwords[1] = 0u; }
+      u32x4 w[4][K], xb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t byte = K == 2 ? (cwords[j >> 1] >> (16 * (j & 1) + 8 * k)) & 0xffu : (cwords[0] >> (8 * j)) & 0xffu;
+          w[j][k] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (uint32_t)k * 4096u + byte * 16u);
+        }
+        const uint32_t c = (uint32_t)quad * 2u + (uint32_t)(kg >> 1), pc = (uint32_t)(kg & 1) * 4u + (uint32_t)j;
+        xb[j] = *(glds_u32x4_ptr)(size_t)(LDS::X + ((c * B + brow) * 8u + (pc ^ bsw)) * 16u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[(j * K + k) & 1] = mfma16<T>(w[j][k], xb[j], acc[(j * K + k) & 1]);
+    }
+    // ---- the eight K shares meet in LDS; wave 0 finishes the tile while the others start the next one
+    const f32x4 mine = acc[0] + acc[1];
+    *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)(buf * KR_NW + wave) * 1024u + (uint32_t)lane * 16u) = mine;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0) {
+      f32x4 v = mine;
+#pragma unroll
+      for (int w8 = 1; w8 < KR_NW; ++w8)  // wave order: the result does not depend on who finishes first
+        v = v + *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(buf * KR_NW + w8) * 1024u + (uint32_t)lane * 16u);
+      const int m = tile * 16 + kg * 4;
+      const int b = arow;
+      if (b < p.B && m < p.M) {
+        uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+        uint16_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mm = m + r < p.M ? m + r : p.M - 1;
+          const float sc = T::to_float(p.scales[mm]), bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+          h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
+        }
+        if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        else
+          for (int r = 0; r < 4; ++r)
+            if (m + r < p.M) dst[r] = h[r];
+      }
+    }
+    buf ^= 1;
+  }
+}
+
+// does the X-resident kernel take the call?  <= 16 rows whose image fits the LDS next to the codebooks and the partial tiles
+template <int K>
+static bool xres_fits(int B, int in_features) {
+  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K>::total(B, in_features) <= 160u * 1024u;
+}
+
+template <class T, int K>
+static int launch_kx8_xres(const KrParams& p, int in_features, hipStream_t stream) {
+  auto kern = gemm_kx8_xres_kernel<T, K>;
+  const size_t lds = KrLds<K>::total(p.B, in_features);
+  if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+  // one workgroup per CU and as many as fit its LDS (small X: two or more share a CU and overlap their latencies)
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  const int per_cu = std::max(1, std::min(4, (int)((160u * 1024u) / lds)));
+  const int grid = std::min(p.ntiles, cus * per_cu);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KR_NW * 64), lds, stream, p);
+  return check_hip(hipGetLastError(), "gemm_kx8_xres launch");
+}
+
 extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* X,
                                       void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
                                       long xs, long ys, int dtype, void* stream_) {
@@ -1268,6 +1433,31 @@ extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, 
   if (!plan_kx8(std::min(batch, 128), out_features, in_features, probe) || !aligned16(codebooks) || !aligned16(X) || xs % 8 != 0) {
     set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
     return AQLM_HIP_E_UNSUPPORTED;
+  }
+  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2>(batch, in_features) : xres_fits<1>(batch, in_features))) {
+    // <= 16 rows: X resident in LDS, no per-step synchronisation (round 5)
+    KrParams kr{};
+    kr.codes = (const uint8_t*)codes;
+    kr.codebooks = (const uint8_t*)codebooks;
+    kr.X = (const uint16_t*)X;
+    kr.scales = (const uint16_t*)scales;
+    kr.bias = (const uint16_t*)bias;
+    kr.Y = (uint16_t*)Y;
+    kr.xs = xs;
+    kr.ys = ys;
+    kr.M = out_features;
+    kr.B = batch;
+    kr.in_groups = in_features / 8;
+    kr.ntiles = (out_features + 15) / 16;
+    if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2>(kr, in_features, stream) : launch_kx8_xres<F16, 1>(kr, in_features, stream);
+    return num_codebooks == 2 ? launch_kx8_xres<BF16, 2>(kr, in_features, stream) : launch_kx8_xres<BF16, 1>(kr, in_features, stream);
+  }
+  for (int b0 = 0; b0 < batch; b0 += 128) {  // every slab is planned before anything is launched (a tail slab plans differently from the probe)
+    KxPlan r{};
+    if (!plan_kx8(std::min(128, batch - b0), out_features, in_features, r)) {
+      set_last_error("aqlm_hip_gemm_kx8_mfma: a slab of %d rows at in_features %d is outside the kernel's plans", std::min(128, batch - b0), in_features);
+      return AQLM_HIP_E_UNSUPPORTED;
+    }
   }
   for (int b0 = 0; b0 < batch; b0 += 128) {  // slabs of 128 rows (the codes are re-read per slab: they are 2 bits per weight)
     const int nb = std::min(128, batch - b0);

@@ -122,6 +122,12 @@ def _gemv(input, codes, codebooks, scales, bias, kind):
     if bias is not None:
         bias = _c(bias)
     B = x.shape[0]
+    if kind == "kx8" and B > _native.MAX_GEMV_BATCH:
+        # more rows than one matvec launch takes: ONE launch of the fused MFMA op (W never materialised) instead of slabs of 8 that
+        # each re-read all the codes -- inside aqlm_hip_gemv_kx8 every slab of >= 3 rows would take that kernel half empty anyway
+        y = _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt)
+        if y is not None:
+            return y
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
     stream = _stream_ptr(input.device)
     with _device_guard(input.device):
