@@ -664,10 +664,12 @@ static int dispatch_kx8_nb(int nb, const GemvParams& p, hipStream_t s) {
 }
 }  // namespace aqlm
 
-// 3..8 rows of a 1x8 / 2x8 g8 layer: the matvec kernels pay one more x read + 4 dot products per code and row (2x8 g8 4096^2:
-// 7.0 / 11.7 / 16.5 / 19.0 us at 2 / 3 / 6 / 8 rows), the fused dequant -> MFMA kernel costs 8.1 us for any count up to 16
-// (4096 -> 11008: 34.5 vs 17.6 us at 6 rows; profiles/r04_kx8_rows_matvec_vs_mfma.log).  From `kx8_mfma_min_rows` rows on (tuning
-// key, default 3, 0 = never) the matvec entries hand the call to aqlm_hip_gemm_kx8_mfma (same numerics: exact products, fp32 sums).
+// 2..8 rows of a 1x8 / 2x8 g8 layer: the matvec kernels pay one more x read + 4 dot products per code and row (2x8 g8 4096^2:
+// 7.0 / 11.7 / 16.5 / 19.0 us at 2 / 3 / 6 / 8 rows), the fused dequant -> MFMA op with X resident in LDS (round 5, gemm_mfma.hip)
+// costs 5.0 / 5.1 / 5.4 / 5.7 us (4096 -> 11008 at 6 rows: 34.5 vs 9.5 us; profiles/r05_gemm_kx8_xres.log).  From `kx8_mfma_min_rows`
+// rows on (tuning key, default 2, 0 = never) the matvec entries hand the call to aqlm_hip_gemm_kx8_mfma: exact products, fp32 sums
+// like the matvec kernels, and a row's bits there depend neither on the other rows nor on their number (2..16 rows) -- only the
+// single-row kernels (replicated-LDS matvec, another summation order) differ from it in the last fp32 bit before the rounding.
 static bool kx8_rows_take_mfma(int batch, int K, int G) {
   const int min_rows = aqlm::tuning().kx8_mfma_min_rows;
   return min_rows > 0 && batch >= min_rows && G == 8 && (K == 1 || K == 2) && !aqlm::tuning().force_generic;

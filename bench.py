@@ -534,123 +534,193 @@ def large_batch_detail(dev, reps):
     return out
 
 
-def sharded_70b(lib, dev, rank, world, steps):
-    """North-star config 5: Llama-3-70B 8192->28672 1x16g8 layer, split along `in` over `world` ranks, partial outputs
-    summed with an RCCL all-reduce (fp16, 56 KiB).  With world == 1 only the per-shard kernel for /8 is timed."""
+class GraphedCalls:
+    """A sequence of callables `fn(stream)` -- kernel launches through the C ABI and torch.distributed collectives alike -- captured
+    into ONE hipGraph on a side stream (after an eager pass on that stream, which also initialises the communicator), timed by
+    replays between HIP events, MAX over the ranks.  An eager RCCL call costs 20-30 us of host time and would swamp a 10-25 us
+    kernel budget; a captured one is a graph node like the kernels around it.  If a collective cannot be captured the same calls
+    are timed eagerly and `timing` says so."""
+
+    def __init__(self, calls, dev):
+        self.calls, self.dev = calls, dev
+        self.stream = torch.cuda.Stream()
+        self.timing = "hipgraph"
+        with torch.cuda.stream(self.stream):
+            for fn in calls:
+                fn(self.stream)
+        self.stream.synchronize()
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                for fn in calls:
+                    fn(torch.cuda.current_stream())
+            self.graph.replay()
+            self.stream.synchronize()
+        except Exception as e:  # noqa: BLE001 - reported in the bench line
+            self.graph, self.timing = None, f"eager ({type(e).__name__}: {str(e)[:120]})"
+            torch.cuda.synchronize()
+
+    def us_per_pass(self, reps, dist=None):
+        import torch.distributed as td
+
+        def run():
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                for fn in self.calls:
+                    fn(self.stream)
+
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):
+                run()
+        torch.cuda.synchronize()
+        if dist is not None and td.is_initialized() and td.get_world_size() > 1:
+            td.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            e0.record(self.stream)
+            for _ in range(reps):
+                run()
+            e1.record(self.stream)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        if dist is not None and td.is_initialized() and td.get_world_size() > 1:
+            t = torch.tensor([us], device=self.dev, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            us = float(t)
+        return us
+
+
+def _ensure_process_group(dev):
+    """The sharded figures run the same code at every N: at N = 1 a single-rank "nccl" (= RCCL) group stands in, so that the
+    collective's launch (captured in the graph) is part of the N = 1 point too."""
     import torch.distributed as dist
+
+    if dist.is_initialized():
+        return True
+    try:
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        return True
+    except Exception:  # noqa: BLE001 - the figures then come without a collective and say so
+        return False
+
+
+def sharded_70b(lib, dev, rank, world, steps):
+    """North-star config 5: Llama-3-70B 8192->28672 1x16g8 layer, split along `in` over the ranks, partial outputs summed with an
+    RCCL all-reduce (fp16, 56 KiB) -- and with the one-shot all-reduce over xGMI fused into the shard kernel's finalize.  The same
+    schema at every N (round 5): kernel-only and end-to-end us per layer, aggregate GB/s, `rccl_ranks`; every figure is a hipGraph
+    replay of [shard kernel, collective] x 16 distinct shards (`collective_timing`).  At N = 1 the shard is the 1/8 shard every rank
+    of 8 would run and the collective runs over one rank (its launch cost, not its wire time)."""
+    import ctypes
+
+    import torch.distributed as dist
+
+    from aqlm_amd import _native
 
     fin, fout = 8192, 28672
     parts = world if world > 1 else 8
     shard_in = fin // parts
+    have_pg = _ensure_process_group(dev)
+    ranks = dist.get_world_size() if have_pg else 1
+    reps = max(4, steps // 2)
     layers = [Layer(shard_in, fout, 1, 16, 8, 1000 + rank * 100 + i, dev) for i in range(16)]
-    gp = GraphedPass(layers, lib)
-    ms = gp.time_replays(max(4, steps // 2))
-    kernel_us = ms * 1e3 / gp.n
-    out = {"layer": "8192->28672 1x16g8", "parts": parts, "shard_in": shard_in, "kernel_us_per_shard": kernel_us,
-           "shard_algorithmic_bytes": layers[0].bytes, "kernel_GBps_per_gpu": layers[0].bytes / kernel_us * 1e-3}
+    gk = GraphedCalls([(lambda st, l=l: l.launch(lib, st.cuda_stream)) for l in layers], dev)
+    kernel_us = gk.us_per_pass(reps, dist) / len(layers)
     full_bytes = algorithmic_bytes(fin, fout)
+    out = {"layer": "8192->28672 1x16g8", "parts": parts, "rccl_ranks": ranks, "shard_in": shard_in,
+           "kernel_us_per_shard": kernel_us, "shard_algorithmic_bytes": layers[0].bytes,
+           "kernel_GBps_per_gpu": layers[0].bytes / kernel_us * 1e-3,
+           "aggregate_GBps_kernel_only": parts * layers[0].bytes / kernel_us * 1e-3,
+           "note": ("N = 1: per-shard figures of the 8-way split measured on one GPU (the collective runs over one rank: launch cost only); "
+                    "the unsharded layer on one GPU is `unsharded_one_gpu`" if world == 1 else "in-split over the ranks, one collective per layer")}
     if world == 1:
-        # the N = 1 point of the 1 / 2 / 4 / 8-GPU series: the UNSHARDED layer on one GPU, same quantity as the
-        # `aggregate_GBps_end_to_end` of the sharded runs (algorithmic bytes of the whole layer / time of one layer)
         whole = [Layer(fin, fout, 1, 16, 8, 1500 + i, dev) for i in range(12)]
         gw = GraphedPass(whole, lib)
-        us = gw.time_replays(max(4, steps // 2)) * 1e3 / gw.n
-        out.update({"end_to_end_us": us, "aggregate_GBps_end_to_end": full_bytes / us * 1e-3,
-                    "collective": "none (1 GPU: the whole 8192->28672 layer in one launch; the /8 shard kernel above is what each "
-                                  "of 8 GPUs would run)"})
+        us = gw.time_replays(reps) * 1e3 / gw.n
+        out["unsharded_one_gpu"] = {"end_to_end_us": us, "aggregate_GBps_end_to_end": full_bytes / us * 1e-3,
+                                    "collective": "none (the whole 8192->28672 layer in one launch)"}
         del gw, whole
-    if world > 1:
-        s = torch.cuda.current_stream()
-        y = layers[0].y
-        for _ in range(5):
-            layers[0].launch(lib, s.cuda_stream)
-            dist.all_reduce(y)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        n = 50
-        for i in range(n):
-            layers[i % len(layers)].launch(lib, s.cuda_stream)
-            dist.all_reduce(layers[i % len(layers)].y)
-        torch.cuda.synchronize()
-        dt = torch.tensor([(time.perf_counter() - t0) / n], device=dev)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        e2e_us = float(dt.item()) * 1e6
-        out.update({"end_to_end_us": e2e_us, "allreduce_bytes": fout * 2, "end_to_end_us_rccl": e2e_us,
-                    "aggregate_GBps_kernel_only": world * layers[0].bytes / kernel_us * 1e-3,
-                    "aggregate_GBps_end_to_end": full_bytes / e2e_us * 1e-3,
-                    "collective": "RCCL all-reduce (fp16, 56 KiB) behind the shard kernel"})
-        # the MI355X-native variant: finalize fused with a one-shot all-reduce over xGMI (aqlm_amd/csrc/xgmi_reduce.hip).
-        # Every rank first agrees that it can run it (peer access to every other GPU of the node); any failure is
-        # reported, never fatal -- the RCCL figure above stands on its own.
-        try:
-            import ctypes
+    if have_pg:
+        def with_rccl(l):
+            def fn(st):
+                l.launch(lib, st.cuda_stream)
+                dist.all_reduce(l.y)
+            return fn
 
-            from aqlm_amd import _native
-            from aqlm_amd.xgmi import OneShotAllReduce
+        gr = GraphedCalls([with_rccl(l) for l in layers], dev)
+        e2e_us = gr.us_per_pass(reps, dist) / len(layers)
+        out.update({"end_to_end_us": e2e_us, "end_to_end_us_rccl": e2e_us, "allreduce_bytes": fout * 2, "collective_timing": gr.timing,
+                    "aggregate_GBps_end_to_end": full_bytes / e2e_us * 1e-3, "aggregate_GBps_end_to_end_rccl": full_bytes / e2e_us * 1e-3,
+                    "collective": "RCCL all-reduce (fp16, 56 KiB) behind the shard kernel, both in one hipGraph"})
+        del gr
+    # the MI355X-native variant: finalize fused with a one-shot all-reduce over xGMI (aqlm_amd/csrc/xgmi_reduce.hip).  Every rank
+    # first agrees that it can run it (peer access to every other GPU of the node); any failure is reported, never fatal
+    try:
+        from aqlm_amd.xgmi import OneShotAllReduce
 
-            can = all(r == torch.cuda.current_device() or torch.cuda.can_device_access_peer(torch.cuda.current_device(), r)
-                      for r in range(torch.cuda.device_count())) and all(l.packed is not None for l in layers)
-            flag = torch.tensor([1 if can else 0], device=dev)
+        can = all(r == torch.cuda.current_device() or torch.cuda.can_device_access_peer(torch.cuda.current_device(), r)
+                  for r in range(torch.cuda.device_count())) and all(l.packed is not None and not l.packed.desc.variable_geometry for l in layers)
+        flag = torch.tensor([1 if (can and have_pg) else 0], device=dev)
+        if have_pg:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag):
-                ar = OneShotAllReduce(fout, dev, spin_limit=1 << 19)  # ~0.25 s per wait at most: a lost peer must not stall the bench
-                sc = layers[0].scales
+        if int(flag):
+            ar = OneShotAllReduce(fout, dev, spin_limit=1 << 19)  # ~0.25 s per wait at most: a lost peer must not stall the bench
+            sc = layers[0].scales
+            pub_own, flag_own = ar.own_pub_flag()
 
-                pub_own, flag_own = ar.own_pub_flag()
-
-                def fused(l):  # two launches: the shard's matvec publishes its totals itself, then the reduce
-                    rc = lib.aqlm_hip_gemv_1x16_packed_publish(ctypes.byref(l.packed.desc), l.packed.data_ptr(),
-                                                               l.codebooks.data_ptr(), l.x.data_ptr(), 1, l.fin, _native.F16,
-                                                               ctypes.byref(ar.xg), pub_own, flag_own, s.cuda_stream)
+            def fused(l):  # two launches: the shard's matvec publishes its totals itself, then the reduce
+                def fn(st):
+                    rc = lib.aqlm_hip_gemv_1x16_packed_publish(ctypes.byref(l.packed.desc), l.packed.data_ptr(), l.codebooks.data_ptr(),
+                                                               l.x.data_ptr(), 1, l.fin, _native.F16, ctypes.byref(ar.xg), pub_own, flag_own,
+                                                               st.cuda_stream)
                     if rc:
                         _native.check(rc)
-                    ar.reduce(sc, None, l.y, fout, 1, _native.F16, s.cuda_stream)
+                    ar.reduce(sc, None, l.y, fout, 1, _native.F16, st.cuda_stream)
+                return fn
 
-                fused(layers[0])
-                torch.cuda.synchronize()
-                bad = torch.tensor([1 if ar.timed_out() else 0], device=dev)
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if int(bad):  # every rank leaves together (the collectives below must stay matched)
-                    raise RuntimeError("one-shot all-reduce: a peer's flag never arrived (IPC mapping over xGMI not working here)")
-                for _ in range(4):
-                    fused(layers[0])
-                torch.cuda.synchronize()
-                y_native = layers[0].y.float().clone()
-                layers[0].launch(lib, s.cuda_stream)
-                y32 = layers[0].y.float()
-                dist.all_reduce(y32)
-                rel = float((y_native - y32).abs().mean() / y32.abs().mean())
-                dist.barrier()
-                t0 = time.perf_counter()
-                for i in range(n):
-                    fused(layers[i % len(layers)])
-                torch.cuda.synchronize()
-                dt = torch.tensor([(time.perf_counter() - t0) / n], device=dev)
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                x_us = float(dt.item()) * 1e6
-                out["xgmi_one_shot"] = {"end_to_end_us": x_us, "aggregate_GBps_end_to_end": full_bytes / x_us * 1e-3,
-                                        "mean_rel_vs_rccl_fp32_sum": rel, "timed_out": ar.timed_out(),
-                                        "note": "shard kernel (publishes its fp32 totals) -> reduce over xGMI: 2 launches, fp32 on the wire, no RCCL launch"}
-                if x_us < out["end_to_end_us"]:  # the headline of the series is the better of the two collectives
-                    out.update({"end_to_end_us": x_us, "aggregate_GBps_end_to_end": full_bytes / x_us * 1e-3,
-                                "collective": "one-shot all-reduce over xGMI fused into the shard kernel's finalize (RCCL figure: end_to_end_us_rccl)"})
-            else:
-                out["xgmi_one_shot"] = {"skipped": "no peer access between all GPUs of the node, or a shard is not prepacked"}
-        except Exception as e:  # noqa: BLE001 - diagnostics only
-            out["xgmi_one_shot"] = {"error": f"{type(e).__name__}: {e}"}
-    out["mlp_plans"] = sharded_mlp_plans(lib, dev, rank, world, steps)
+            s = torch.cuda.current_stream()
+            fused(layers[0])(s)
+            torch.cuda.synchronize()
+            bad = torch.tensor([1 if ar.timed_out() else 0], device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad):  # every rank leaves together (the collectives below must stay matched)
+                raise RuntimeError("one-shot all-reduce: a peer's flag never arrived (IPC mapping over xGMI not working here)")
+            y_native = layers[0].y.float().clone()
+            layers[0].launch(lib, s.cuda_stream)
+            y32 = layers[0].y.float()
+            dist.all_reduce(y32)
+            rel = float((y_native - y32).abs().mean() / y32.abs().mean())
+            gx = GraphedCalls([fused(l) for l in layers], dev)
+            x_us = gx.us_per_pass(reps, dist) / len(layers)
+            out["xgmi_one_shot"] = {"end_to_end_us": x_us, "aggregate_GBps_end_to_end": full_bytes / x_us * 1e-3, "collective_timing": gx.timing,
+                                    "mean_rel_vs_rccl_fp32_sum": rel, "timed_out": ar.timed_out(),
+                                    "note": "shard kernel (publishes its fp32 totals) -> reduce over xGMI: 2 launches, fp32 on the wire, no RCCL launch"}
+            if "end_to_end_us" not in out or x_us < out["end_to_end_us"]:  # the headline of the series is the better of the two collectives
+                out.update({"end_to_end_us": x_us, "aggregate_GBps_end_to_end": full_bytes / x_us * 1e-3,
+                            "collective": "one-shot all-reduce over xGMI fused into the shard kernel's finalize (RCCL figure: end_to_end_us_rccl)"})
+            del gx
+        else:
+            out["xgmi_one_shot"] = {"skipped": "no peer access between all GPUs of the node, no process group, or a shard is not prepacked on the 16 x 16 geometry"}
+    except Exception as e:  # noqa: BLE001 - diagnostics only
+        out["xgmi_one_shot"] = {"error": f"{type(e).__name__}: {e}"}
+    del gk
+    out["mlp_plans"] = sharded_mlp_plans(lib, dev, rank, world, steps, have_pg)
     return out
 
 
-def sharded_mlp_plans(lib, dev, rank, world, steps):
+def sharded_mlp_plans(lib, dev, rank, world, steps, have_pg=True):
     """The Llama-3-70B MLP (gate, up: 8192 -> 28672; down: 28672 -> 8192) under the two tensor-parallel plans of SURVEY.md 8(e), per rank:
       * in-split everywhere (north-star config 5 applied to every layer): gate / up shards 8192/N -> 28672, down 28672/N -> 8192,
         THREE all-reduces (28672, 28672, 8192 values);
-      * Megatron pairing (aqlm_amd.sharded.shard_mlp): gate / up out-split 8192 -> 28672/N with NO collective, down in-split on the
-        same cut, ONE all-reduce of 8192 values.
-    With world == 1 the shard shapes of N = 8 are timed without collectives (what every rank of 8 would run): the pairing's kernels
-    are cheaper before any collective is counted."""
+      * Megatron pairing (aqlm_amd.sharded.shard_mlp): gate / up out-split 8192 -> 28672/N with NO collective -- both multiply the same
+        x, so they run as ONE shared-input launch --, down in-split on the same cut, ONE all-reduce of 8192 values.
+    Kernels and collectives of an MLP sit in one hipGraph (6 distinct MLPs per replay); N = 1 runs the shard shapes of N = 8 with
+    single-rank collectives (their launch cost)."""
     import torch.distributed as dist
 
     parts = world if world > 1 else 8
@@ -659,39 +729,39 @@ def sharded_mlp_plans(lib, dev, rank, world, steps):
     plans = {"in_split_everywhere": [(hid // parts, inter), (hid // parts, inter), (inter // parts // 8 * 8, hid)],
              "paired": [(hid, i_sh), (hid, i_sh), (i_sh, hid)]}
     reduces = {"in_split_everywhere": [inter, inter, hid], "paired": [0, 0, hid]}
-    res = {"parts": parts, "note": "per rank: three shard matvecs per MLP (prepacked kernel), hipGraph-timed kernels; collectives "
-                                   "(fp16, RCCL) timed eagerly behind them when world > 1"}
+    reps = max(4, steps // 2)
+    res = {"parts": parts, "rccl_ranks": dist.get_world_size() if have_pg and dist.is_initialized() else 1,
+           "note": "per rank: the MLP's shard matvecs (prepacked kernel; the pairing's gate / up in one shared-input launch) and its fp16 "
+                   "RCCL all-reduces captured in ONE hipGraph per rank; us per MLP"}
     for name, shapes in plans.items():
         sets = [[Layer(fi, fo, 1, 16, 8, 2000 + rank * 100 + 10 * k + i, dev) for k, (fi, fo) in enumerate(shapes)] for i in range(6)]
-        flat = [l for st in sets for l in st]
-        gp = GraphedPass(flat, lib)
-        us = gp.time_replays(max(4, steps // 2)) * 1e3 / len(sets)
-        entry = {"shard_shapes": [f"{fi}->{fo}" for fi, fo in shapes], "kernels_us_per_mlp": us,
+        units = []  # per MLP: the launchable units in order, with the all-reduce size behind each (0 = none)
+        for st in sets:
+            if name == "paired":
+                gate, up, down = st
+                up.x = gate.x  # one hidden state
+                units.append([(FusedLayers([gate, up]), 0, None), (down, hid, down.y)])
+            else:
+                units.append([(l, n, l.y) for l, n in zip(st, reduces[name])])
+        gk = GraphedCalls([(lambda s_, u=u: u.launch(lib, s_.cuda_stream)) for mlp in units for (u, _, _) in mlp], dev)
+        k_us = gk.us_per_pass(reps, dist) / len(sets)
+        entry = {"shard_shapes": [f"{fi}->{fo}" for fi, fo in shapes], "launches_per_mlp": len(units[0]), "kernels_us_per_mlp": k_us,
                  "collectives_per_mlp": sum(1 for n in reduces[name] if n), "allreduce_values": [n for n in reduces[name] if n]}
-        if world > 1:
-            s = torch.cuda.current_stream()
-            bufs = [torch.zeros((n,), device=dev, dtype=torch.float16) if n else None for n in reduces[name]]
+        del gk
+        if have_pg:
+            def with_coll(u, n, y):
+                def fn(s_):
+                    u.launch(lib, s_.cuda_stream)
+                    if n:
+                        dist.all_reduce(y)
+                return fn
 
-            def one(st):
-                for l, b in zip(st, bufs):
-                    l.launch(lib, s.cuda_stream)
-                    if b is not None:
-                        dist.all_reduce(b)
-
-            for st in sets[:2]:
-                one(st)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            n = 30
-            for i in range(n):
-                one(sets[i % len(sets)])
-            torch.cuda.synchronize()
-            dt = torch.tensor([(time.perf_counter() - t0) / n], device=dev)
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            entry["end_to_end_us_per_mlp"] = float(dt.item()) * 1e6
+            ge = GraphedCalls([with_coll(u, n, y) for mlp in units for (u, n, y) in mlp], dev)
+            entry["end_to_end_us_per_mlp"] = ge.us_per_pass(reps, dist) / len(sets)
+            entry["collective_timing"] = ge.timing
+            del ge
         res[name] = entry
-        del gp, flat, sets
+        del units, sets
     return res
 
 
@@ -1101,6 +1171,11 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        import torch.distributed as td
+
+        if td.is_initialized():  # the single-rank group the sharded figures made for themselves at N = 1
+            td.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -220,7 +220,7 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
         # batched result, and the plain LDS kernel (forced) reproduces the batched row bit for bit
         from aqlm_amd import _native
 
-        # (and batches of 3+ rows take the fused MFMA kernel: same exact products, another summation order)
+        # (and batches of 2+ rows take the fused MFMA kernel: same exact products, another summation order)
         check_close(y_single.float().cpu().numpy(), y[2].float().cpu().numpy().astype(np.float64), dtype, "replicated vs batched")
         _native.set_tuning("kx8_replicas", 0)
         _native.set_tuning("kx8_mfma_min_rows", 0)
@@ -230,7 +230,7 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
             check_close(y.float().cpu().numpy(), y_plain.float().cpu().numpy().astype(np.float64), dtype, "mfma vs plain matvec kernel, batched")
         finally:
             _native.set_tuning("kx8_replicas", 1)
-            _native.set_tuning("kx8_mfma_min_rows", 3)
+            _native.set_tuning("kx8_mfma_min_rows", 2)
     else:
         assert torch.equal(y_single, y[2])
     # (3) zero input -> exactly the bias
@@ -402,8 +402,8 @@ def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
 def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     """The fused K x 8 MFMA op at <= 16 rows (round 5: X resident in LDS, aqlm_hip_gemm_kx8_mfma / the 3+ row route of
     aqlm_hip_gemv_kx8): fp64 oracle, the streaming 16-row kernel (tuning key kx8_xres = 0: same exact products, another summation
-    order), and batch invariance -- a row's bits depend neither on the other rows nor on how many there are (3..16), which the
-    streaming kernel behind the 3-row switch did not give (VERDICT r04 weak #1a)."""
+    order), and batch invariance -- a row's bits depend neither on the other rows nor on how many there are (2..16), which the
+    streaming kernel behind round 4's 3-row switch did not give (VERDICT r04 weak #1a)."""
     from aqlm_amd import _native
 
     dtype = tdtype(dt)
@@ -416,12 +416,12 @@ def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     y_full = op(T["x"][:rows_max], T["codes"], T["codebooks"], T["scales"], T["bias"])
     check_close(y_full.float().cpu().numpy(), y64[:rows_max], dtype, f"x-resident {K}x8 {fin}->{fout}, {rows_max} rows")
     assert torch.equal(y_full, op(T["x"][:rows_max], T["codes"], T["codebooks"], T["scales"], T["bias"]))
-    for B in (3, 4, 6, 8, 13, 16):
+    for B in (2, 3, 4, 6, 8, 13, 16):
         if B > rows_max:
             continue
         yb = op(T["x"][:B], T["codes"], T["codebooks"], T["scales"], T["bias"])
         assert torch.equal(yb, y_full[:B]), f"rows of a {B}-row call differ from the same rows of a {rows_max}-row call"
-        if B <= 8:   # the decode route: aqlm_hip_gemv_kx8 hands 3+ rows to the same kernel
+        if B <= 8:   # the decode route: aqlm_hip_gemv_kx8 hands 2+ rows to the same kernel
             assert torch.equal(raw(T["x"][:B], T["codes"], T["codebooks"], T["scales"], T["bias"]), yb)
     x2 = T["x"][:rows_max].clone()
     x2[1:] = torch.flip(x2[1:], dims=(0,))
