@@ -1112,7 +1112,7 @@ def main():
             except Exception:
                 return None
 
-        for sname, (K, nb, g), pmc in (("2x8g8", (2, 8, 8), "r04_2x8_rep_kernel_pmc.json"), ("8x8g32", (8, 8, 32), "r04_8x8_lut_planar_kernel_pmc.json")):
+        for sname, (K, nb, g), pmc in (("2x8g8", (2, 8, 8), "r05_2x8_rep_kernel_pmc.json"), ("8x8g32", (8, 8, 32), "r05_8x8_lut_planar_kernel_pmc.json")):
             per, tot_b, tot_us = {}, 0.0, 0.0
             for fi, fo in ((4096, 4096), (4096, 11008)):
                 ls = [Layer(fi, fo, K, nb, g, 9500 + rank * 10000 + i, dev) for i in range(int(600e6 / algorithmic_bytes(fi, fo, K, nb, g)) + 1)]

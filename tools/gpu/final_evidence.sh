@@ -7,6 +7,7 @@
 # Outputs land under gpurun_out/<tag>/; copy what is to be judged into profiles/ (tools/gpu/README.md).
 set +e
 TAG=${1:-final}
+RND=${2:-r05}   # prefix of the counter files copied to profiles/
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -16,7 +17,7 @@ timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_gpu.lo
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -1
 # kernel counters first: bench.py reads the traffic of configs 3 / 4 from profiles/
-for spec in "2x8g8 4096 kx8 gemv_kx8_rep_kernel r04_2x8_rep_kernel_pmc.json" "8x8g32LUTP 4096 lutp gemv_8x8_lut_kernel r04_8x8_lut_planar_kernel_pmc.json" "8x8g32LUT= 4096 lutc gemv_8x8_lut_kernel r04_8x8_lut_kernel_pmc.json"; do
+for spec in "2x8g8 4096 kx8 gemv_kx8_rep_kernel ${RND}_2x8_rep_kernel_pmc.json" "8x8g32LUTP 4096 lutp gemv_8x8_lut_kernel ${RND}_8x8_lut_planar_kernel_pmc.json" "8x8g32LUT= 4096 lutc gemv_8x8_lut_kernel ${RND}_8x8_lut_kernel_pmc.json"; do
   set -- $spec
   bash tools/gpu/gpu_pmc.sh $1 $2 ${TAG}_$3 > $OUT/pmc_$3.log 2>&1
   python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$3 $4 $OUT/$5 > /dev/null

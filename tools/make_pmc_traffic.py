@@ -29,6 +29,13 @@ def per_kernel(path, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
+def is_timed_matvec(name):
+    """Kernels of the timed step only: the 1x16 matvec kernels (packed / direct) and their finalize.  The set-up kernels of the
+    same process (the parameter checksums of round 5, the generic kernel of the parity tripwire) are listed but not averaged in --
+    round 5's first summary did average the 64 checksum launches in and reported 17.7 MB for what is 20.4 MB per matvec."""
+    return "gemv_1x16" in name or ("gemv_kernel" in name and "generic" not in name) or "finalize" in name
+
+
 def main():
     root = sys.argv[1]
     fetch = per_kernel(f"{root}/pmc_fetch", "FETCH_SIZE")
@@ -43,10 +50,13 @@ def main():
         # load-time repack kernels (pk_*_kernel) are not the hot path; pk_g8 / pk_g16 are the namespaces of the two packed builds
         if "aqlm::" not in name or "prepack" in name or re.search(r"::pk_[a-z0-9]+_kernel", name):
             continue
+        timed = is_timed_matvec(name)
         f, nf = fetch.get(name, (0.0, 0))
         w, _ = write.get(name, (0.0, 0))
         hbm = 2 * f * 1024 + w * 1024
-        out["per_kernel"][name[:110]] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": hbm, "launches": nf}
+        out["per_kernel"][name[:110]] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": hbm, "launches": nf, "in_the_timed_step": timed}
+        if not timed:
+            continue
         total += hbm * nf
         if "finalize" not in name:
             launches += nf
@@ -54,7 +64,7 @@ def main():
     out["how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 4 --warmup 1 "
                   "--no-detail --no-cpu`, read bytes = 2 x FETCH_SIZE x 1024 (gfx950), tools/make_pmc_traffic.py")
     out["note"] = ("per matvec of the bench step = (all matvec kernels of the timed launches) / number of matvecs; "
-                   "algorithmic bytes per matvec 8 820 224: the prepacked path (format v6, 32-bit entries) reads ~4.5 B per "
+                   "algorithmic bytes per matvec 8 820 224: the prepacked path (32-bit entries) reads ~4.5-4.8 B per "
                    "code plus the row-start table and the codebook slices")
     json.dump(out, sys.stdout, indent=1)
 
