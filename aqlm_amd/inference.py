@@ -196,8 +196,10 @@ class QuantizedLinear(nn.Module):
 
             if isinstance(packed, hip_kernel.PlanarCodes):
                 # 8x8 on planar codes: the look-up-table matvec takes the gemv rule's 1..6 rows (2+: one launch of rows x the
-                # single-row workgroups); anything else goes through the ordinary ops below
-                if input.numel() >= input.shape[-1] > 0:
+                # single-row workgroups); anything else goes through the ordinary ops below.  8x8 g32 calls of
+                # fused_8x8_min_rows(layer)+ rows (3 at 4096 x 4096) go to the ops too while the checkpoint-layout codes are there:
+                # the fused MFMA kernel (aqlm_hip_gemm_8x8_mfma, round 5) costs the same for 3 rows as for 16.
+                if input.numel() >= input.shape[-1] > 0 and not self._rows_take_the_fused_8x8_op(input):
                     if torch.compiler.is_compiling():  # traced: the dispatcher op (it has a fake implementation)
                         return torch.ops.aqlm.code8x8_matmat_planar(input, packed.buf, self.codebooks, self.scales, self.bias,
                                                                     [packed.out_features, packed.in_features, packed.in_group_size],
@@ -214,6 +216,14 @@ class QuantizedLinear(nn.Module):
             return torch.nn.functional.linear(input, self._dense_weight(), self.bias)
         op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
         return op.apply(input, self._canonical_codes(), self.codebooks, self.scales, self.bias)
+
+    def _rows_take_the_fused_8x8_op(self, input: torch.Tensor) -> bool:
+        from .inference_kernels import hip_kernel
+
+        return (hip_kernel.USE_FUSED_8X8_MFMA and not self._codes_dropped and self.in_group_size == 32 and self.in_features % 256 == 0
+                and self.in_features >= 2048
+                and math.prod(input.shape[:-1]) >= hip_kernel.fused_8x8_min_rows(self.out_features, self.in_features)
+                and not torch.compiler.is_compiling())
 
     def _dense_weight(self) -> torch.Tensor:
         """W in the storage dtype, dequantised once and kept while codes / codebooks / scales are what they were (identity +
@@ -404,9 +414,14 @@ class QuantizedLinear(nn.Module):
             kind, buf, desc = _front.KIND_GEMV_KX8, None, ""
         else:
             return
+        max_rows = GEMV_MAX_ROWS
+        if (kind == _front.KIND_LUT_PLANAR_8X8 and hip_kernel.USE_FUSED_8X8_MFMA and not self._codes_dropped and self.in_group_size == 32
+                and self.in_features % 256 == 0 and self.in_features >= 2048):
+            # more rows: the fused MFMA op (forward hands them over)
+            max_rows = min(max_rows, hip_kernel.fused_8x8_min_rows(self.out_features, self.in_features) - 1)
         try:
             self._fast = _front.ext.FastLinear(self._parameters, kind, buf, desc, self.in_features, self.out_features,
-                                               self.num_codebooks, self.in_group_size, not self._codes_dropped, GEMV_MAX_ROWS)
+                                               self.num_codebooks, self.in_group_size, not self._codes_dropped, max_rows)
         except RuntimeError:
             self._fast = None
 

@@ -1082,6 +1082,11 @@ def codekx8_matmat(input, codes, codebooks, scales, bias=None):
     (kernel_selector.py:91-94, triton_kernel.py:187-205)."""
     if codebooks.shape[1] != 256:
         raise NotImplementedError(f"codekx8_matmat needs 256-entry codebooks, got {tuple(codebooks.shape)}")
+    if (codebooks.shape[0] == 8 and codebooks.shape[3] == 32 and input.dtype == codebooks.dtype and input.dtype in _DT and codes.dim() == 3
+            and _lut_rows(input) >= fused_8x8_min_rows(codes.shape[0], codes.shape[1] * 32)):
+        y = _fused_8x8_mfma(input, codes, codebooks, scales, bias, _DT[input.dtype])  # one MFMA per codebook, rows (<= 16) for free
+        if y is not None:
+            return y
     if (USE_8X8_LUT and codebooks.shape[0] == 8 and codebooks.shape[2] == 1 and codebooks.shape[3] in (8, 16, 32)
             and 1 <= _lut_rows(input) <= LUT_MAX_ROWS and input.dtype == codebooks.dtype):
         return _gemv_8x8_lut(input, codes, codebooks, scales, bias)
@@ -1198,6 +1203,8 @@ def _matmat_dequant_kx8(input, codes, codebooks, scales, bias):
     library GEMM, scale + bias."""
     dt = _dtype_id(input)
     y = _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt)
+    if y is None and codebooks.shape[0] == 8:
+        y = _fused_8x8_mfma(input, codes, codebooks, scales, bias, dt)
     if y is not None:
         return y
     # W without the scales: exact for one codebook, one rounding of the K-term sum otherwise (as in the reference, which
@@ -1243,6 +1250,60 @@ def _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt):
         return None
     if rc:
         _native.check(rc, "aqlm gemm_kx8_mfma")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
+# 8x8 g32 beyond one row (aqlm_hip_gemm_8x8_mfma, round 5): the codebooks in LDS, one MFMA per codebook and k-step, cost independent
+# of the number of rows up to 16 and +8 MFMAs per k-step for every further 16.  Below fused_8x8_min_rows(layer) rows the look-up-table
+# matvec (one set of workgroups per row) is faster; above FUSED_8X8_MFMA_MAX_ROWS W is dequantised once and hipBLASLt runs the GEMM,
+# as the reference does.  Numerics: exact products, fp32 sums (the table kernel: the same terms in another order).
+USE_FUSED_8X8_MFMA = True
+FUSED_8X8_MFMA_MIN_ROWS = 0   # 0 = by the measured cost model below (fused_8x8_min_rows); n > 0 = from n rows on, whatever the layer
+FUSED_8X8_MFMA_MAX_ROWS = 128
+
+
+def fused_8x8_min_rows(out_features: int, in_features: int) -> int:
+    """Rows from which the fused MFMA kernel beats the look-up-table matvec on an 8x8 g32 layer.  Both times are affine in what
+    they scale with (profiles/r05_gemm_8x8_mfma.log, r05_mb_lutrows.log; us, MI355X): the fused kernel costs 3.6 + 2.15 per round
+    of 256 sixteen-row tiles and 1024 input features, whatever the rows (<= 16); the table kernel 1.3 + rows x (3.7 + 0.05 per
+    million weights).  4096 x 4096: 3 rows; 4096 -> 11008 and 8192 x 8192: 5; 11008 -> 4096: 4."""
+    if FUSED_8X8_MFMA_MIN_ROWS > 0:
+        return FUSED_8X8_MFMA_MIN_ROWS
+    rounds = -(-(-(-out_features // 16)) // 256)
+    fused = 3.6 + 2.15 * rounds * in_features / 1024.0
+    per_row = 3.7 + 0.05 * out_features * in_features * 1e-6
+    return max(2, int((fused - 1.3) / per_row) + 1)
+
+
+def _fused_8x8_mfma(input, codes, codebooks, scales, bias, dt):
+    """The fused dequant -> MFMA kernel for 8x8 g32 on checkpoint-layout codes (W never materialised), or None when the call is
+    outside it."""
+    K, size, og, g = codebooks.shape
+    if not USE_FUSED_8X8_MFMA or K != 8 or size != 256 or og != 1 or g != 32 or codes.dtype != torch.int8 or codes.dim() != 3:
+        return None
+    in_features = codes.shape[1] * g
+    if in_features % 256 != 0 or in_features < 2048 or input.shape[-1] != in_features:
+        return None
+    if codebooks.dtype != input.dtype or scales.dtype != input.dtype or (bias is not None and bias.dtype != input.dtype):
+        return None
+    if not input.is_cuda or any(t is not None and t.device != input.device for t in (codes, codebooks, scales, bias)):
+        return None
+    x = _flat_rows(input)
+    B = x.shape[0]
+    out_features = codes.shape[0]
+    if B < 1 or B > FUSED_8X8_MFMA_MAX_ROWS:
+        return None
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    with _device_guard(input.device):
+        rc = _lib.aqlm_hip_gemm_8x8_mfma(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(), y.data_ptr(),
+                                         B, out_features, in_features, g, x.stride(0), out_features, dt, _stream_ptr(input.device))
+    if rc == _native.E_UNSUPPORTED:
+        return None
+    if rc:
+        _native.check(rc, "aqlm gemm_8x8_mfma")
     return y.reshape(input.shape[:-1] + (out_features,))
 
 

@@ -127,6 +127,10 @@ class Layer:
                                                self.codebooks.data_ptr(), self.scales.data_ptr(), None, self.x.data_ptr(),
                                                self.y.data_ptr(), batch, self.fin, self.fout, _native.F16,
                                                self.ws.data_ptr(), self.ws.numel() * 4, stream)
+        elif batch <= self.x.shape[0] and getattr(self, "fused_8x8", False) and (self.K, self.nbits, self.g) == (8, 8, 32):
+            # 8x8 g32 beyond one row: the codebooks in LDS, one MFMA per codebook and k-step (aqlm_hip_gemm_8x8_mfma, round 5)
+            rc = lib.aqlm_hip_gemm_8x8_mfma(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None, self.x.data_ptr(),
+                                            self.y.data_ptr(), batch, self.fout, self.fin, self.g, self.fin, self.fout, _native.F16, stream)
         elif batch <= self.x.shape[0] and self.K == 8 and self.nbits == 8 and (batch == 1 or (self.planar is not None and getattr(self, "lut_rows", True))):
             if getattr(self, "lut_cells", None) is None or self.lut_cells.numel() < batch * self.fout:  # zero-at-rest accumulator cells of the single-kernel form
                 self.lut_cells = torch.zeros((self.x.shape[0] * self.fout,), dtype=torch.int64, device=self.codes.device)
@@ -1129,12 +1133,15 @@ def main():
                                           "kernel": "gemv_kx8_rep_kernel (16-fold replicated codebooks in LDS)" if K == 2 else
                                                     "gemv_8x8_lut_kernel on planar codes (per-token look-up tables in LDS)"}
         # 8x8 g32 at 2..6 input rows (the module's gemv rule): the table kernel as ONE launch of rows x the single-row workgroups
-        # (aqlm_hip_gemv_8x8_lut_batch, round 5) next to the plain LDS kernel that served 2+ rows before (VERDICT r04 missing #4)
+        # (aqlm_hip_gemv_8x8_lut_batch, round 5) next to the plain LDS kernel that served 2+ rows before (VERDICT r04 missing #4),
+        # and the fused dequant -> MFMA kernel (aqlm_hip_gemm_8x8_mfma) at 2..64 rows
         if PACK_MIN_OUT:
             rows8 = {}
             for fi, fo in ((4096, 4096), (4096, 11008)):
-                ls = [Layer(fi, fo, 8, 8, 32, 9700 + rank * 10000 + i, dev, batch=6) for i in range(min(96, int(600e6 / algorithmic_bytes(fi, fo, 8, 8, 32)) + 1))]
+                ls = [Layer(fi, fo, 8, 8, 32, 9700 + rank * 10000 + i, dev, batch=64) for i in range(min(96, int(600e6 / algorithmic_bytes(fi, fo, 8, 8, 32)) + 1))]
                 per = {}
+                from aqlm_amd.inference_kernels import hip_kernel as hk8
+                per["fused_mfma_from_rows"] = hk8.fused_8x8_min_rows(fo, fi)  # the operator's switch (cost model read off these numbers)
                 for B in (1, 2, 3, 4, 6):
                     gpb = GraphedPass(ls, lib, batch=B)
                     us = gpb.time_replays(reps) * 1e3 / gpb.n
@@ -1148,6 +1155,14 @@ def main():
                         del gpo
                         for l in ls:
                             l.lut_rows = True
+                for B in (2, 3, 4, 6, 16, 64):  # the fused dequant -> MFMA kernel: one cost up to 16 rows
+                    for l in ls:
+                        l.fused_8x8 = True
+                    gpf = GraphedPass(ls, lib, batch=B)
+                    per.setdefault(f"B{B}", {})["fused_mfma_us"] = gpf.time_replays(reps) * 1e3 / gpf.n
+                    del gpf
+                    for l in ls:
+                        l.fused_8x8 = False
                 for B in (1, 2, 3, 4, 6):
                     per[f"B{B}"]["vs_B1"] = per[f"B{B}"]["lut_us"] / per["B1"]["lut_us"]
                 rows8[f"{fi}->{fo}"] = per

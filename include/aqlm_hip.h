@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 7
+#define AQLM_HIP_ABI_VERSION 8
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -448,6 +448,22 @@ int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const f
 int aqlm_hip_gemm_kx8_mfma(const void* codes_i8, const void* codebooks, const void* scales, const void* bias, const void* X,
                            void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
                            long x_row_stride, long y_row_stride, int dtype, void* stream);
+
+/*
+ * 8 codebooks of 256 x 32 (8x8 g32, 2 bits per weight) at 2 .. many batch rows (ABI 8): Y[B][out] = (X[B][in] @ W^T) * scales + bias,
+ * W never materialised.  The eight codebooks (128 KiB) live in LDS as 16-byte piece planes; a workgroup owns 16-row output tiles over
+ * all of K, a group of 32 features is one k-step of v_mfma_f32_16x16x32 whose A fragment lanes gather their piece of the entry
+ * the lane's code byte names -- one MFMA per codebook, so the eight terms of a weight meet in the fp32 accumulator (exact
+ * products, fp32 sums; W is never rounded).  Codes in the CHECKPOINT layout [out][in_groups][8] (not the planar copy).  No
+ * workspace, one launch per 64 batch rows; a row's bits do not depend on the other rows of the call nor on their number.
+ * Replaces: the reference's Triton kernel looped over the rows (triton_kernel.py:161-182) and, above the gemv rule's 6 rows,
+ * dequantize_gemm = _dequantize_weight + F.linear (dequantization.py:9-21, utils.py:43-70) for this scheme.
+ * AQLM_HIP_E_UNSUPPORTED (the caller takes its other routes): group sizes other than 32, in_features not a multiple of 256 or
+ * < 2048, codes / codebooks / X rows not 16-B aligned.
+ */
+int aqlm_hip_gemm_8x8_mfma(const void* codes_i8, const void* codebooks, const void* scales, const void* bias, const void* X, void* Y,
+                           int batch, int out_features, int in_features, int in_group_size, long x_row_stride, long y_row_stride,
+                           int dtype, void* stream);
 
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3

@@ -32,7 +32,7 @@ def test_header_and_binding_agree(native):
 
 
 def test_abi_version_and_error_string(native):
-    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 7
+    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 8
     assert isinstance(native.last_error(), str)
 
 
