@@ -1300,15 +1300,30 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
     __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebooks + (size_t)wave * 1024 + lane * 16),
                                      (glds_void_ptr)(size_t)(LDS::CB + (uint32_t)wave * 1024u), 16, 0, 0);
   {
+    // piece q = (chunk c, row b, 16-byte piece sl) = (q / ppc, (q % ppc) / 8, q % 8).  ONE division per lane; after that (c, r) are
+    // stepped by the quotient and remainder of the 512 pieces all waves advance together, and the source is a 32-bit byte offset
+    // (host: 16 rows x the row stride fit): the first cut recomputed q / ppc and a 64-bit b * xs per KiB -- ~33 VALU instructions
+    // with quarter-rate multiplies, 16 times per wave at 16 rows, which the fill had to wait for (counters: VALU 2.2 us per SIMD)
     const uint32_t ppc = B * 8u;                                  // pieces per chunk
     const uint32_t npieces = (uint32_t)(p.in_groups >> 3) * ppc;  // chunks x rows x 8
+    const uint32_t dq = (KR_NW * 64u) / ppc, dr = (KR_NW * 64u) - dq * ppc;
+    const uint32_t xs2 = (uint32_t)p.xs * 2u;                     // bytes per row of X (< 2^24: host)
+    uint32_t q = (uint32_t)wave * 64u + (uint32_t)lane;
+    uint32_t c = q / ppc, r = q - c * ppc;
+    const uint8_t* xb = (const uint8_t*)p.X;
     for (uint32_t q0 = (uint32_t)wave * 64u; q0 < npieces; q0 += KR_NW * 64u) {
-      uint32_t q = q0 + (uint32_t)lane;
-      q = q < npieces ? q : npieces - 1u;  // (the last KiB may be partly padding: any valid source will do)
-      const uint32_t c = q / ppc, r = q - c * ppc;
-      const uint32_t b = r >> 3, sl = r & 7u;
-      const uint16_t* src = p.X + (size_t)b * p.xs + (size_t)c * 64 + (size_t)(sl ^ kr_swz(b)) * 8;
-      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)src, (glds_void_ptr)(size_t)(LDS::X + q0 * 16u), 16, 0, 0);
+      const bool in = q < npieces;  // (the last KiB may be partly padding: any valid source will do)
+      const uint32_t cc = in ? c : 0u, rr = in ? r : 0u;
+      const uint32_t b = rr >> 3, sl = rr & 7u;
+      const uint32_t off = (b & 0xffu) * (xs2 & 0xffffffu) + cc * 128u + ((sl ^ kr_swz(b)) << 4);
+      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(xb + off), (glds_void_ptr)(size_t)(LDS::X + q0 * 16u), 16, 0, 0);
+      q += KR_NW * 64u;
+      c += dq;
+      r += dr;
+      if (r >= ppc) {
+        r -= ppc;
+        c += 1u;
+      }
     }
   }
   const uint32_t brow = (uint32_t)arow < B ? (uint32_t)arow : B - 1u;  // batch column of this lane's B fragments
@@ -1387,8 +1402,8 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
 
 // does the X-resident kernel take the call?  <= 16 rows whose image fits the LDS next to the codebooks and the partial tiles
 template <int K>
-static bool xres_fits(int B, int in_features) {
-  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K>::total(B, in_features) <= 160u * 1024u;
+static bool xres_fits(int B, int in_features, long xs) {
+  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K>::total(B, in_features) <= 160u * 1024u && xs > 0 && xs < (1l << 22);
 }
 
 template <class T, int K>
@@ -1434,7 +1449,7 @@ extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, 
     set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
     return AQLM_HIP_E_UNSUPPORTED;
   }
-  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2>(batch, in_features) : xres_fits<1>(batch, in_features))) {
+  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2>(batch, in_features, xs) : xres_fits<1>(batch, in_features, xs))) {
     // <= 16 rows: X resident in LDS, no per-step synchronisation (round 5)
     KrParams kr{};
     kr.codes = (const uint8_t*)codes;

@@ -1259,7 +1259,7 @@ def _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt):
 # as the reference does.  Numerics: exact products, fp32 sums (the table kernel: the same terms in another order).
 USE_FUSED_8X8_MFMA = True
 FUSED_8X8_MFMA_MIN_ROWS = 0   # 0 = by the measured cost model below (fused_8x8_min_rows); n > 0 = from n rows on, whatever the layer
-FUSED_8X8_MFMA_MAX_ROWS = 128
+FUSED_8X8_MFMA_MAX_ROWS = 64    # one slab; two slabs (128 rows) cost what dequantise + GEMM costs (4096^2: 44 vs 47 us; 4096 -> 11008: 104 vs 84)
 
 
 def fused_8x8_min_rows(out_features: int, in_features: int) -> int:

@@ -24,6 +24,17 @@ def layers(fin, fout, K, n):
     return out
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "one":  # python tools/gemm_kx8_xres_benchmark.py one <K> <in> <out> <rows>: 200 calls (counter passes)
+    K, fin, fout, B = (int(a) for a in sys.argv[2:6])
+    ls = layers(fin, fout, K, 8)
+    scales = torch.ones((fout, 1, 1, 1), device=dev, dtype=torch.float16)
+    x = torch.randn((B, fin), device=dev).half()
+    op = hk.code2x8_matmat_dequant if K == 2 else hk.code1x8_matmat_dequant
+    for i in range(200):
+        op(x, ls[i % 8][0], ls[i % 8][1], scales, None)
+    torch.cuda.synchronize()
+    sys.exit(0)
+
 for K in (2, 1):
     for fin, fout in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (4096, 1024)):
         if K == 1 and (fin, fout) != (4096, 4096):
