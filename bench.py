@@ -555,7 +555,9 @@ class GraphedCalls:
         self.stream.synchronize()
         try:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            # thread_local: the RCCL watchdog thread of torch.distributed queries events while this thread captures; in the default
+            # ("global") mode such a call from another thread invalidates the capture
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 for fn in calls:
                     fn(torch.cuda.current_stream())
             self.graph.replay()
@@ -593,6 +595,49 @@ class GraphedCalls:
             td.all_reduce(t, op=td.ReduceOp.MAX)
             us = float(t)
         return us
+
+
+class ExtrasWatchdog:
+    """The one JSON line must come out whatever happens after the timed region.  A daemon thread waits `budget_s`; if the main
+    thread has not called finish() by then, rank 0 prints the result as it stands (with `extras_timed_out` naming the section that
+    was running) and every rank leaves through os._exit -- a rank stuck in a collective cannot be joined."""
+
+    def __init__(self, result, rank, budget_s):
+        import threading
+
+        self.result, self.rank, self.budget_s = result, rank, budget_s
+        self.section = "detail"
+        self.lock = threading.Lock()
+        self.done = False
+        self.fired = False
+        if budget_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def _run(self):
+        time.sleep(self.budget_s)
+        with self.lock:
+            if self.done:
+                return
+            self.fired = True
+        if self.rank == 0:
+            self.result["extras_timed_out"] = {"after_s": self.budget_s, "section": self.section}
+            try:
+                line = json.dumps(self.result, default=lambda o: None)
+            except Exception:  # noqa: BLE001 - a dict mutated mid-dump: fall back to the headline fields
+                line = json.dumps({k: v for k, v in self.result.items() if k not in ("detail", "sharded_70b")}, default=lambda o: None)
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+        else:
+            time.sleep(5.0)  # rank 0 prints first
+        os._exit(0)
+
+    def finish(self):
+        with self.lock:
+            if self.fired:
+                time.sleep(3600)  # the watchdog thread is printing / exiting
+                return False
+            self.done = True
+        return True
 
 
 def _ensure_process_group(dev):
@@ -975,9 +1020,15 @@ def main():
     assert all(v < 1e-3 for v in parity.values()), f"bench outputs are off: {parity}"
     assert all(v < 1e-3 for v in parity_oracle.values()), f"bench outputs differ from the CPU oracle: {parity_oracle}"
 
+    # ---- everything below is OUTSIDE the timed region and must never cost the headline line: a watchdog prints what there is and
+    # ends the process if the extras (per-shape detail, the sharded figures with their captured collectives -- never run on more
+    # than one GPU before the driver's 8-GPU tier --, the CPU and reference legs) are not done within their budget
+    extras = ExtrasWatchdog(result, rank, float(os.environ.get("AQLM_BENCH_EXTRAS_TIMEOUT_S", "480")))
+
     # ---- untimed breakdown (rank 0 prints; every rank runs the collectives inside)
     if not args.no_detail:
         detail = {}
+        result["detail"] = detail  # filled in place: a timed-out run still reports what it had
         reps = max(4, args.steps // 5)
         for name, idxs in (("1x16g8 4096->4096", range(0, 2 * NBLOCKS, 2)), ("1x16g8 4096->11008", range(1, 2 * NBLOCKS, 2))):
             sub = [layers[i] for i in idxs]
@@ -1173,14 +1224,18 @@ def main():
                                                 "frac": lb["fused_TFLOPs"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("r03_gemm_glds_kernel_pmc.json")},
                                    "fused_mfma_us": lb["fused_mfma_us"], "dense_fp16_gemm_us": lb["dense_fp16_gemm_us"],
                                    "kernel": "gemm_1x16_glds_kernel + gemm_glds_finalize_kernel"}
-        result["detail"] = detail
+        extras.section = "sharded_70b"
         result["sharded_70b"] = sharded_70b(lib, dev, rank, world, args.steps)
 
     if rank == 0:  # rank 0 at every N (the other ranks wait at the barrier below; outside every timed region)
+        extras.section = "cpu_baseline"
         result["cpu_baseline"] = None if args.no_cpu else cpu_baseline()
         if not args.no_cpu:
+            extras.section = "gpu_reference_baseline"
             result["gpu_reference_baseline"] = gpu_reference_baseline()
 
+    if not extras.finish():
+        return  # the watchdog has printed the line and is ending the process
     if rank == 0:
         print(json.dumps(result))
     if dist:

@@ -86,3 +86,29 @@ def test_bench_launcher_command_is_the_drivers_form():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, timeout=300)
     assert p.returncode != 0 and b"WORLD_SIZE=3" in p.stderr
+
+
+def test_bench_extras_watchdog_prints_the_line_and_ends_the_process():
+    """bench.py's extras (detail, sharded figures with captured collectives, CPU / reference legs) run after the timed region; if
+    they hang -- a collective that cannot be captured on 8 GPUs was never exercised before the driver's scaling tier -- the one
+    JSON line must still come out: rank 0 prints what it has, every rank exits 0."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "res = {'metric': 'm', 'value': 1.5, 'detail': {'a': 1}}\n"
+            "w = bench.ExtrasWatchdog(res, int(sys.argv[1]), 0.3)\n"
+            "w.section = 'sharded_70b'\n"
+            "time.sleep(60)\n"
+            "print('not reached')\n") % ROOT
+    p0 = subprocess.run([sys.executable, "-c", code, "0"], cwd=ROOT, capture_output=True, timeout=120)
+    assert p0.returncode == 0 and b"not reached" not in p0.stdout
+    line = json.loads([l for l in p0.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["value"] == 1.5 and line["detail"] == {"a": 1} and line["extras_timed_out"] == {"after_s": 0.3, "section": "sharded_70b"}
+    p1 = subprocess.run([sys.executable, "-c", code, "1"], cwd=ROOT, capture_output=True, timeout=120)
+    assert p1.returncode == 0 and p1.stdout.strip() == b""
+    # finished in time: nothing is printed by the watchdog, finish() says go on
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "w = bench.ExtrasWatchdog({'value': 2}, 0, 0.5)\n"
+             "assert w.finish()\n"
+             "time.sleep(1.0)\n"
+             "print('done')\n") % ROOT
+    p2 = subprocess.run([sys.executable, "-c", code2], cwd=ROOT, capture_output=True, timeout=120)
+    assert p2.returncode == 0 and p2.stdout.strip() == b"done"
