@@ -20,6 +20,7 @@ MAX_GEMV_BATCH = 8
 OP_GEMM_1X16_MFMA = 1
 OP_GEMV_1X16_PACKED = 3
 OP_GEMV_8X8_LUT = 4
+OP_GEMM_KX8_MFMA = 6
 OP_GEMV_1X16_G16_PACKED = 5
 
 MAX_SEGMENTS = 4
@@ -133,6 +134,7 @@ SIGNATURES = {
     "aqlm_hip_dequant_generic": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_gemm_1x16_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemm_kx8_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
+    "aqlm_hip_gemm_kx8_mfma_ws": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemm_8x8_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
     "aqlm_hip_checksum": (_ci, [_vp, _sz, _vp, _vp]),

@@ -57,6 +57,8 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "gemm_variant")) return &t.gemm_variant;
   if (!strcmp(key, "kx8_mfma_min_rows")) return &t.kx8_mfma_min_rows;
   if (!strcmp(key, "kx8_xres")) return &t.kx8_xres;
+  if (!strcmp(key, "kx8_ksplit")) return &t.kx8_ksplit;
+  if (!strcmp(key, "kx8_rt")) return &t.kx8_rt;
   if (!strcmp(key, "gemm_debug")) return &t.gemm_debug;
   if (!strcmp(key, "gemm_store_nt")) return &t.gemm_store_nt;
   if (!strcmp(key, "force_generic")) return &t.force_generic;

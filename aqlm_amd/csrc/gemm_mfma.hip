@@ -978,7 +978,11 @@ struct KxParams {
   const uint16_t* bias;
   uint16_t* Y;
   long xs, ys;
-  int M, B, in_groups, nsteps;  // nsteps = K_features / (64 CPB)
+  int M, B, in_groups, nsteps;  // nsteps = steps of 64 CPB features of ONE K slice
+  // K split (round 5): block = (row block blockIdx.x % row_blocks, K slice blockIdx.x / row_blocks); with ksplit > 1 the block leaves
+  // its fp32 tile in partial[ks][b][m] and gemm_glds_finalize_kernel sums the slices, scales, adds the bias and rounds once
+  float* partial;
+  int ksplit, row_blocks;
 };
 
 // RT = 16-row tiles per block: every block streams all of X through its L1, so tall layers (>= 8192 rows: still >= 256 blocks)
@@ -992,8 +996,10 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int arow = lane & 15, kg = lane >> 4;
-  const int row0 = (int)blockIdx.x * (16 * RT);
+  const int ks = p.ksplit > 1 ? (int)blockIdx.x / p.row_blocks : 0;
+  const int row0 = (p.ksplit > 1 ? (int)blockIdx.x - ks * p.row_blocks : (int)blockIdx.x) * (16 * RT);
   const int n = p.nsteps;  // >= NSX - 1 (host)
+  const size_t s0 = (size_t)ks * (size_t)n;  // first step of this block's K slice
 
   if (wave < LDS::NXP) {
     // ============================================== X producer =======================================================
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
       const int cc = step < n ? step : n - 1;
 #pragma unroll
       for (int x = 0; x < PX; ++x)
-        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (size_t)cc * (128 * CPB)),
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(x_src[x] + (s0 + (size_t)cc) * (128 * CPB)),
                                          (glds_void_ptr)(size_t)(x_dst[x] + (uint32_t)stage * LDS::X_STAGE), 16, 0, 0);
     };
     for (int q = 0; q < NSX - 1; ++q) dma_x(q, q);
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
-        const uint8_t* src = code_base[rt] + ((size_t)cc * (8 * CPB) + 4 * (cw + KX_NC * j)) * K;
+        const uint8_t* src = code_base[rt] + ((s0 + (size_t)cc) * (8 * CPB) + 4 * (cw + KX_NC * j)) * K;
         if constexpr (K == 2) c[rt][j] = *reinterpret_cast<const uint16_t*>(src);
         else c[rt][j] = *src;
       }
@@ -1131,6 +1137,14 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
     const int m = row0 + rt * 16 + kg * 4;
     const int b = bt * 16 + arow;
     if (b < p.B && m < p.M) {
+      if (p.ksplit > 1) {  // this K slice's share of the tile: fp32, summed by the finalize kernel in slice order
+        float* dst = p.partial + ((size_t)ks * p.B + b) * p.M + m;
+        if ((p.M & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+        else
+          for (int r = 0; r < 4; ++r)
+            if (m + r < p.M) dst[r] = v[r];
+        continue;
+      }
       uint16_t* dst = p.Y + (size_t)b * p.ys + m;
       uint16_t h[4];
 #pragma unroll
@@ -1148,25 +1162,58 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
 }
 
 struct KxPlan {
-  int nbt, cpb, rt, nsteps;
+  int nbt, cpb, rt, nsteps, ksplit;  // nsteps: per K slice
 };
 
-static bool plan_kx8(int B, int M, int Kf, KxPlan& r) {
+constexpr int KX_MAX_KSPLIT = 4;
+
+// `can_split`: the caller gave a workspace for fp32 partials (aqlm_hip_gemm_kx8_mfma_ws).
+static bool plan_kx8(int B, int M, int Kf, KxPlan& r, bool can_split = false) {
   if (Kf % (2 * BK) != 0 || B < 1 || B > 128) return false;
   const int t = (B + 15) / 16;
   r.nbt = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
   const int chunks = Kf / BK;
   r.cpb = (r.nbt <= 2 && chunks % 4 == 0) ? 4 : 2;
   r.nsteps = chunks / r.cpb;
+  r.ksplit = 1;
   // two row tiles per block where that still fills the chip AND X is what the block mostly moves (measured, 4096 -> 11008: 128 rows
   // 46.5 -> 39.6 us, 64 rows 28.5 -> 26.9, but 16 rows 18.2 -> 20.8: 344 blocks are 1.3 rounds of the chip)
   r.rt = ((M + 31) / 32 >= 256 && r.nbt >= 4) ? 2 : 1;
-  return r.nsteps >= 3;  // the X ring's prologue (NSX <= 4)
+  if (r.nsteps < 3) return false;  // the X ring's prologue (NSX <= 4)
+  // K split (round 5, given a workspace): the K range dealt to 2 / 4 blocks whose fp32 tiles a finalize launch sums (+ ~3 us).  Measured
+  // (profiles/r05_gemm_kx8_ksplit.log, 2x8 g8, 128 rows, us; no split -> split): it pays (a) where the layer has too few rows to fill the
+  // chip -- 4096 -> 1024: 64 blocks, 15.2 -> 11.0 with 4 slices of one tile -- and (b) on long K with two tiles per block, where a step's
+  // X fragments feed twice the MFMAs -- 11008 -> 4096: 45.7 -> 35.0 (64 rows: 37.5 -> 24.7); it does NOT pay at 4096 x 4096 (16.6 -> 18.0:
+  // a 32-step block is not X-bound, the finalize is pure cost) nor where two tiles per block already fill the chip (8192 x 8192).
+  const int force_ks = tuning().kx8_ksplit, force_rt = tuning().kx8_rt;
+  if (can_split && r.nbt >= 4 && force_ks != 1) {
+    const int rb16 = (M + 15) / 16, rb32 = (M + 31) / 32;
+    int rt = 0, ks = 1;
+    if (force_ks > 1) {
+      rt = force_rt == 1 ? 1 : 2;
+      ks = force_ks;
+    } else if (rb16 <= 128) {
+      rt = 1;
+      ks = std::min(KX_MAX_KSPLIT, 256 / rb16);
+    } else if (Kf >= 8192 && rb32 < 256) {
+      rt = 2;
+      ks = std::min(KX_MAX_KSPLIT, std::max(1, 256 / rb32));
+    }
+    while (ks > 1 && (r.nsteps % ks != 0 || r.nsteps / ks < 3)) --ks;
+    if (ks > 1) {
+      r.rt = rt;
+      r.ksplit = ks;
+      r.nsteps /= ks;
+    }
+  } else if (force_rt == 1 || force_rt == 2) {
+    r.rt = force_rt;
+  }
+  return true;
 }
 
 template <class T, int K>
 static int launch_kx8(const KxParams& p, const KxPlan& r, hipStream_t stream) {
-  const dim3 grid((unsigned)((p.M + 16 * r.rt - 1) / (16 * r.rt)));
+  const dim3 grid((unsigned)(((p.M + 16 * r.rt - 1) / (16 * r.rt)) * r.ksplit));
   auto go = [&](auto kern, size_t lds, int waves) -> int {
     if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
     hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds, stream, p);
@@ -1236,6 +1283,8 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   if (batch <= 0 || out_features <= 0 || in_features <= 0) return 0;
   if (op == AQLM_HIP_OP_GEMV_1X16_PACKED || op == AQLM_HIP_OP_GEMV_1X16_G16_PACKED)  // fp32 partials [slices][rows of x][out]
     return (size_t)(op == AQLM_HIP_OP_GEMV_1X16_PACKED ? 16 : 32) * std::min(batch, AQLM_HIP_MAX_GEMV_BATCH) * out_features * sizeof(float);
+  if (op == AQLM_HIP_OP_GEMM_KX8_MFMA)  // fp32 partials of the K-split form (64+ rows); 0 below: the op then needs no workspace
+    return batch >= 49 ? (size_t)KX_MAX_KSPLIT * std::min(batch, 128) * out_features * sizeof(float) : 0;
   if (op != AQLM_HIP_OP_GEMM_1X16_MFMA) return 0;
   // covers both kernels of the op (the LDS-DMA pipeline and the register-staged one behind the `gemm_variant` knob)
   const GemmPlan g = plan_gemm(batch, out_features, in_features);
@@ -1427,6 +1476,13 @@ static int launch_kx8_xres(const KrParams& p, int in_features, hipStream_t strea
 extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* X,
                                       void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
                                       long xs, long ys, int dtype, void* stream_) {
+  return aqlm_hip_gemm_kx8_mfma_ws(codes, codebooks, scales, bias, X, Y, batch, out_features, in_features, num_codebooks, in_group_size, xs,
+                                   ys, dtype, nullptr, 0, stream_);
+}
+
+extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* X,
+                                         void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
+                                         long xs, long ys, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!codes || !codebooks || !scales || !X || !Y) {
     set_last_error("aqlm_hip_gemm_kx8_mfma: null pointer argument");
@@ -1467,9 +1523,15 @@ extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, 
     if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2>(kr, in_features, stream) : launch_kx8_xres<F16, 1>(kr, in_features, stream);
     return num_codebooks == 2 ? launch_kx8_xres<BF16, 2>(kr, in_features, stream) : launch_kx8_xres<BF16, 1>(kr, in_features, stream);
   }
+  // fp32 partials of the K-split form: [<= KX_MAX_KSPLIT][rows of the slab][out_features]; a workspace too small for a slab's plan
+  // simply keeps that slab on the no-split form
+  auto can_split = [&](int nb) {
+    return workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 &&
+           workspace_bytes >= (size_t)KX_MAX_KSPLIT * nb * out_features * sizeof(float);
+  };
   for (int b0 = 0; b0 < batch; b0 += 128) {  // every slab is planned before anything is launched (a tail slab plans differently from the probe)
     KxPlan r{};
-    if (!plan_kx8(std::min(128, batch - b0), out_features, in_features, r)) {
+    if (!plan_kx8(std::min(128, batch - b0), out_features, in_features, r, can_split(std::min(128, batch - b0)))) {
       set_last_error("aqlm_hip_gemm_kx8_mfma: a slab of %d rows at in_features %d is outside the kernel's plans", std::min(128, batch - b0), in_features);
       return AQLM_HIP_E_UNSUPPORTED;
     }
@@ -1477,7 +1539,7 @@ extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, 
   for (int b0 = 0; b0 < batch; b0 += 128) {  // slabs of 128 rows (the codes are re-read per slab: they are 2 bits per weight)
     const int nb = std::min(128, batch - b0);
     KxPlan r{};
-    plan_kx8(nb, out_features, in_features, r);
+    plan_kx8(nb, out_features, in_features, r, can_split(nb));
     KxParams kp{};
     kp.codes = (const uint8_t*)codes;
     kp.codebooks = (const uint8_t*)codebooks;
@@ -1491,10 +1553,31 @@ extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, 
     kp.B = nb;
     kp.in_groups = in_features / 8;
     kp.nsteps = r.nsteps;
+    kp.partial = (float*)workspace;
+    kp.ksplit = r.ksplit;
+    kp.row_blocks = (out_features + 16 * r.rt - 1) / (16 * r.rt);
     int e;
     if (dtype == AQLM_HIP_F16) e = num_codebooks == 2 ? launch_kx8<F16, 2>(kp, r, stream) : launch_kx8<F16, 1>(kp, r, stream);
     else e = num_codebooks == 2 ? launch_kx8<BF16, 2>(kp, r, stream) : launch_kx8<BF16, 1>(kp, r, stream);
     if (e) return e;
+    if (r.ksplit > 1) {  // the slices meet: sum in slice order, scale, bias, one rounding (the 1x16 pipeline's finalize kernel)
+      GldsFinalizeParams f{};
+      f.partial = (const float*)workspace;
+      f.scales = (const uint16_t*)scales;
+      f.bias = (const uint16_t*)bias;
+      f.Y = (uint16_t*)Y + (long)b0 * ys;
+      f.ys = ys;
+      f.M = out_features;
+      f.B = nb;
+      f.ksplit = r.ksplit;
+      f.row_blocks = (out_features + 127) / 128;
+      f.bchunks = (nb + 7) / 8;
+      f.rb_rows = 128;
+      const dim3 grid((unsigned)(8 * ((f.row_blocks + 7) / 8) * f.bchunks));
+      if (dtype == AQLM_HIP_F16) hipLaunchKernelGGL(gemm_glds_finalize_kernel<F16>, grid, dim3(256), 0, stream, f);
+      else hipLaunchKernelGGL(gemm_glds_finalize_kernel<BF16>, grid, dim3(256), 0, stream, f);
+      if (int e2 = check_hip(hipGetLastError(), "gemm_kx8 finalize launch")) return e2;
+    }
   }
   return 0;
 }

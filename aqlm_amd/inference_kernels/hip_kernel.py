@@ -1220,6 +1220,7 @@ def _matmat_dequant_kx8(input, codes, codebooks, scales, bias):
 FUSED_KX8_MFMA_MAX_ROWS = 128         # any layer
 FUSED_KX8_MFMA_MAX_ROWS_SMALL = 256   # layers of <= 4096 x 4096
 USE_FUSED_KX8_MFMA = True
+USE_FUSED_KX8_KSPLIT = True   # False: never hand the fused op a workspace (no K split; A/B runs)
 
 
 def _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt):
@@ -1243,9 +1244,15 @@ def _fused_kx8_mfma(input, codes, codebooks, scales, bias, dt):
     if bias is not None:
         bias = _c(bias)
     y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    # 49+ rows: fp32 partials for the K-split form (two row tiles per block, the K range dealt to 2 / 4 blocks: every CU pulls half /
+    # a quarter of X through its L1); below, and when the plan does not split, the workspace is not touched
+    ws_bytes = _lib.aqlm_hip_workspace_bytes(_native.OP_GEMM_KX8_MFMA, B, out_features, in_features) if USE_FUSED_KX8_KSPLIT else 0
+    stream = _stream_ptr(input.device)
+    ws = _workspace(input.device, ws_bytes, stream) if ws_bytes else None
     with _device_guard(input.device):
-        rc = _lib.aqlm_hip_gemm_kx8_mfma(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(), y.data_ptr(),
-                                         B, out_features, in_features, K, g, x.stride(0), out_features, dt, _stream_ptr(input.device))
+        rc = _lib.aqlm_hip_gemm_kx8_mfma_ws(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(), y.data_ptr(),
+                                            B, out_features, in_features, K, g, x.stride(0), out_features, dt,
+                                            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
     if rc == _native.E_UNSUPPORTED:
         return None
     if rc:

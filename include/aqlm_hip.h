@@ -465,7 +465,20 @@ int aqlm_hip_gemm_8x8_mfma(const void* codes_i8, const void* codebooks, const vo
                            int batch, int out_features, int in_features, int in_group_size, long x_row_stride, long y_row_stride,
                            int dtype, void* stream);
 
+/*
+ * aqlm_hip_gemm_kx8_mfma with a workspace (ABI 8): at 49+ batch rows every 16-row block of the no-workspace form pulls all of X
+ * (batch x in_features x 2 bytes: 1 MiB at 128 rows of a 4096-wide layer) through its CU's L1; given `workspace` (16-B aligned,
+ * aqlm_hip_workspace_bytes(AQLM_HIP_OP_GEMM_KX8_MFMA, batch, out_features, in_features) bytes) the entry takes two row tiles per
+ * block and deals the K range to 2 or 4 blocks -- half / a quarter of the X bytes per CU -- whose fp32 tiles a second small kernel
+ * sums in slice order before scale, bias and the one rounding (deterministic; results differ from the no-workspace form only in
+ * the order of the fp32 sums).  workspace == NULL or too small: exactly aqlm_hip_gemm_kx8_mfma.
+ */
+int aqlm_hip_gemm_kx8_mfma_ws(const void* codes_i8, const void* codebooks, const void* scales, const void* bias, const void* X,
+                              void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
+                              long x_row_stride, long y_row_stride, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 #define AQLM_HIP_OP_GEMM_1X16_MFMA 1
+#define AQLM_HIP_OP_GEMM_KX8_MFMA 6
 #define AQLM_HIP_OP_GEMV_1X16_PACKED 3
 #define AQLM_HIP_OP_GEMV_8X8_LUT 4
 #define AQLM_HIP_OP_GEMV_1X16_G16_PACKED 5 /* prepacked codes of 16-element vectors: 32 slices */

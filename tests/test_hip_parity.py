@@ -381,6 +381,24 @@ def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
         hk.USE_FUSED_KX8_MFMA = True
     den = float(y_lib.float().abs().mean())
     assert float((y.float() - y_lib.float()).abs().mean()) / den < (2e-3 if dtype == torch.float16 else 1e-2)
+    if B >= 49:  # the K-split form (round 5: two row tiles per block, 2 / 4 K slices, fp32 partials + finalize) against the one-launch form
+        hk.USE_FUSED_KX8_KSPLIT = False
+        try:
+            y_one = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+        finally:
+            hk.USE_FUSED_KX8_KSPLIT = True
+        check_close(y_one.float().cpu().numpy(), y64, dtype, f"fused {K}x8 mfma, no K split {fin}->{fout} B{B}")
+        check_close(y.float().cpu().numpy(), y_one.double().cpu().numpy(), dtype, "K-split vs one-launch form")
+        from aqlm_amd import _native
+        for ks, rt in ((2, 1), (4, 2)):   # forced plans (a plan that does not divide the steps falls back to fewer slices)
+            _native.set_tuning("kx8_ksplit", ks)
+            _native.set_tuning("kx8_rt", rt)
+            try:
+                y_f = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+            finally:
+                _native.set_tuning("kx8_ksplit", 0)
+                _native.set_tuning("kx8_rt", 0)
+            check_close(y_f.float().cpu().numpy(), y64, dtype, f"fused {K}x8 mfma, {ks} K slices x {rt} tiles")
     # a row's result does not depend on the rows around it (same kernel instance: same batch-tile count)
     if B >= 3:
         x2 = T["x"].clone()
