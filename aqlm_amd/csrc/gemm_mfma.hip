@@ -1173,6 +1173,8 @@ static bool plan_kx8(int B, int M, int Kf, KxPlan& r, bool can_split = false) {
   const int t = (B + 15) / 16;
   r.nbt = t <= 1 ? 1 : (t <= 2 ? 2 : (t <= 4 ? 4 : 8));
   const int chunks = Kf / BK;
+  // (steps of 4 chunks at 64 / 128 rows -- X ring of 3 x 32 / 2 x 64 KiB -- measured in round 5: 4096^2 at 64 rows 13.4 -> 12.0 us, every other
+  // shape and 128 rows equal or up to 16 % slower, profiles/r05_gemm_kx8_steps_of_4_chunks.log: not kept)
   r.cpb = (r.nbt <= 2 && chunks % 4 == 0) ? 4 : 2;
   r.nsteps = chunks / r.cpb;
   r.ksplit = 1;

@@ -23,7 +23,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "ksplit":  # the K-split form at 64+ row
         for B in (64, 128, 256):
             x = torch.randn((B, fin), device=dev).half()
             res = {}
-            cases = {"no split (round 4)": (1, 0), "plan": (0, 0), "2 slices x 2 tiles": (2, 2), "4 x 2": (4, 2), "2 x 1": (2, 1), "4 x 1": (4, 1)}
+            cases = {"no split (round 4)": (1, 0), "plan": (0, 0)}
+            if len(sys.argv) > 2 and sys.argv[2] == "all":
+                cases.update({"2 slices x 2 tiles": (2, 2), "4 x 2": (4, 2), "2 x 1": (2, 1), "4 x 1": (4, 1)})
             for rep in range(2):
                 for name, (ks, rt) in cases.items():
                     _native.set_tuning("kx8_ksplit", ks)

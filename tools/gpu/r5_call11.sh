@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, development call 10: K-split form of the fused K x 8 MFMA op at 64+ rows -- tests, then plans side by side.
+# Round 5, development call 11: K-split form of the fused K x 8 MFMA op at 64+ rows -- tests, then plans side by side.
 set +e
-TAG=${1:-r5c10}
+TAG=${1:-r5c11}
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
