@@ -217,12 +217,11 @@ int launch_e8(const E8Params& p, hipStream_t stream) {
   auto kern = gemm_8x8g32_rows16_kernel<T, NBT>;
   const size_t lds = (size_t)E8_CB_BYTES + (size_t)E8_NW * NBT * 1024;
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
-  static int cus = 0;
-  if (cus == 0) {
+  static const int cus = [] {  // (initialised once, thread-safe; every GPU of a node is the same part)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus = n;
-  }
+    return n;
+  }();
   // one workgroup per CU (the codebooks fill its LDS); tiles are dealt round-robin, so the last round is as even as it gets
   const int rounds = (p.ntiles + cus - 1) / cus;
   const int grid = (p.ntiles + rounds - 1) / rounds;

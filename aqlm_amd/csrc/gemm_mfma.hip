@@ -1463,12 +1463,11 @@ static int launch_kx8_xres(const KrParams& p, int in_features, hipStream_t strea
   const size_t lds = KrLds<K>::total(p.B, in_features);
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   // one workgroup per CU and as many as fit its LDS (small X: two or more share a CU and overlap their latencies)
-  static int cus = 0;
-  if (cus == 0) {
+  static const int cus = [] {  // (initialised once, thread-safe; every GPU of a node is the same part)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus = n;
-  }
+    return n;
+  }();
   const int per_cu = std::max(1, std::min(4, (int)((160u * 1024u) / lds)));
   const int grid = std::min(p.ntiles, cus * per_cu);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KR_NW * 64), lds, stream, p);

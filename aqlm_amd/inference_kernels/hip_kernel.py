@@ -1276,7 +1276,8 @@ def fused_8x8_min_rows(out_features: int, in_features: int) -> int:
     million weights).  4096 x 4096: 3 rows; 4096 -> 11008 and 8192 x 8192: 5; 11008 -> 4096: 4."""
     if FUSED_8X8_MFMA_MIN_ROWS > 0:
         return FUSED_8X8_MFMA_MIN_ROWS
-    rounds = -(-(-(-out_features // 16)) // 256)
+    tiles = (out_features + 15) // 16
+    rounds = (tiles + 255) // 256
     fused = 3.6 + 2.15 * rounds * in_features / 1024.0
     per_row = 3.7 + 0.05 * out_features * in_features * 1e-6
     return max(2, int((fused - 1.3) / per_row) + 1)
