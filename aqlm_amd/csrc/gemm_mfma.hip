@@ -1313,31 +1313,44 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
 // Numerics: exact products, fp32 sums (per wave over its quads in order, then the 8 waves in wave order): a row's bits do not
 // depend on the other rows of the call, nor on B.
 constexpr int KR_NW = 8;
+constexpr int KR_MAX_SEG = AQLM_HIP_MAX_SEGMENTS;
 
-struct KrParams {
+// One layer, or (round 5) up to KR_MAX_SEG layers that multiply the SAME X (q / k / v, gate / up: aqlm_hip_gemv_kx8_multi): the X
+// image is loaded once, every layer's codebooks (K x 4 KiB each) sit side by side in LDS, and the tile walk runs over the layers'
+// tiles back to back (tile -> layer by three comparisons).  A tile's arithmetic does not know about the other layers: outputs are
+// bit-identical to separate launches.
+struct KrSeg {
   const uint8_t* codes;      // [M][in_groups][K] u8
   const uint8_t* codebooks;  // [K][256][8] halfs
-  const uint16_t* X;         // [B][xs]
   const uint16_t* scales;
   const uint16_t* bias;
   uint16_t* Y;
-  long xs, ys;
-  int M, B, in_groups, ntiles;
+  long ys;
+  int M;
+  int tile0;                 // first tile of the layer in the launch's tile sequence
 };
 
-template <int K>
+template <int NSEG>
+struct KrParams {
+  KrSeg seg[NSEG];
+  const uint16_t* X;         // [B][xs]
+  long xs;
+  int B, in_groups, ntiles, nseg;
+};
+
+template <int K, int NSEG>
 struct KrLds {
-  static constexpr uint32_t CB = 0;                                  // [K][256][16 B]
-  static constexpr uint32_t RED = (uint32_t)K * 4096u;               // [2][KR_NW][64 lanes][16 B] fp32 partial tiles
+  static constexpr uint32_t CB = 0;                                  // [layer][K][256][16 B]
+  static constexpr uint32_t RED = (uint32_t)NSEG * K * 4096u;        // [2][KR_NW][64 lanes][16 B] fp32 partial tiles
   static constexpr uint32_t X = RED + 2u * KR_NW * 1024u;            // the X image, rounded up to whole KiB (DMA granularity)
   static size_t total(int B, int in_features) { return (size_t)X + (((size_t)B * in_features * 2 + 1023) & ~(size_t)1023); }
 };
 
 __device__ __forceinline__ uint32_t kr_swz(uint32_t b) { return ((b >> 1) & 7u) ^ ((b & 8u) >> 1); }
 
-template <class T, int K>
-__global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParams p) {
-  using LDS = KrLds<K>;
+template <class T, int K, int NSEG>
+__global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParams<NSEG> p) {
+  using LDS = KrLds<K, NSEG>;
   extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1345,11 +1358,17 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
   const int arow = lane & 15, kg = lane >> 4;
   const uint32_t B = (uint32_t)p.B;
   const int nquads = p.in_groups >> 4;  // 128 k each (host: in_features % 128 == 0)
+  auto seg_of = [&](int tile) -> int {  // wave-uniform
+    if constexpr (NSEG == 1) return 0;
+    else return (int)(tile >= p.seg[1].tile0) + (int)(tile >= p.seg[2].tile0) + (int)(tile >= p.seg[3].tile0);  // (absent layers: tile0 = ntiles)
+  };
 
   // ---- prologue: codebooks and the whole of X by LDS-DMA; the first tile's codes are requested before anything is waited for
-  if (wave < K * 4)
-    __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebooks + (size_t)wave * 1024 + lane * 16),
-                                     (glds_void_ptr)(size_t)(LDS::CB + (uint32_t)wave * 1024u), 16, 0, 0);
+  for (int i = wave; i < K * 4 * (NSEG == 1 ? 1 : p.nseg); i += KR_NW) {
+    const int sg = i / (K * 4), off = i - sg * (K * 4);
+    __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.seg[sg].codebooks + (size_t)off * 1024 + lane * 16),
+                                     (glds_void_ptr)(size_t)(LDS::CB + (uint32_t)i * 1024u), 16, 0, 0);
+  }
   {
     // piece q = (chunk c, row b, 16-byte piece sl) = (q / ppc, (q % ppc) / 8, q % 8).  ONE division per lane; after that (c, r) are
     // stepped by the quotient and remainder of the 512 pieces all waves advance together, and the source is a 32-bit byte offset
@@ -1381,9 +1400,10 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
   const uint32_t bsw = kr_swz(brow);
   typedef typename std::conditional<K == 2, u32x2, uint32_t>::type code_t;
   auto code_ptr = [&](int tile, int quad) -> const code_t* {
-    int r = tile * 16 + arow;
-    r = r < p.M ? r : p.M - 1;
-    return reinterpret_cast<const code_t*>(p.codes + ((size_t)r * p.in_groups + (size_t)quad * 16 + (size_t)kg * 4) * K);
+    const int sg = seg_of(tile);
+    int r = (tile - p.seg[sg].tile0) * 16 + arow;
+    r = r < p.seg[sg].M ? r : p.seg[sg].M - 1;
+    return reinterpret_cast<const code_t*>(p.seg[sg].codes + ((size_t)r * p.in_groups + (size_t)quad * 16 + (size_t)kg * 4) * K);
   };
   int tile = (int)blockIdx.x;
   code_t cnext{};
@@ -1393,6 +1413,8 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
 
   int buf = 0;
   for (; tile < p.ntiles; tile += (int)gridDim.x) {
+    const int sg = seg_of(tile);
+    const uint32_t cb = LDS::CB + (uint32_t)sg * (uint32_t)(K * 4096);  // this layer's codebooks
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     for (int quad = wave; quad < nquads; quad += KR_NW) {
       const code_t cw = cnext;
@@ -1410,7 +1432,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const uint32_t byte = K == 2 ? (cwords[j >> 1] >> (16 * (j & 1) + 8 * k)) & 0xffu : (cwords[0] >> (8 * j)) & 0xffu;
-          w[j][k] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (uint32_t)k * 4096u + byte * 16u);
+          w[j][k] = *(glds_u32x4_ptr)(size_t)(cb + (uint32_t)k * 4096u + byte * 16u);
         }
         const uint32_t c = (uint32_t)quad * 2u + (uint32_t)(kg >> 1), pc = (uint32_t)(kg & 1) * 4u + (uint32_t)j;
         xb[j] = *(glds_u32x4_ptr)(size_t)(LDS::X + ((c * B + brow) * 8u + (pc ^ bsw)) * 16u);
@@ -1430,21 +1452,22 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
 #pragma unroll
       for (int w8 = 1; w8 < KR_NW; ++w8)  // wave order: the result does not depend on who finishes first
         v = v + *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(buf * KR_NW + w8) * 1024u + (uint32_t)lane * 16u);
-      const int m = tile * 16 + kg * 4;
+      const KrSeg& S = p.seg[sg];
+      const int m = (tile - S.tile0) * 16 + kg * 4;
       const int b = arow;
-      if (b < p.B && m < p.M) {
-        uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+      if (b < p.B && m < S.M) {
+        uint16_t* dst = S.Y + (size_t)b * S.ys + m;
         uint16_t h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int mm = m + r < p.M ? m + r : p.M - 1;
-          const float sc = T::to_float(p.scales[mm]), bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+          const int mm = m + r < S.M ? m + r : S.M - 1;
+          const float sc = T::to_float(S.scales[mm]), bi = S.bias ? T::to_float(S.bias[mm]) : 0.f;
           h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
         }
-        if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        if ((S.M & 3) == 0 && (S.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
         else
           for (int r = 0; r < 4; ++r)
-            if (m + r < p.M) dst[r] = h[r];
+            if (m + r < S.M) dst[r] = h[r];
       }
     }
     buf ^= 1;
@@ -1452,15 +1475,15 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
 }
 
 // does the X-resident kernel take the call?  <= 16 rows whose image fits the LDS next to the codebooks and the partial tiles
-template <int K>
+template <int K, int NSEG>
 static bool xres_fits(int B, int in_features, long xs) {
-  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K>::total(B, in_features) <= 160u * 1024u && xs > 0 && xs < (1l << 22);
+  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K, NSEG>::total(B, in_features) <= 160u * 1024u && xs > 0 && xs < (1l << 22);
 }
 
-template <class T, int K>
-static int launch_kx8_xres(const KrParams& p, int in_features, hipStream_t stream) {
-  auto kern = gemm_kx8_xres_kernel<T, K>;
-  const size_t lds = KrLds<K>::total(p.B, in_features);
+template <class T, int K, int NSEG>
+static int launch_kx8_xres(const KrParams<NSEG>& p, int in_features, hipStream_t stream) {
+  auto kern = gemm_kx8_xres_kernel<T, K, NSEG>;
+  const size_t lds = KrLds<K, NSEG>::total(p.B, in_features);
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   // one workgroup per CU and as many as fit its LDS (small X: two or more share a CU and overlap their latencies)
   static const int cus = [] {  // (initialised once, thread-safe; every GPU of a node is the same part)
@@ -1473,6 +1496,46 @@ static int launch_kx8_xres(const KrParams& p, int in_features, hipStream_t strea
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KR_NW * 64), lds, stream, p);
   return check_hip(hipGetLastError(), "gemm_kx8_xres launch");
 }
+
+namespace aqlm {
+// Shared-input launches of the fused K x 8 op at <= 16 rows (called by aqlm_hip_gemv_kx8_multi; arguments validated there):
+// AQLM_HIP_E_UNSUPPORTED when the layers' codebooks + X do not fit the LDS together (the caller launches the layers one by one).
+int gemm_kx8_xres_multi(const aqlm_hip_segment* segments, int num_segments, const void* X, int in_features, int K, int batch, long xs,
+                        int dtype, hipStream_t stream) {
+  if (num_segments < 2 || num_segments > KR_MAX_SEG || !tuning().kx8_xres || (K != 1 && K != 2)) return AQLM_HIP_E_UNSUPPORTED;
+  if (!(K == 2 ? xres_fits<2, KR_MAX_SEG>(batch, in_features, xs) : xres_fits<1, KR_MAX_SEG>(batch, in_features, xs)) || !aligned16(X) || xs % 8 != 0)
+    return AQLM_HIP_E_UNSUPPORTED;
+  KrParams<KR_MAX_SEG> p{};
+  int tiles = 0;
+  for (int k = 0; k < KR_MAX_SEG; ++k) {
+    KrSeg& S = p.seg[k];
+    if (k < num_segments) {
+      const aqlm_hip_segment& sg = segments[k];
+      if (!aligned16(sg.codebook)) return AQLM_HIP_E_UNSUPPORTED;
+      S.codes = (const uint8_t*)sg.codes;
+      S.codebooks = (const uint8_t*)sg.codebook;
+      S.scales = (const uint16_t*)sg.scales;
+      S.bias = (const uint16_t*)sg.bias;
+      S.Y = (uint16_t*)sg.y;
+      S.ys = sg.y_row_stride;
+      S.M = sg.out_features;
+      S.tile0 = tiles;
+      tiles += (sg.out_features + 15) / 16;
+    } else {
+      S = p.seg[0];
+      S.tile0 = 0x7fffffff;  // never reached
+    }
+  }
+  p.X = (const uint16_t*)X;
+  p.xs = xs;
+  p.B = batch;
+  p.in_groups = in_features / 8;
+  p.ntiles = tiles;
+  p.nseg = num_segments;
+  if (dtype == AQLM_HIP_F16) return K == 2 ? launch_kx8_xres<F16, 2, KR_MAX_SEG>(p, in_features, stream) : launch_kx8_xres<F16, 1, KR_MAX_SEG>(p, in_features, stream);
+  return K == 2 ? launch_kx8_xres<BF16, 2, KR_MAX_SEG>(p, in_features, stream) : launch_kx8_xres<BF16, 1, KR_MAX_SEG>(p, in_features, stream);
+}
+}  // namespace aqlm
 
 extern "C" int aqlm_hip_gemm_kx8_mfma(const void* codes, const void* codebooks, const void* scales, const void* bias, const void* X,
                                       void* Y, int batch, int out_features, int in_features, int num_codebooks, int in_group_size,
@@ -1506,23 +1569,25 @@ extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebook
     set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
     return AQLM_HIP_E_UNSUPPORTED;
   }
-  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2>(batch, in_features, xs) : xres_fits<1>(batch, in_features, xs))) {
+  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2, 1>(batch, in_features, xs) : xres_fits<1, 1>(batch, in_features, xs))) {
     // <= 16 rows: X resident in LDS, no per-step synchronisation (round 5)
-    KrParams kr{};
-    kr.codes = (const uint8_t*)codes;
-    kr.codebooks = (const uint8_t*)codebooks;
+    KrParams<1> kr{};
+    kr.seg[0].codes = (const uint8_t*)codes;
+    kr.seg[0].codebooks = (const uint8_t*)codebooks;
+    kr.seg[0].scales = (const uint16_t*)scales;
+    kr.seg[0].bias = (const uint16_t*)bias;
+    kr.seg[0].Y = (uint16_t*)Y;
+    kr.seg[0].ys = ys;
+    kr.seg[0].M = out_features;
+    kr.seg[0].tile0 = 0;
     kr.X = (const uint16_t*)X;
-    kr.scales = (const uint16_t*)scales;
-    kr.bias = (const uint16_t*)bias;
-    kr.Y = (uint16_t*)Y;
     kr.xs = xs;
-    kr.ys = ys;
-    kr.M = out_features;
     kr.B = batch;
     kr.in_groups = in_features / 8;
     kr.ntiles = (out_features + 15) / 16;
-    if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2>(kr, in_features, stream) : launch_kx8_xres<F16, 1>(kr, in_features, stream);
-    return num_codebooks == 2 ? launch_kx8_xres<BF16, 2>(kr, in_features, stream) : launch_kx8_xres<BF16, 1>(kr, in_features, stream);
+    kr.nseg = 1;
+    if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<F16, 1, 1>(kr, in_features, stream);
+    return num_codebooks == 2 ? launch_kx8_xres<BF16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<BF16, 1, 1>(kr, in_features, stream);
   }
   // fp32 partials of the K-split form: [<= KX_MAX_KSPLIT][rows of the slab][out_features]; a workspace too small for a slab's plan
   // simply keeps that slab on the no-split form

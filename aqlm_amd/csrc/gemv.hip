@@ -670,6 +670,11 @@ static int dispatch_kx8_nb(int nb, const GemvParams& p, hipStream_t s) {
 // rows on (tuning key, default 2, 0 = never) the matvec entries hand the call to aqlm_hip_gemm_kx8_mfma: exact products, fp32 sums
 // like the matvec kernels, and a row's bits there depend neither on the other rows nor on their number (2..16 rows) -- only the
 // single-row kernels (replicated-LDS matvec, another summation order) differ from it in the last fp32 bit before the rounding.
+namespace aqlm {
+int gemm_kx8_xres_multi(const aqlm_hip_segment* segments, int num_segments, const void* X, int in_features, int K, int batch, long xs,
+                        int dtype, hipStream_t stream);  // gemm_mfma.hip
+}
+
 static bool kx8_rows_take_mfma(int batch, int K, int G) {
   const int min_rows = aqlm::tuning().kx8_mfma_min_rows;
   return min_rows > 0 && batch >= min_rows && G == 8 && (K == 1 || K == 2) && !aqlm::tuning().force_generic;
@@ -794,7 +799,16 @@ extern "C" int aqlm_hip_gemv_kx8_multi(const aqlm_hip_segment* segments, int num
   const size_t x_budget = std::min<size_t>(kMaxXTileBytes, 160 * 1024 - (size_t)K * 256 * 16 - 2048);
   const bool fast = in_group_size == 8 && (K == 1 || K == 2) && !tuning().force_generic && in_groups % 8 == 0 &&
                     aligned && xs % 8 == 0 && x_row_bytes + 256 <= x_budget;
-  // (3+ rows of 1x8 / 2x8 g8: one launch of the fused MFMA kernel per segment beats one matvec launch over all of them)
+  // 2+ rows of 1x8 / 2x8 g8 (round 5): ONE launch of the X-resident fused MFMA kernel over all layers -- X is loaded once, the layers'
+  // codebooks sit side by side in LDS, the tile walk runs over the layers back to back (bit-identical to separate launches)
+  {
+    const int mr = tuning().kx8_multi_xres_min_rows;
+    if (fast && mr > 0 && batch >= mr && batch <= 16 && (batch == 1 || kx8_rows_take_mfma(batch, K, in_group_size))) {
+      const int e = aqlm::gemm_kx8_xres_multi(segments, num_segments, x, in_features, K, batch, xs, dtype, stream);
+      if (e != AQLM_HIP_E_UNSUPPORTED) return e;
+    }
+  }
+  // (layers whose codebooks + X do not fit one LDS together: one launch of the fused MFMA kernel per segment still beats one matvec launch over all of them)
   if (!fast || kx8_rows_take_mfma(batch, K, in_group_size)) {  // other schemes (8x8 ...) and odd shapes: one launch per segment, same results as the single-layer op
     for (int k = 0; k < num_segments; ++k) {
       const aqlm_hip_segment& sg = segments[k];

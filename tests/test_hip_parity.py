@@ -1458,6 +1458,11 @@ def test_gemv_1x16_packed_multi_is_bit_identical_to_separate_launches(hk, fin, f
     (2, 1024, (256, 512), "float16", 1),           # < 4096 rows in total -> plain LDS kernel, one launch
     (2, 4096, (4096, 4096), "float16", 5),         # batch > 1 -> plain LDS kernel, batch chunks 4 + 1
     (1, 12352, (512, 512), "float16", 1),          # 4 unit iterations: replicated kernel refuses, plain kernel runs
+    (2, 4096, (4096, 1024, 1024), "float16", 4),   # round 5: 2+ rows -> ONE launch of the X-resident MFMA kernel over all layers
+    (2, 4096, (11008, 11008), "bfloat16", 8),      # gate / up, 64 KiB of X next to two layers' codebooks
+    (1, 2048, (300, 37, 4096, 16), "float16", 16), # four ragged layers, 1x8, the full first batch tile
+    (2, 11008, (4096, 4096), "float16", 3),        # 66 KiB of X: fits next to 32 KiB of codebooks
+    (2, 11008, (4096, 4096), "float16", 7),        # 154 KiB of X: does not fit -> one launch per layer (6 rows would; 7 do not)
 ])
 def test_gemv_kx8_multi_matches_separate_launches(hk, K, fin, fouts, dt, batch):
     dtype = tdtype(dt)
@@ -1473,6 +1478,8 @@ def test_gemv_kx8_multi_matches_separate_launches(hk, K, fin, fouts, dt, batch):
         check_close(y.float().cpu().numpy(), y64, dtype, f"multi {K}x8g8 {fin}->{L['codes'].shape[0]}")
         single = hk.codekx8_matmat(x, T["codes"], T["codebooks"], T["scales"], T["bias"])
         check_close(y.float().cpu().numpy(), single.float().cpu().numpy().astype(np.float64), dtype, "multi vs single")
+        if batch > 1:   # the fused MFMA kernel serves both forms: a tile's arithmetic does not know about the other layers
+            assert torch.equal(y, single), "shared-input launch differs from the layer's own launch"
         if T["bias"] is not None:   # zero input -> exactly the bias
             yz = torch.ops.aqlm.codekx8_matmat_multi(torch.zeros_like(x), [T["codes"]], [T["codebooks"]], [T["scales"]], [T["bias"]])[0]
             assert torch.equal(yz, T["bias"].expand_as(yz))

@@ -35,6 +35,25 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":  # python tools/gemm_kx8_xres_ben
     torch.cuda.synchronize()
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "multi":  # shared-input launches (q / k / v, gate / up): one launch over all layers vs one per layer
+    groups = {"llama2-7b q/k/v": (4096, (4096, 4096, 4096)), "llama2-7b gate/up": (4096, (11008, 11008)),
+              "llama3-8b q/k/v": (4096, (4096, 1024, 1024)), "llama2-13b gate/up": (5120, (13824, 13824))}
+    for name, (fin, fouts) in groups.items():
+        sets = [[layers(fin, fo, 2, 1)[0] for fo in fouts] for _ in range(16)]
+        scs = [torch.ones((fo, 1, 1, 1), device=dev, dtype=torch.float16) for fo in fouts]
+        for B in (1, 2, 4, 8, 16):
+            x = torch.randn((B, fin), device=dev).half()
+            res = {}
+            for rep in range(2):
+                for mr in (0, 2, 1):
+                    _native.set_tuning("kx8_multi_xres_min_rows", mr)
+                    t = timeit(lambda *ls: hk.codekx8_matmat_multi(x, [l[0] for l in ls], [l[1] for l in ls], scs, [None] * len(ls)),
+                               [tuple(st) for st in sets])
+                    res[mr] = min(res.get(mr, 1e9), t)
+            _native.set_tuning("kx8_multi_xres_min_rows", 2)
+            print(f"2x8g8 {name} {fin}->{fouts} B={B}: one launch per layer {res[0]:.2f} us  shared-input default {res[2]:.2f} us  X-resident kernel also at 1 row {res[1]:.2f} us", flush=True)
+    sys.exit(0)
+
 for K in (2, 1):
     for fin, fout in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (4096, 1024)):
         if K == 1 and (fin, fout) != (4096, 4096):

@@ -30,13 +30,13 @@ def layers(fin, fout, g, n):
 def timeit(fn, ls, reps=5):
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
-        for c, cb in ls:
-            fn(c, cb)
+        for item in ls:
+            fn(*item)
     st.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=st):
-        for c, cb in ls:
-            fn(c, cb)
+        for item in ls:
+            fn(*item)
     with torch.cuda.stream(st):
         g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
