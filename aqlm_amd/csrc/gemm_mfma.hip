@@ -1338,19 +1338,19 @@ struct KrParams {
   int B, in_groups, ntiles, nseg;
 };
 
-template <int K, int NSEG>
-struct KrLds {
-  static constexpr uint32_t CB = 0;                                  // [layer][K][256][16 B]
-  static constexpr uint32_t RED = (uint32_t)NSEG * K * 4096u;        // [2][KR_NW][64 lanes][16 B] fp32 partial tiles
-  static constexpr uint32_t X = RED + 2u * KR_NW * 1024u;            // the X image, rounded up to whole KiB (DMA granularity)
-  static size_t total(int B, int in_features) { return (size_t)X + (((size_t)B * in_features * 2 + 1023) & ~(size_t)1023); }
+template <int K>
+struct KrLds {  // sized by the number of layers of the launch: two layers leave room for a second workgroup per CU where four would not
+  static constexpr uint32_t CB = 0;                                                        // [layer][K][256][16 B]
+  static constexpr uint32_t red(int nseg) { return (uint32_t)nseg * K * 4096u; }          // [2][KR_NW][64 lanes][16 B] fp32 partial tiles
+  static constexpr uint32_t x(int nseg) { return red(nseg) + 2u * KR_NW * 1024u; }        // the X image, rounded up to whole KiB (DMA granularity)
+  static size_t total(int B, int in_features, int nseg) { return (size_t)x(nseg) + (((size_t)B * in_features * 2 + 1023) & ~(size_t)1023); }
 };
 
 __device__ __forceinline__ uint32_t kr_swz(uint32_t b) { return ((b >> 1) & 7u) ^ ((b & 8u) >> 1); }
 
 template <class T, int K, int NSEG>
 __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParams<NSEG> p) {
-  using LDS = KrLds<K, NSEG>;
+  using LDS = KrLds<K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1358,6 +1358,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
   const int arow = lane & 15, kg = lane >> 4;
   const uint32_t B = (uint32_t)p.B;
   const int nquads = p.in_groups >> 4;  // 128 k each (host: in_features % 128 == 0)
+  const uint32_t lds_red = LDS::red(NSEG == 1 ? 1 : p.nseg), lds_x = LDS::x(NSEG == 1 ? 1 : p.nseg);
   auto seg_of = [&](int tile) -> int {  // wave-uniform
     if constexpr (NSEG == 1) return 0;
     else return (int)(tile >= p.seg[1].tile0) + (int)(tile >= p.seg[2].tile0) + (int)(tile >= p.seg[3].tile0);  // (absent layers: tile0 = ntiles)
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
       const uint32_t cc = in ? c : 0u, rr = in ? r : 0u;
       const uint32_t b = rr >> 3, sl = rr & 7u;
       const uint32_t off = (b & 0xffu) * (xs2 & 0xffffffu) + cc * 128u + ((sl ^ kr_swz(b)) << 4);
-      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(xb + off), (glds_void_ptr)(size_t)(LDS::X + q0 * 16u), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(xb + off), (glds_void_ptr)(size_t)(lds_x + q0 * 16u), 16, 0, 0);
       q += KR_NW * 64u;
       c += dq;
       r += dr;
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
           w[j][k] = *(glds_u32x4_ptr)(size_t)(cb + (uint32_t)k * 4096u + byte * 16u);
         }
         const uint32_t c = (uint32_t)quad * 2u + (uint32_t)(kg >> 1), pc = (uint32_t)(kg & 1) * 4u + (uint32_t)j;
-        xb[j] = *(glds_u32x4_ptr)(size_t)(LDS::X + ((c * B + brow) * 8u + (pc ^ bsw)) * 16u);
+        xb[j] = *(glds_u32x4_ptr)(size_t)(lds_x + ((c * B + brow) * 8u + (pc ^ bsw)) * 16u);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1444,14 +1445,14 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
     }
     // ---- the eight K shares meet in LDS; wave 0 finishes the tile while the others start the next one
     const f32x4 mine = acc[0] + acc[1];
-    *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)(buf * KR_NW + wave) * 1024u + (uint32_t)lane * 16u) = mine;
+    *reinterpret_cast<f32x4*>(glds_smem + lds_red + (uint32_t)(buf * KR_NW + wave) * 1024u + (uint32_t)lane * 16u) = mine;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave == 0) {
       f32x4 v = mine;
 #pragma unroll
       for (int w8 = 1; w8 < KR_NW; ++w8)  // wave order: the result does not depend on who finishes first
-        v = v + *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(buf * KR_NW + w8) * 1024u + (uint32_t)lane * 16u);
+        v = v + *reinterpret_cast<const f32x4*>(glds_smem + lds_red + (uint32_t)(buf * KR_NW + w8) * 1024u + (uint32_t)lane * 16u);
       const KrSeg& S = p.seg[sg];
       const int m = (tile - S.tile0) * 16 + kg * 4;
       const int b = arow;
@@ -1475,15 +1476,15 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
 }
 
 // does the X-resident kernel take the call?  <= 16 rows whose image fits the LDS next to the codebooks and the partial tiles
-template <int K, int NSEG>
-static bool xres_fits(int B, int in_features, long xs) {
-  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K, NSEG>::total(B, in_features) <= 160u * 1024u && xs > 0 && xs < (1l << 22);
+template <int K>
+static bool xres_fits(int B, int in_features, long xs, int nseg = 1) {
+  return B >= 1 && B <= 16 && in_features % 128 == 0 && KrLds<K>::total(B, in_features, nseg) <= 160u * 1024u && xs > 0 && xs < (1l << 22);
 }
 
 template <class T, int K, int NSEG>
 static int launch_kx8_xres(const KrParams<NSEG>& p, int in_features, hipStream_t stream) {
   auto kern = gemm_kx8_xres_kernel<T, K, NSEG>;
-  const size_t lds = KrLds<K, NSEG>::total(p.B, in_features);
+  const size_t lds = KrLds<K>::total(p.B, in_features, p.nseg);
   if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   // one workgroup per CU and as many as fit its LDS (small X: two or more share a CU and overlap their latencies)
   static const int cus = [] {  // (initialised once, thread-safe; every GPU of a node is the same part)
@@ -1503,7 +1504,7 @@ namespace aqlm {
 int gemm_kx8_xres_multi(const aqlm_hip_segment* segments, int num_segments, const void* X, int in_features, int K, int batch, long xs,
                         int dtype, hipStream_t stream) {
   if (num_segments < 2 || num_segments > KR_MAX_SEG || !tuning().kx8_xres || (K != 1 && K != 2)) return AQLM_HIP_E_UNSUPPORTED;
-  if (!(K == 2 ? xres_fits<2, KR_MAX_SEG>(batch, in_features, xs) : xres_fits<1, KR_MAX_SEG>(batch, in_features, xs)) || !aligned16(X) || xs % 8 != 0)
+  if (!(K == 2 ? xres_fits<2>(batch, in_features, xs, num_segments) : xres_fits<1>(batch, in_features, xs, num_segments)) || !aligned16(X) || xs % 8 != 0)
     return AQLM_HIP_E_UNSUPPORTED;
   KrParams<KR_MAX_SEG> p{};
   int tiles = 0;
@@ -1569,7 +1570,7 @@ extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebook
     set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
     return AQLM_HIP_E_UNSUPPORTED;
   }
-  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2, 1>(batch, in_features, xs) : xres_fits<1, 1>(batch, in_features, xs))) {
+  if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2>(batch, in_features, xs) : xres_fits<1>(batch, in_features, xs))) {
     // <= 16 rows: X resident in LDS, no per-step synchronisation (round 5)
     KrParams<1> kr{};
     kr.seg[0].codes = (const uint8_t*)codes;
