@@ -57,6 +57,7 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "gemm_variant")) return &t.gemm_variant;
   if (!strcmp(key, "kx8_mfma_min_rows")) return &t.kx8_mfma_min_rows;
   if (!strcmp(key, "kx8_xres")) return &t.kx8_xres;
+  if (!strcmp(key, "kx8_xres_phased")) return &t.kx8_xres_phased;
   if (!strcmp(key, "kx8_multi_xres_min_rows")) return &t.kx8_multi_xres_min_rows;
   if (!strcmp(key, "kx8_ksplit")) return &t.kx8_ksplit;
   if (!strcmp(key, "kx8_rt")) return &t.kx8_rt;

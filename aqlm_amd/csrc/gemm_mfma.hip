@@ -1498,6 +1498,187 @@ static int launch_kx8_xres(const KrParams<NSEG>& p, int in_features, hipStream_t
   return check_hip(hipGetLastError(), "gemm_kx8_xres launch");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// X-resident kernel in PHASES (round 5): down-projection-shaped layers (11008 / 14336 / 28672 input features) at 7..16 rows have an X
+// image of 150-900 KiB -- it does not fit the LDS, and the call fell to the streaming 16-row kernel (16.7 us for 8 rows of
+// 11008 -> 4096 where 6 rows cost 10.6).  Here the image is loaded in nphases pieces of `qpp` quads (128 features each): all waves
+// walk the block's one or two tiles over the quads of the piece that is resident, the fp32 accumulators of the tiles stay in
+// registers across the phases (TPB x 2 x f32x4 per wave), and the K shares meet in LDS once, at the end.  The fill of a phase is
+// not overlapped with the arithmetic of the previous one (one image buffer) -- it costs what the bytes cost (X once per
+// workgroup) instead of the streaming kernel's step chain.  Same arithmetic per (row, quad) as gemm_kx8_xres_kernel and the
+// same summation order (per wave over its quads in ascending order, then the waves in wave order): the results are bit-identical
+// to the single-phase kernel's, so a row's bits still depend neither on the other rows nor on their number.
+struct KpParams {
+  const uint8_t* codes;      // [M][in_groups][K] u8
+  const uint8_t* codebooks;  // [K][256][8] halfs
+  const uint16_t* X;         // [B][xs]
+  const uint16_t* scales;
+  const uint16_t* bias;
+  uint16_t* Y;
+  long xs, ys;
+  int M, B, in_groups, ntiles, nphases, qpp;
+};
+
+template <int K, int TPB>
+struct KpLds {
+  static constexpr uint32_t CB = 0;                                  // [K][256][16 B]
+  static constexpr uint32_t RED = (uint32_t)K * 4096u;               // [KR_NW][TPB][64 lanes][16 B] fp32 partial tiles
+  static constexpr uint32_t X = RED + (uint32_t)KR_NW * TPB * 1024u; // the image of one phase
+  static size_t image_bytes(int B, int qpp) { return (size_t)B * qpp * 256; }
+};
+
+template <class T, int K, int TPB>
+__global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const KpParams p) {
+  using LDS = KpLds<K, TPB>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+  if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int arow = lane & 15, kg = lane >> 4;
+  const uint32_t B = (uint32_t)p.B;
+  const int nquads = p.in_groups >> 4;
+  const int grid = (int)gridDim.x;
+
+  if (wave < K * 4)
+    __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebooks + (size_t)wave * 1024 + lane * 16),
+                                     (glds_void_ptr)(size_t)(LDS::CB + (uint32_t)wave * 1024u), 16, 0, 0);
+  const uint32_t brow = (uint32_t)arow < B ? (uint32_t)arow : B - 1u;
+  const uint32_t bsw = kr_swz(brow);
+  typedef typename std::conditional<K == 2, u32x2, uint32_t>::type code_t;
+  auto code_ptr = [&](int tile, int quad) -> const code_t* {
+    int r = tile * 16 + arow;
+    r = r < p.M ? r : p.M - 1;
+    return reinterpret_cast<const code_t*>(p.codes + ((size_t)r * p.in_groups + (size_t)quad * 16 + (size_t)kg * 4) * K);
+  };
+  f32x4 acc[TPB][2];
+#pragma unroll
+  for (int ts = 0; ts < TPB; ++ts) acc[ts][0] = acc[ts][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ph = 0; ph < p.nphases; ++ph) {
+    const int q_lo = ph * p.qpp, q_hi = q_lo + p.qpp < nquads ? q_lo + p.qpp : nquads;
+    // wave w owns the quads = w (mod 8) whatever the phases are (the single-phase kernel's deal): the summation order of a row does
+    // not depend on how the image was cut, i.e. not on the number of rows of the call
+    const int q_first = q_lo + ((wave - q_lo) & (KR_NW - 1));
+    // the first code word of the phase is requested before its image (it does not depend on it)
+    code_t cnext{};
+    if ((int)blockIdx.x < p.ntiles && q_first < q_hi) cnext = *code_ptr((int)blockIdx.x, q_first);
+    if (ph > 0) __builtin_amdgcn_s_barrier();  // every wave is done with the previous image
+    {
+      // the image of quads [q_lo, q_hi): chunk c (64 features) of the piece, row b, 16-byte piece sl (stepped as in gemm_kx8_xres_kernel)
+      const uint32_t ppc = B * 8u;
+      const uint32_t npieces = (uint32_t)(q_hi - q_lo) * 2u * ppc;
+      const uint32_t dq = (KR_NW * 64u) / ppc, dr = (KR_NW * 64u) - dq * ppc;
+      const uint32_t xs2 = (uint32_t)p.xs * 2u;
+      uint32_t q = (uint32_t)wave * 64u + (uint32_t)lane;
+      uint32_t c = q / ppc, r = q - c * ppc;
+      const uint8_t* xb = (const uint8_t*)p.X + (size_t)q_lo * 256;  // 128 features x 2 bytes per quad
+      for (uint32_t q0 = (uint32_t)wave * 64u; q0 < npieces; q0 += KR_NW * 64u) {
+        const bool in = q < npieces;
+        const uint32_t cc = in ? c : 0u, rr = in ? r : 0u;
+        const uint32_t b = rr >> 3, sl = rr & 7u;
+        const uint32_t off = (b & 0xffu) * (xs2 & 0xffffffu) + cc * 128u + ((sl ^ kr_swz(b)) << 4);
+        __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(xb + off), (glds_void_ptr)(size_t)(LDS::X + q0 * 16u), 16, 0, 0);
+        q += KR_NW * 64u;
+        c += dq;
+        r += dr;
+        if (r >= ppc) {
+          r -= ppc;
+          c += 1u;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the image (and, in phase 0, the codebooks) are in LDS
+#pragma unroll
+    for (int ts = 0; ts < TPB; ++ts) {
+      const int tile = (int)blockIdx.x + ts * grid;
+      if (tile >= p.ntiles) break;
+      for (int quad = q_first; quad < q_hi; quad += KR_NW) {
+        const code_t cw = cnext;
+        {  // the next code word of this wave: the next quad of the tile, else the first quad of the block's next tile in this phase
+          int nq = quad + KR_NW, nt = tile;
+          if (nq >= q_hi) { nq = q_first; nt = tile + grid; }
+          if (nt < p.ntiles && nt < (int)blockIdx.x + TPB * grid && nq < q_hi) cnext = *code_ptr(nt, nq);
+        }
+        uint32_t cwords[2];
+        if constexpr (K == 2) { cwords[0] = cw.x; cwords[1] = cw.y; } else { cwords[0] = cw; cwords[1] = 0u; }
+        u32x4 w[4][K], xb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const uint32_t byte = K == 2 ? (cwords[j >> 1] >> (16 * (j & 1) + 8 * k)) & 0xffu : (cwords[0] >> (8 * j)) & 0xffu;
+            w[j][k] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (uint32_t)k * 4096u + byte * 16u);
+          }
+          const uint32_t c = (uint32_t)(quad - q_lo) * 2u + (uint32_t)(kg >> 1), pc = (uint32_t)(kg & 1) * 4u + (uint32_t)j;
+          xb[j] = *(glds_u32x4_ptr)(size_t)(LDS::X + ((c * B + brow) * 8u + (pc ^ bsw)) * 16u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[ts][(j * K + k) & 1] = mfma16<T>(w[j][k], xb[j], acc[ts][(j * K + k) & 1]);
+      }
+    }
+  }
+  // ---- the eight K shares of every tile meet in LDS; wave ts finishes tile ts
+#pragma unroll
+  for (int ts = 0; ts < TPB; ++ts)
+    *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)((wave * TPB + ts) * 1024) + (uint32_t)lane * 16u) = acc[ts][0] + acc[ts][1];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave < TPB) {
+    const int ts = wave, tile = (int)blockIdx.x + ts * grid;
+    if (tile < p.ntiles) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(ts * 1024) + (uint32_t)lane * 16u);
+#pragma unroll
+      for (int w8 = 1; w8 < KR_NW; ++w8)  // wave order, as in the single-phase kernel
+        v = v + *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)((w8 * TPB + ts) * 1024) + (uint32_t)lane * 16u);
+      const int m = tile * 16 + kg * 4;
+      const int b = arow;
+      if (b < p.B && m < p.M) {
+        uint16_t* dst = p.Y + (size_t)b * p.ys + m;
+        uint16_t h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mm = m + r < p.M ? m + r : p.M - 1;
+          const float sc = T::to_float(p.scales[mm]), bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
+          h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
+        }
+        if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        else
+          for (int r = 0; r < 4; ++r)
+            if (m + r < p.M) dst[r] = h[r];
+      }
+    }
+  }
+}
+
+// plan + launch; AQLM_HIP_E_UNSUPPORTED when the layer has more tiles than two per CU, or a phase would hold fewer than 8 quads
+template <class T, int K>
+static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t stream) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int tpb = p.ntiles <= cus ? 1 : 2;
+  if (p.ntiles > 2 * cus) return AQLM_HIP_E_UNSUPPORTED;
+  const size_t fixed = tpb == 1 ? KpLds<K, 1>::X : KpLds<K, 2>::X;
+  const int nquads = in_features / 128;
+  const int qmax = (int)((160u * 1024u - fixed) / ((size_t)p.B * 256));  // quads whose image fits
+  if (qmax < KR_NW) return AQLM_HIP_E_UNSUPPORTED;
+  p.nphases = (nquads + qmax - 1) / qmax;
+  p.qpp = (nquads + p.nphases - 1) / p.nphases;
+  const size_t lds = fixed + (((size_t)p.B * p.qpp * 256 + 1023) & ~(size_t)1023);
+  const int grid = (p.ntiles + tpb - 1) / tpb;
+  auto go = [&](auto kern) -> int {
+    if (int e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KR_NW * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "gemm_kx8_xres_phased launch");
+  };
+  return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1>) : go(gemm_kx8_xres_phased_kernel<T, K, 2>);
+}
+
 namespace aqlm {
 // Shared-input launches of the fused K x 8 op at <= 16 rows (called by aqlm_hip_gemv_kx8_multi; arguments validated there):
 // AQLM_HIP_E_UNSUPPORTED when the layers' codebooks + X do not fit the LDS together (the caller launches the layers one by one).
@@ -1589,6 +1770,26 @@ extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebook
     kr.nseg = 1;
     if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<F16, 1, 1>(kr, in_features, stream);
     return num_codebooks == 2 ? launch_kx8_xres<BF16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<BF16, 1, 1>(kr, in_features, stream);
+  }
+  if (batch <= 16 && tuning().kx8_xres && tuning().kx8_xres_phased && in_features % 128 == 0 && xs > 0 && xs < (1l << 22)) {
+    // <= 16 rows whose X image does not fit the LDS at once: the same kernel in phases (round 5)
+    KpParams kp{};
+    kp.codes = (const uint8_t*)codes;
+    kp.codebooks = (const uint8_t*)codebooks;
+    kp.X = (const uint16_t*)X;
+    kp.scales = (const uint16_t*)scales;
+    kp.bias = (const uint16_t*)bias;
+    kp.Y = (uint16_t*)Y;
+    kp.xs = xs;
+    kp.ys = ys;
+    kp.M = out_features;
+    kp.B = batch;
+    kp.in_groups = in_features / 8;
+    kp.ntiles = (out_features + 15) / 16;
+    int e;
+    if (dtype == AQLM_HIP_F16) e = num_codebooks == 2 ? launch_kx8_xres_phased<F16, 2>(kp, in_features, stream) : launch_kx8_xres_phased<F16, 1>(kp, in_features, stream);
+    else e = num_codebooks == 2 ? launch_kx8_xres_phased<BF16, 2>(kp, in_features, stream) : launch_kx8_xres_phased<BF16, 1>(kp, in_features, stream);
+    if (e != AQLM_HIP_E_UNSUPPORTED) return e;
   }
   // fp32 partials of the K-split form: [<= KX_MAX_KSPLIT][rows of the slab][out_features]; a workspace too small for a slab's plan
   // simply keeps that slab on the no-split form

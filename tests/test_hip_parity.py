@@ -421,8 +421,11 @@ def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
     (2, 4096, 4096, "float16", True),      # one tile per CU
     (2, 4096, 11008, "float16", False),    # 688 tiles on 256 CUs: workgroups walk 2-3 tiles, the reduction buffers alternate
     (1, 4096, 1000, "bfloat16", True),     # one codebook, ragged last tile
-    (2, 11008, 640, "float16", True),      # 86 quads (not a multiple of the 8 waves); 6 rows are 132 KiB of X: the largest image that fits
+    (2, 11008, 640, "float16", True),      # 86 quads (not a multiple of the 8 waves); 6 rows are 132 KiB of X: the largest image that fits --
+                                           # 7+ rows run the kernel in PHASES (round 5): 16 rows = 344 KiB of X in three pieces
     (2, 384, 40, "float16", True),         # 3 quads: five of the eight waves only take part in the barriers
+    (2, 14336, 4096, "float16", False),    # Llama-3-8B down projection: 5+ rows in phases (16 rows: 448 KiB in four), one tile per workgroup
+    (1, 8192, 6000, "bfloat16", True),     # 375 tiles: two tiles per workgroup in the phased form, the last workgroups hold one; 10+ rows phased
 ])
 def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     """The fused K x 8 MFMA op at <= 16 rows (round 5: X resident in LDS, aqlm_hip_gemm_kx8_mfma / the 3+ row route of
@@ -437,11 +440,11 @@ def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     op = hk.code2x8_matmat_dequant if K == 2 else hk.code1x8_matmat_dequant
     raw = hk.code2x8_matmat if K == 2 else hk.code1x8_matmat
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
-    rows_max = 16 if fin <= 4096 else 6
+    rows_max = 16   # (what does not fit the LDS at once runs in phases: same deal of the quads to the waves, same bits)
     y_full = op(T["x"][:rows_max], T["codes"], T["codebooks"], T["scales"], T["bias"])
     check_close(y_full.float().cpu().numpy(), y64[:rows_max], dtype, f"x-resident {K}x8 {fin}->{fout}, {rows_max} rows")
     assert torch.equal(y_full, op(T["x"][:rows_max], T["codes"], T["codebooks"], T["scales"], T["bias"]))
-    for B in (2, 3, 4, 6, 8, 13, 16):
+    for B in (2, 3, 4, 5, 6, 7, 8, 10, 13, 16):   # across the single-phase / phased boundary of the big-K layers too
         if B > rows_max:
             continue
         yb = op(T["x"][:B], T["codes"], T["codebooks"], T["scales"], T["bias"])
