@@ -157,6 +157,9 @@ class Layer:
             rc = lib.aqlm_hip_gemv_1x16(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                         self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.g, batch,
                                         self.fin, self.fout, _native.F16, stream)
+        elif batch > _native.MAX_GEMV_BATCH:  # 9+ rows of 1x8 / 2x8: the fused dequant -> MFMA op (the raw ops send them there too)
+            rc = lib.aqlm_hip_gemm_kx8_mfma(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None, self.x.data_ptr(),
+                                            self.y.data_ptr(), batch, self.fout, self.fin, self.K, self.g, self.fin, self.fout, _native.F16, stream)
         else:
             rc = lib.aqlm_hip_gemv_kx8(self.codes.data_ptr(), self.codebooks.data_ptr(), self.scales.data_ptr(), None,
                                        self.x.data_ptr(), self.y.data_ptr(), self.fout, self.fin, self.K, self.g, batch,
@@ -1183,6 +1186,26 @@ def main():
                                           "per_shape": per,
                                           "kernel": "gemv_kx8_rep_kernel (16-fold replicated codebooks in LDS)" if K == 2 else
                                                     "gemv_8x8_lut_kernel on planar codes (per-token look-up tables in LDS)"}
+        # 2x8 g8 at 1..16 input rows: one row = the replicated-LDS matvec, 2+ rows = the X-resident fused MFMA kernel (round 5; in phases
+        # where 11008 features x rows do not fit the LDS), against a dense fp16 GEMM on rotating weights
+        rows2 = {}
+        for fi, fo in ((4096, 4096), (4096, 11008), (11008, 4096)):
+            ls = [Layer(fi, fo, 2, 8, 8, 9600 + rank * 10000 + i, dev, batch=16) for i in range(min(64, int(600e6 / algorithmic_bytes(fi, fo, 2, 8, 8)) + 1))]
+            Ws = [torch.randn((fo, fi), device=dev, dtype=torch.float16) for _ in range(24)]
+            per = {}
+            for B in (1, 2, 4, 8, 16):
+                gpb = GraphedPass(ls, lib, batch=B)
+                per[f"B{B}"] = {"us": gpb.time_replays(reps) * 1e3 / gpb.n}
+                del gpb
+                xb = ls[0].x[:B]
+                gd = GraphedCalls([(lambda st, W=W: torch.nn.functional.linear(xb, W)) for W in Ws], dev)
+                per[f"B{B}"]["dense_fp16_us"] = gd.us_per_pass(reps) / len(Ws)
+                del gd
+            for B in (2, 4, 8, 16):
+                per[f"B{B}"]["vs_B1"] = per[f"B{B}"]["us"] / per["B1"]["us"]
+            rows2[f"{fi}->{fo}"] = per
+            del ls, Ws
+        detail["small_batch_rows_2x8g8"] = rows2
         # 8x8 g32 at 2..6 input rows (the module's gemv rule): the table kernel as ONE launch of rows x the single-row workgroups
         # (aqlm_hip_gemv_8x8_lut_batch, round 5) next to the plain LDS kernel that served 2+ rows before (VERDICT r04 missing #4),
         # and the fused dequant -> MFMA kernel (aqlm_hip_gemm_8x8_mfma) at 2..64 rows
