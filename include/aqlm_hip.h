@@ -108,7 +108,9 @@ int aqlm_hip_gemv_kx8(const void* codes_i8, const void* codebooks, const void* s
  * launch (tuned: 1x8 / 2x8 g8; other schemes run one launch per segment).  segment.codes is int8
  * [out_features][in_features/in_group_size][num_codebooks], segment.codebook is [num_codebooks][256][in_group_size].
  * Results agree with separate aqlm_hip_gemv_kx8 calls to fp32 rounding (a segment may run on a different kernel of
- * the family than it would alone: replicated-LDS vs plain LDS).
+ * the family than it would alone: replicated-LDS vs plain LDS).  2 .. 16 rows of 1x8 / 2x8 g8 (ABI 8): ONE launch of the X-resident
+ * fused MFMA kernel over all layers when their codebooks and the X image fit one LDS together (X loaded once, tile walk over the
+ * layers back to back) -- bit-identical to the layers' own calls; else one launch per layer.
  * Replaces: consecutive code2x8_matmat / code1x8_matmat calls on one hidden state (cuda_kernel.cpp:387-421, 552-586).
  */
 int aqlm_hip_gemv_kx8_multi(const aqlm_hip_segment* segments, int num_segments, const void* x, int in_features,
@@ -440,6 +442,9 @@ int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const f
  * (1x8 g8, 2x8 g8), W never materialised: the codebooks live in LDS, a block owns 16 output rows over all of K, every lane
  * takes its lanes of the 16 x 32 MFMA fragments straight from the codebook entries its code bytes name (one MFMA per codebook:
  * exact products, fp32 sums -- W is never rounded), X streams through LDS.  No workspace, one launch per 128 batch rows.
+ * At <= 16 rows (ABI 7) X is RESIDENT in LDS instead: a workgroup loads the X image once (in phases when batch x in_features x 2
+ * bytes exceed the LDS: ABI 8) and walks 16-row tiles with nothing to synchronise inside a tile; a row's bits then depend neither on
+ * the other rows of the call nor on their number.
  * Replaces: code2x8_matmat_dequant / code1x8_matmat_dequant = Code2x8Dequant / CodeKx8Dequant + F::linear(cuBLAS) + epilogue
  * (cuda_kernel.cpp:450-484, 615-649; kernels cuda_kernel.cu:235-294, 392-468).
  * AQLM_HIP_E_UNSUPPORTED (the caller dequantises + calls its GEMM, like the reference): other schemes, in_features not a
