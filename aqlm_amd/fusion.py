@@ -75,7 +75,16 @@ class SharedInputGroup:
             return False
         if torch.is_grad_enabled() and input.requires_grad:
             return False
-        return not torch.compiler.is_compiling()
+        if torch.compiler.is_compiling():
+            return False
+        first = self.members[0]
+        if first.num_codebooks == 8 and first.in_group_size == 32 and math.prod(input.shape[:-1]) > 2:
+            # 8x8 g32 from a few rows on: every member is better off alone on the fused MFMA kernel (its cost does not grow with the
+            # rows; the shared-input table kernel is launched once per row) -- measured in the Hugging Face decode loop at 4 rows:
+            # 389 tokens/s member by member, 314 through the group
+            if any(m._rows_take_the_fused_8x8_op(input) for m in self.members):
+                return False
+        return True
 
     def forward(self, member: QuantizedLinear, input: torch.Tensor) -> torch.Tensor:
         idx = next(i for i, m in enumerate(self.members) if m is member)

@@ -554,6 +554,37 @@ def test_fused_8x8g32_mfma(hk, fin, fout, rows, dt, bias, monkeypatch):
         assert hk._fused_8x8_mfma(T4["x"], T4["codes"], T4["codebooks"], T4["scales"], None, hk._dtype_id(T4["x"])) is None
 
 
+def test_8x8g32_shared_input_group_steps_aside_for_the_fused_kernel(hk):
+    """A shared-input group of 8x8 g32 layers serves 1-2 rows through the table kernel (one launch for all members); from the row
+    count at which a member's own fused MFMA kernel is faster, the group must not take the call (round 5: measured in the Hugging
+    Face decode loop at 4 rows, 389 tokens/s member by member vs 314 through the group)."""
+    import aqlm
+
+    fin = 4096
+    holder = torch.nn.Module()
+    Ls = {}
+    for k, (n, fo) in enumerate([("gate_proj", 512), ("up_proj", 768)]):
+        Ls[n] = orc.make_layer(4900 + k, fin, fo, 8, 8, 32, batch=5, bias=False)
+        m, _ = _module_from(Ls[n], 8, 8, 32, fin, fo, torch.float16)
+        setattr(holder, n, m)
+    x = to_dev(Ls["gate_proj"], torch.float16)["x"]
+    with torch.no_grad():
+        alone = {n: getattr(holder, n)(x) for n in Ls}
+        alone1 = {n: getattr(holder, n)(x[:1]) for n in Ls}
+        groups = aqlm.fuse_shared_input_linears(holder)
+        assert len(groups) == 1
+        g = groups[0]
+        assert g.applicable(x[:1]) and g.applicable(x[:2]) and not g.applicable(x)
+        for n in Ls:
+            assert torch.equal(getattr(holder, n)(x), alone[n])
+        assert g.launches == 0
+        x1 = x[:1]   # (the group recognises its siblings' calls by the identity of the input tensor)
+        for n in Ls:
+            assert torch.equal(getattr(holder, n)(x1), alone1[n])
+        assert g.launches == 1 and g.served == 1
+        aqlm.unfuse_shared_input_linears(holder)
+
+
 def test_kx8_mfma_route_inside_hipgraph(hk):
     """3+ row calls of the 8-bit ops (fused MFMA kernel behind aqlm_hip_gemv_kx8) and the large-batch op are captured and replayed
     like every other entry: no allocation, no synchronisation, same result as the eager call."""

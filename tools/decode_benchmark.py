@@ -76,12 +76,12 @@ class Decoder:
     """Greedy single-token decode with a static KV cache; every tensor the step touches is allocated once, so the step
     can be captured into a hipGraph (what notebooks/aqlm_cuda_graph.ipynb does with torch.compile / CUDA graphs)."""
 
-    def __init__(self, model, max_len, device):
+    def __init__(self, model, max_len, device, batch=1):
         from transformers import StaticCache
 
         self.model, self.device = model, device
         self.cache = StaticCache(config=model.config, max_cache_len=max_len)
-        self.tok = torch.zeros((1, 1), dtype=torch.long, device=device)
+        self.tok = torch.zeros((batch, 1), dtype=torch.long, device=device)
         self.pos = torch.zeros((1,), dtype=torch.long, device=device)
         self.graph = None
 
@@ -122,7 +122,7 @@ class Decoder:
 
 
 def measure(model, args, device, use_graph, prompt):
-    dec = Decoder(model, args.prompt + 3 * args.tokens + 16, device)
+    dec = Decoder(model, args.prompt + 3 * args.tokens + 16, device, batch=prompt.shape[0])
     dec.prefill(prompt)
     if use_graph:
         dec.capture()
@@ -133,8 +133,8 @@ def measure(model, args, device, use_graph, prompt):
     toks = dec.run(args.tokens)
     sync()
     dt = time.perf_counter() - t0
-    return {"tokens_per_s": args.tokens / dt, "ms_per_token": dt / args.tokens * 1e3,
-            "first_tokens": [int(t) for t in toks[:8]]}
+    return {"tokens_per_s": args.tokens * prompt.shape[0] / dt, "ms_per_token": dt / args.tokens * 1e3,   # ms per decode step (all sequences)
+            "first_tokens": [int(t[0]) for t in toks[:8]]}
 
 
 def main():
@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--scheme", default="1x16g8", choices=sorted(SCHEMES))
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--prompt", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded together (rows of every linear's input); tokens_per_s counts all of them")
+    ap.add_argument("--tune", default="", help="library tuning keys for A/B runs, e.g. kx8_xres=0,kx8_multi_xres_min_rows=0")
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--dense-only", action="store_true", help="skip the AQLM model (CPU smoke test of the loop)")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense fp16 baseline")
@@ -152,9 +154,10 @@ def main():
     if device.type == "cuda":
         torch.cuda.set_device(device)
     res = {"model": args.model, "scheme": args.scheme, "new_tokens": args.tokens, "prompt_tokens": args.prompt,
-           "dtype": str(dtype), "data": "random weights of the real shapes, greedy decode, static KV cache, batch 1"}
+           "dtype": str(dtype), "batch": args.batch,
+           "data": f"random weights of the real shapes, greedy decode, static KV cache, batch {args.batch}"}
     model = build_dense(args.model, device, dtype, args.prompt + 3 * args.tokens + 16)
-    prompt = torch.randint(0, model.config.vocab_size, (1, args.prompt), generator=torch.Generator().manual_seed(3)).to(device)
+    prompt = torch.randint(0, model.config.vocab_size, (args.batch, args.prompt), generator=torch.Generator().manual_seed(3)).to(device)
     graphs = [False, True] if device.type == "cuda" else [False]
     if not args.no_dense:
         for g in graphs:
@@ -162,6 +165,13 @@ def main():
     if not args.dense_only:
         import aqlm
 
+        if args.tune:
+            from aqlm_amd import _native
+
+            for kv in args.tune.split(","):
+                k, v = kv.split("=")
+                _native.set_tuning(k.strip(), int(v))
+            res["tune"] = args.tune
         res["quantized_linears"] = quantize_in_place(model, args.scheme, device, dtype)
         torch.cuda.empty_cache()
         for fused in (False, True):
