@@ -119,10 +119,11 @@ class FastLinear {
   // and the bytes of its aqlm_hip_packed_desc (kind 0), or the planar 8x8 codes and the 4 bytes of their codebook bound (kind 3:
   // single-row look-up-table matvec, aqlm_hip_gemv_8x8_lut_planar; the reference reaches Triton here, kernel_selector.py:91-94).
   FastLinear(py::dict params, int kind, c10::optional<at::Tensor> packed, std::string desc_bytes, int64_t in_features,
-             int64_t out_features, int64_t num_codebooks, int64_t in_group_size, bool watch_codes, int64_t max_rows)
+             int64_t out_features, int64_t num_codebooks, int64_t in_group_size, bool watch_codes, int64_t max_rows,
+             int64_t fused_8x8_from_rows = 0)
       : params_(std::move(params)), kind_(kind), in_(in_features), out_(out_features), K_((int)num_codebooks),
         g_((int)in_group_size), watch_codes_(watch_codes),
-        max_rows_(max_rows < AQLM_HIP_MAX_GEMV_BATCH ? max_rows : AQLM_HIP_MAX_GEMV_BATCH) {
+        max_rows_(max_rows < AQLM_HIP_MAX_GEMV_BATCH ? max_rows : AQLM_HIP_MAX_GEMV_BATCH), fused_8x8_from_rows_(fused_8x8_from_rows) {
     w_codes_ = watch(params_, "codes", &codes_);
     w_cb_ = watch(params_, "codebooks", &codebooks_);
     w_scales_ = watch(params_, "scales", &scales_);
@@ -145,6 +146,10 @@ class FastLinear {
       packed_ = *packed;
       std::memcpy(&absmax_, desc_bytes.data(), sizeof(float));
       TORCH_CHECK(absmax_ > 0.f && K_ == 8, "FastLinear: the look-up-table lane needs 8 codebooks and a positive codebook bound");
+      // 8x8 g32 with its checkpoint-layout codes still there: from fused_8x8_from_rows rows on the lane launches the fused dequant -> MFMA
+      // kernel (aqlm_hip_gemm_8x8_mfma) instead of the table kernel once per row
+      if (fused_8x8_from_rows_ > 0 && !(watch_codes_ && g_ == 32 && codes_.defined() && codes_.is_cuda() && codes_.is_contiguous() && codes_.numel() > 0))
+        fused_8x8_from_rows_ = 0;
     } else {
       TORCH_CHECK(codes_.defined() && codes_.is_cuda() && codes_.is_contiguous(), "FastLinear: canonical codes required");
     }
@@ -170,7 +175,10 @@ class FastLinear {
     int rc;
     {
       py::gil_scoped_release nogil;
-      if (kind_ == kLutPlanar8x8 && rows > 1)  // one launch of rows x the single-row workgroups
+      if (kind_ == kLutPlanar8x8 && fused_8x8_from_rows_ > 0 && rows >= fused_8x8_from_rows_)
+        rc = aqlm_hip_gemm_8x8_mfma(codes_.data_ptr(), codebooks_.data_ptr(), scales_.data_ptr(), bias, x2.data_ptr(), y.data_ptr(), (int)rows,
+                                    (int)out_, (int)in_, g_, x2.stride(0), out_, dtype_, stream);
+      else if (kind_ == kLutPlanar8x8 && rows > 1)  // one launch of rows x the single-row workgroups
         rc = aqlm_hip_gemv_8x8_lut_batch(packed_.data_ptr(), codebooks_.data_ptr(), scales_.data_ptr(), bias, x2.data_ptr(), y.data_ptr(),
                                          (int)out_, (int)in_, g_, (int)rows, x2.stride(0), out_, dtype_, 1, absmax_, cells, (size_t)kCellsBytes, stream);
       else if (kind_ == kLutPlanar8x8)
@@ -211,6 +219,7 @@ class FastLinear {
   int K_, g_;
   bool watch_codes_;
   int64_t max_rows_;
+  int64_t fused_8x8_from_rows_ = 0;
   int dtype_ = 0;
   at::Tensor codes_, codebooks_, scales_, packed_;
   c10::optional<at::Tensor> bias_;
@@ -536,9 +545,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled host glue of aqlm_amd's decode path (see aqlm_amd/csrc_front/front.cpp)";
   m.attr("ABI_VERSION") = AQLM_HIP_ABI_VERSION;
   py::class_<FastLinear, std::shared_ptr<FastLinear>>(m, "FastLinear")
-      .def(py::init<py::dict, int, c10::optional<at::Tensor>, std::string, int64_t, int64_t, int64_t, int64_t, bool, int64_t>(), py::arg("params"),
+      .def(py::init<py::dict, int, c10::optional<at::Tensor>, std::string, int64_t, int64_t, int64_t, int64_t, bool, int64_t, int64_t>(), py::arg("params"),
            py::arg("kind"), py::arg("packed"), py::arg("desc_bytes"), py::arg("in_features"), py::arg("out_features"),
-           py::arg("num_codebooks"), py::arg("in_group_size"), py::arg("watch_codes"), py::arg("max_rows"))
+           py::arg("num_codebooks"), py::arg("in_group_size"), py::arg("watch_codes"), py::arg("max_rows"), py::arg("fused_8x8_from_rows") = 0)
       .def("is_current", &FastLinear::is_current)
       .def("forward", &FastLinear::forward)
       .def("__call__", &FastLinear::forward)

@@ -414,14 +414,14 @@ class QuantizedLinear(nn.Module):
             kind, buf, desc = _front.KIND_GEMV_KX8, None, ""
         else:
             return
-        max_rows = GEMV_MAX_ROWS
+        fused_from = 0
         if (kind == _front.KIND_LUT_PLANAR_8X8 and hip_kernel.USE_FUSED_8X8_MFMA and not self._codes_dropped and self.in_group_size == 32
-                and self.in_features % 256 == 0 and self.in_features >= 2048):
-            # more rows: the fused MFMA op (forward hands them over)
-            max_rows = min(max_rows, hip_kernel.fused_8x8_min_rows(self.out_features, self.in_features) - 1)
+                and self.in_features % 256 == 0 and self.in_features >= 2048 and self.codes.is_cuda and self.codes.is_contiguous()):
+            # more rows: the lane launches the fused MFMA op on the checkpoint-layout codes (what forward would do through the ops)
+            fused_from = hip_kernel.fused_8x8_min_rows(self.out_features, self.in_features)
         try:
             self._fast = _front.ext.FastLinear(self._parameters, kind, buf, desc, self.in_features, self.out_features,
-                                               self.num_codebooks, self.in_group_size, not self._codes_dropped, max_rows)
+                                               self.num_codebooks, self.in_group_size, not self._codes_dropped, GEMV_MAX_ROWS, fused_from)
         except RuntimeError:
             self._fast = None
 

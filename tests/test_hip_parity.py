@@ -1711,7 +1711,8 @@ def test_8x8_module_uses_planar_codes_and_can_drop_the_canonical_ones(hk):
             assert holder.q_proj._fast is not None and holder.q_proj._fast.kind == _front.KIND_LUT_PLANAR_8X8
             y2f = holder.q_proj._fast(x3[:2])  # 2 rows: one launch of rows x the single-row workgroups (round 5)
             assert torch.equal(holder.q_proj._fast(x1), y1) and y2f is not None and torch.equal(y2f[:1], y1)
-            assert holder.q_proj._fast(x3) is None   # 3+ rows of 8x8 g32: handed back, forward sends them to the fused MFMA op
+            y3f = holder.q_proj._fast(x3)   # 3+ rows of 8x8 g32: the lane launches the fused MFMA kernel itself (same bits as the op)
+            assert y3f is not None and torch.equal(y3f, hk.codekx8_matmat(x3, T["codes"], T["codebooks"], T["scales"], T["bias"]))
             assert torch.equal(holder.q_proj(x1), y1)
         y64 = orc.dequantize_gemm(Ls["q_proj"]["x"], Ls["q_proj"]["codes"], Ls["q_proj"]["codebooks"], Ls["q_proj"]["scales"], Ls["q_proj"]["bias"])
         check_close(y1.float().cpu().numpy(), y64[:1], torch.float16, "8x8 module, one row")
