@@ -84,6 +84,25 @@ def check_close(y, y64, dtype, what="", el_scale=1.0):
     return m
 
 
+def check_rounded(y, y64, dtype, what=""):
+    """The arithmetic contract of the fused kernels -- exact fp16 / bf16 products, fp32 sums, `acc * scale + bias` in fp32, ONE rounding
+    -- stated without a hand-picked tolerance: the output must be the correctly rounded fp64 result, except where the fp32
+    accumulation noise (~ 2^-24 of the sum of |terms|, a few 1e-6 of the output scale) moves a value across a rounding boundary.
+    So: every element within one unit in the last place of the storage type (+ that noise) of the rounded oracle, and almost all of
+    them equal to it bit for bit.  (check_close's bf16 bounds -- 8e-3 mean, 1.6e-2 per element -- only say "one rounding of 8 bits".)"""
+    y = np.asarray(y, dtype=np.float64)
+    y64 = np.asarray(y64, dtype=np.float64)
+    yr = torch.from_numpy(y64).to(dtype).double().numpy()   # round-to-nearest-even into the storage type
+    sigma = float(np.sqrt(np.mean(y64 * y64)))
+    err = np.abs(y - yr)
+    bound = ulp(y64, dtype) + 2e-5 * sigma
+    bad = err > bound
+    assert not bad.any(), f"{what}: {bad.sum()} elements more than one ulp (+ fp32 noise) from the rounded oracle, worst {err.max():.4g}"
+    exact = float(np.mean(y == yr))
+    assert exact >= (0.97 if dtype == torch.float16 else 0.995), f"{what}: only {exact:.4f} of the outputs equal the correctly rounded result"
+    return exact
+
+
 def run_forward(hk, K, nbits, g, T, batch_shape=None):
     x = T["x"] if batch_shape is None else T["x"].reshape(*batch_shape, T["x"].shape[-1])
     if (K, nbits) == (1, 16):
@@ -208,6 +227,11 @@ def test_full_size_vs_c_oracle_and_properties(hk, K, nbits, g, fin, fout, dt):
     yh = y.float().cpu().numpy()
     for b in range(4):
         check_close(yh[b], ref(L["x"][b]).copy(), dtype, f"full {K}x{nbits}g{g} {fin}->{fout} row {b}")
+    # ... and against the fp64 oracle as a ROUNDING statement (no tolerance of our own choosing): the kernels' outputs are the correctly
+    # rounded result up to fp32 accumulation noise -- fp16 and bf16 alike
+    if fin * fout <= 1 << 26:
+        y64f = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
+        check_rounded(yh, y64f, dtype, f"full {K}x{nbits}g{g} {fin}->{fout}")
     # (2) batch consistency: a row of the batched launch == the same row launched alone (bit-exact)
     T1 = dict(T, x=T["x"][2:3].contiguous())
     y_single = run_forward(hk, K, nbits, g, T1)[0]
@@ -443,6 +467,7 @@ def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     rows_max = 16   # (what does not fit the LDS at once runs in phases: same deal of the quads to the waves, same bits)
     y_full = op(T["x"][:rows_max], T["codes"], T["codebooks"], T["scales"], T["bias"])
     check_close(y_full.float().cpu().numpy(), y64[:rows_max], dtype, f"x-resident {K}x8 {fin}->{fout}, {rows_max} rows")
+    check_rounded(y_full.float().cpu().numpy(), y64[:rows_max], dtype, f"x-resident {K}x8 {fin}->{fout}, {rows_max} rows")
     assert torch.equal(y_full, op(T["x"][:rows_max], T["codes"], T["codebooks"], T["scales"], T["bias"]))
     for B in (2, 3, 4, 5, 6, 7, 8, 10, 13, 16):   # across the single-phase / phased boundary of the big-K layers too
         if B > rows_max:
@@ -494,6 +519,7 @@ def test_fused_8x8g32_mfma(hk, fin, fout, rows, dt, bias, monkeypatch):
     assert y is not None
     y64 = orc.dequantize_gemm(L["x"], L["codes"], L["codebooks"], L["scales"], L["bias"])
     check_close(y.float().cpu().numpy(), y64, dtype, f"fused 8x8g32 mfma {fin}->{fout} rows {rows}")
+    check_rounded(y.float().cpu().numpy(), y64, dtype, f"fused 8x8g32 mfma {fin}->{fout} rows {rows}")
     assert torch.equal(y, hk._fused_8x8_mfma(T["x"], *args, hk._dtype_id(T["x"])))
     # the ops that lead to it: the large-batch op always, the decode op from FUSED_8X8_MFMA_MIN_ROWS rows on
     assert torch.equal(hk.code2x8_matmat_dequant(T["x"], *args), y)
