@@ -1502,7 +1502,7 @@ static int launch_kx8_xres(const KrParams<NSEG>& p, int in_features, hipStream_t
 // X-resident kernel in PHASES (round 5): down-projection-shaped layers (11008 / 14336 / 28672 input features) at 7..16 rows have an X
 // image of 150-900 KiB -- it does not fit the LDS, and the call fell to the streaming 16-row kernel (16.7 us for 8 rows of
 // 11008 -> 4096 where 6 rows cost 10.6).  Here the image is loaded in nphases pieces of `qpp` quads (128 features each): all waves
-// walk the block's one or two tiles over the quads of the piece that is resident, the fp32 accumulators of the tiles stay in
+// walk the block's one to three tiles over the quads of the piece that is resident, the fp32 accumulators of the tiles stay in
 // registers across the phases (TPB x 2 x f32x4 per wave), and the K shares meet in LDS once, at the end.  The fill of a phase is
 // not overlapped with the arithmetic of the previous one (one image buffer) -- it costs what the bytes cost (X once per
 // workgroup) instead of the streaming kernel's step chain.  Same arithmetic per (row, quad) as gemm_kx8_xres_kernel and the
@@ -1519,17 +1519,18 @@ struct KpParams {
   int M, B, in_groups, ntiles, nphases, qpp;
 };
 
-template <int K, int TPB>
+template <int K, int TPB, int NBT>
 struct KpLds {
-  static constexpr uint32_t CB = 0;                                  // [K][256][16 B]
-  static constexpr uint32_t RED = (uint32_t)K * 4096u;               // [KR_NW][TPB][64 lanes][16 B] fp32 partial tiles
-  static constexpr uint32_t X = RED + (uint32_t)KR_NW * TPB * 1024u; // the image of one phase
+  static constexpr uint32_t CB = 0;                                        // [K][256][16 B]
+  static constexpr uint32_t RED = (uint32_t)K * 4096u;                     // [KR_NW][TPB][NBT][64 lanes][16 B] fp32 partial tiles
+  static constexpr uint32_t X = RED + (uint32_t)KR_NW * TPB * NBT * 1024u; // the image of one phase
   static size_t image_bytes(int B, int qpp) { return (size_t)B * qpp * 256; }
 };
 
-template <class T, int K, int TPB>
+// NBT = 16-column batch tiles (17 .. 32 rows: two; the A fragments of a k-step feed both)
+template <class T, int K, int TPB, int NBT>
 __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const KpParams p) {
-  using LDS = KpLds<K, TPB>;
+  using LDS = KpLds<K, TPB, NBT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)glds_smem != 0u) __builtin_trap();  // LDS map above starts at 0
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1542,17 +1543,23 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const 
   if (wave < K * 4)
     __builtin_amdgcn_global_load_lds((ggbl_void_ptr)(p.codebooks + (size_t)wave * 1024 + lane * 16),
                                      (glds_void_ptr)(size_t)(LDS::CB + (uint32_t)wave * 1024u), 16, 0, 0);
-  const uint32_t brow = (uint32_t)arow < B ? (uint32_t)arow : B - 1u;
-  const uint32_t bsw = kr_swz(brow);
+  uint32_t brow[NBT], bsw[NBT];  // batch column of this lane's B fragments, per batch tile
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) {
+    brow[bt] = (uint32_t)(bt * 16 + arow) < B ? (uint32_t)(bt * 16 + arow) : B - 1u;
+    bsw[bt] = kr_swz(brow[bt]);
+  }
   typedef typename std::conditional<K == 2, u32x2, uint32_t>::type code_t;
   auto code_ptr = [&](int tile, int quad) -> const code_t* {
     int r = tile * 16 + arow;
     r = r < p.M ? r : p.M - 1;
     return reinterpret_cast<const code_t*>(p.codes + ((size_t)r * p.in_groups + (size_t)quad * 16 + (size_t)kg * 4) * K);
   };
-  f32x4 acc[TPB][2];
+  f32x4 acc[TPB][NBT][2];
 #pragma unroll
-  for (int ts = 0; ts < TPB; ++ts) acc[ts][0] = acc[ts][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ts = 0; ts < TPB; ++ts)
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) acc[ts][bt][0] = acc[ts][bt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int ph = 0; ph < p.nphases; ++ph) {
     const int q_lo = ph * p.qpp, q_hi = q_lo + p.qpp < nquads ? q_lo + p.qpp : nquads;
@@ -1602,7 +1609,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const 
         }
         uint32_t cwords[2];
         if constexpr (K == 2) { cwords[0] = cw.x; cwords[1] = cw.y; } else { cwords[0] = cw; cwords[1] = 0u; }
-        u32x4 w[4][K], xb[4];
+        u32x4 w[4][K], xb[4][NBT];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1611,30 +1618,36 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const 
             w[j][k] = *(glds_u32x4_ptr)(size_t)(LDS::CB + (uint32_t)k * 4096u + byte * 16u);
           }
           const uint32_t c = (uint32_t)(quad - q_lo) * 2u + (uint32_t)(kg >> 1), pc = (uint32_t)(kg & 1) * 4u + (uint32_t)j;
-          xb[j] = *(glds_u32x4_ptr)(size_t)(LDS::X + ((c * B + brow) * 8u + (pc ^ bsw)) * 16u);
+#pragma unroll
+          for (int bt = 0; bt < NBT; ++bt)
+            xb[j][bt] = *(glds_u32x4_ptr)(size_t)(LDS::X + ((c * B + brow[bt]) * 8u + (pc ^ bsw[bt])) * 16u);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int k = 0; k < K; ++k) acc[ts][(j * K + k) & 1] = mfma16<T>(w[j][k], xb[j], acc[ts][(j * K + k) & 1]);
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) acc[ts][bt][(j * K + k) & 1] = mfma16<T>(w[j][k], xb[j][bt], acc[ts][bt][(j * K + k) & 1]);
       }
     }
   }
-  // ---- the eight K shares of every tile meet in LDS; wave ts finishes tile ts
+  // ---- the eight K shares of every (row tile, batch tile) meet in LDS; wave ts NBT + bt finishes that pair
 #pragma unroll
   for (int ts = 0; ts < TPB; ++ts)
-    *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)((wave * TPB + ts) * 1024) + (uint32_t)lane * 16u) = acc[ts][0] + acc[ts][1];
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt)
+      *reinterpret_cast<f32x4*>(glds_smem + LDS::RED + (uint32_t)(((wave * TPB + ts) * NBT + bt) * 1024) + (uint32_t)lane * 16u) = acc[ts][bt][0] + acc[ts][bt][1];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (wave < TPB) {
-    const int ts = wave, tile = (int)blockIdx.x + ts * grid;
+  if (wave < TPB * NBT) {
+    const int ts = wave / NBT, bt = wave - ts * NBT, tile = (int)blockIdx.x + ts * grid;
     if (tile < p.ntiles) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(ts * 1024) + (uint32_t)lane * 16u);
+      f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)((ts * NBT + bt) * 1024) + (uint32_t)lane * 16u);
 #pragma unroll
       for (int w8 = 1; w8 < KR_NW; ++w8)  // wave order, as in the single-phase kernel
-        v = v + *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)((w8 * TPB + ts) * 1024) + (uint32_t)lane * 16u);
+        v = v + *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)(((w8 * TPB + ts) * NBT + bt) * 1024) + (uint32_t)lane * 16u);
       const int m = tile * 16 + kg * 4;
-      const int b = arow;
+      const int b = bt * 16 + arow;
       if (b < p.B && m < p.M) {
         uint16_t* dst = p.Y + (size_t)b * p.ys + m;
         uint16_t h[4];
@@ -1653,7 +1666,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const 
   }
 }
 
-// plan + launch; AQLM_HIP_E_UNSUPPORTED when the layer has more tiles than two per CU, or a phase would hold fewer than 8 quads
+// plan + launch; AQLM_HIP_E_UNSUPPORTED when the layer has more tiles than three per CU, or a phase would hold fewer than 8 quads
 template <class T, int K>
 static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t stream) {
   static const int cus = [] {
@@ -1661,9 +1674,10 @@ static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t strea
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
   }();
-  const int tpb = p.ntiles <= cus ? 1 : 2;
-  if (p.ntiles > 2 * cus) return AQLM_HIP_E_UNSUPPORTED;
-  const size_t fixed = tpb == 1 ? KpLds<K, 1>::X : KpLds<K, 2>::X;
+  const int tpb = (p.ntiles + cus - 1) / cus;  // tiles per workgroup: 1 .. 3 (their accumulators live in registers across the phases)
+  const int nbt = p.B <= 16 ? 1 : 2;
+  if (tpb > 3 || p.B > 32) return AQLM_HIP_E_UNSUPPORTED;
+  const size_t fixed = (size_t)KpLds<K, 1, 1>::RED + (size_t)KR_NW * tpb * nbt * 1024u;
   const int nquads = in_features / 128;
   const int qmax = (int)((160u * 1024u - fixed) / ((size_t)p.B * 256));  // quads whose image fits
   if (qmax < KR_NW) return AQLM_HIP_E_UNSUPPORTED;
@@ -1676,7 +1690,8 @@ static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t strea
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KR_NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemm_kx8_xres_phased launch");
   };
-  return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1>) : go(gemm_kx8_xres_phased_kernel<T, K, 2>);
+  if (nbt == 1) return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1, 1>) : (tpb == 2 ? go(gemm_kx8_xres_phased_kernel<T, K, 2, 1>) : go(gemm_kx8_xres_phased_kernel<T, K, 3, 1>));
+  return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1, 2>) : (tpb == 2 ? go(gemm_kx8_xres_phased_kernel<T, K, 2, 2>) : go(gemm_kx8_xres_phased_kernel<T, K, 3, 2>));
 }
 
 namespace aqlm {
@@ -1771,8 +1786,8 @@ extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebook
     if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<F16, 1, 1>(kr, in_features, stream);
     return num_codebooks == 2 ? launch_kx8_xres<BF16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<BF16, 1, 1>(kr, in_features, stream);
   }
-  if (batch <= 16 && tuning().kx8_xres && tuning().kx8_xres_phased && in_features % 128 == 0 && xs > 0 && xs < (1l << 22)) {
-    // <= 16 rows whose X image does not fit the LDS at once: the same kernel in phases (round 5)
+  if (batch <= (tuning().kx8_xres_phased == 2 ? 16 : 32) && tuning().kx8_xres && tuning().kx8_xres_phased && in_features % 128 == 0 && xs > 0 && xs < (1l << 21)) {
+    // <= 16 rows whose X image does not fit the LDS at once, and 17 .. 32 rows (two batch tiles): the same kernel in phases (round 5)
     KpParams kp{};
     kp.codes = (const uint8_t*)codes;
     kp.codebooks = (const uint8_t*)codebooks;

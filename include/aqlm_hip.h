@@ -442,8 +442,8 @@ int aqlm_hip_gemv_8x8_lut_planar_multi(const aqlm_hip_segment* segments, const f
  * (1x8 g8, 2x8 g8), W never materialised: the codebooks live in LDS, a block owns 16 output rows over all of K, every lane
  * takes its lanes of the 16 x 32 MFMA fragments straight from the codebook entries its code bytes name (one MFMA per codebook:
  * exact products, fp32 sums -- W is never rounded), X streams through LDS.  No workspace, one launch per 128 batch rows.
- * At <= 16 rows (ABI 7) X is RESIDENT in LDS instead: a workgroup loads the X image once (in phases when batch x in_features x 2
- * bytes exceed the LDS: ABI 8) and walks 16-row tiles with nothing to synchronise inside a tile; a row's bits then depend neither on
+ * At <= 32 rows (<= 16: ABI 7) X is RESIDENT in LDS instead: a workgroup loads the X image once (in phases when batch x in_features x 2
+ * bytes exceed the LDS, and for 17 .. 32 rows: ABI 8) and walks 16-row tiles with nothing to synchronise inside a tile; a row's bits then depend neither on
  * the other rows of the call nor on their number.
  * Replaces: code2x8_matmat_dequant / code1x8_matmat_dequant = Code2x8Dequant / CodeKx8Dequant + F::linear(cuBLAS) + epilogue
  * (cuda_kernel.cpp:450-484, 615-649; kernels cuda_kernel.cu:235-294, 392-468).

@@ -459,7 +459,7 @@ def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     from aqlm_amd import _native
 
     dtype = tdtype(dt)
-    L = orc.make_layer(9100 + fin + fout, fin, fout, K, 8, 8, batch=16, bias=bias, float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
+    L = orc.make_layer(9100 + fin + fout, fin, fout, K, 8, 8, batch=32, bias=bias, float_dtype=np.float16 if dtype == torch.float16 else "bfloat16")
     T = to_dev(L, dtype)
     op = hk.code2x8_matmat_dequant if K == 2 else hk.code1x8_matmat_dequant
     raw = hk.code2x8_matmat if K == 2 else hk.code1x8_matmat
@@ -476,6 +476,13 @@ def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
         assert torch.equal(yb, y_full[:B]), f"rows of a {B}-row call differ from the same rows of a {rows_max}-row call"
         if B <= 8:   # the decode route: aqlm_hip_gemv_kx8 hands 2+ rows to the same kernel
             assert torch.equal(raw(T["x"][:B], T["codes"], T["codebooks"], T["scales"], T["bias"]), yb)
+    # 17 .. 32 rows (round 5): the phased form with two batch tiles -- the same arithmetic per row, so the first 16 rows repeat bit for bit
+    if fin >= 1024 and (fout + 15) // 16 <= 768:   # (more than three tiles per CU: the streaming kernel, another summation order)
+        y32 = op(T["x"], T["codes"], T["codebooks"], T["scales"], T["bias"])
+        check_close(y32.float().cpu().numpy(), y64, dtype, f"x-resident {K}x8 {fin}->{fout}, 32 rows")
+        assert torch.equal(y32[:16], y_full)
+        for B in (17, 24, 31):
+            assert torch.equal(op(T["x"][:B], T["codes"], T["codebooks"], T["scales"], T["bias"]), y32[:B]), f"{B}-row call differs from the 32-row call"
     x2 = T["x"][:rows_max].clone()
     x2[1:] = torch.flip(x2[1:], dims=(0,))
     y2 = op(x2, T["codes"], T["codebooks"], T["scales"], T["bias"])

@@ -62,7 +62,7 @@ for K in (2, 1):
         scales = torch.ones((fout, 1, 1, 1), device=dev, dtype=torch.float16)
         Ws = [torch.randn((fout, fin), device=dev).half() for _ in range(24)]
         op = hk.code2x8_matmat_dequant if K == 2 else hk.code1x8_matmat_dequant
-        for B in (1, 2, 3, 4, 6, 8, 12, 16):
+        for B in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
             x = torch.randn((B, fin), device=dev).half()
             res = {}
             for xres in (1, 0, 1, 0):
