@@ -1186,14 +1186,14 @@ def main():
                                           "per_shape": per,
                                           "kernel": "gemv_kx8_rep_kernel (16-fold replicated codebooks in LDS)" if K == 2 else
                                                     "gemv_8x8_lut_kernel on planar codes (per-token look-up tables in LDS)"}
-        # 2x8 g8 at 1..16 input rows: one row = the replicated-LDS matvec, 2+ rows = the X-resident fused MFMA kernel (round 5; in phases
-        # where 11008 features x rows do not fit the LDS), against a dense fp16 GEMM on rotating weights
+        # 2x8 g8 at 1..32 input rows: one row = the replicated-LDS matvec, 2+ rows = the X-resident fused MFMA kernel (round 5; in phases
+        # where features x rows do not fit the LDS, and for 17..32 rows), against a dense fp16 GEMM on rotating weights
         rows2 = {}
         for fi, fo in ((4096, 4096), (4096, 11008), (11008, 4096)):
-            ls = [Layer(fi, fo, 2, 8, 8, 9600 + rank * 10000 + i, dev, batch=16) for i in range(min(64, int(600e6 / algorithmic_bytes(fi, fo, 2, 8, 8)) + 1))]
+            ls = [Layer(fi, fo, 2, 8, 8, 9600 + rank * 10000 + i, dev, batch=32) for i in range(min(64, int(600e6 / algorithmic_bytes(fi, fo, 2, 8, 8)) + 1))]
             Ws = [torch.randn((fo, fi), device=dev, dtype=torch.float16) for _ in range(24)]
             per = {}
-            for B in (1, 2, 4, 8, 16):
+            for B in (1, 2, 4, 8, 16, 32):
                 gpb = GraphedPass(ls, lib, batch=B)
                 per[f"B{B}"] = {"us": gpb.time_replays(reps) * 1e3 / gpb.n}
                 del gpb
@@ -1201,7 +1201,7 @@ def main():
                 gd = GraphedCalls([(lambda st, W=W: torch.nn.functional.linear(xb, W)) for W in Ws], dev)
                 per[f"B{B}"]["dense_fp16_us"] = gd.us_per_pass(reps) / len(Ws)
                 del gd
-            for B in (2, 4, 8, 16):
+            for B in (2, 4, 8, 16, 32):
                 per[f"B{B}"]["vs_B1"] = per[f"B{B}"]["us"] / per["B1"]["us"]
             rows2[f"{fi}->{fo}"] = per
             del ls, Ws
