@@ -268,3 +268,21 @@ def test_module_copies_and_pickles_after_a_forward_cpu(K, nbits, g):
     buf.seek(0)
     assert torch.equal(torch.load(buf, weights_only=False)(x), y)
     assert m.gemv_op is not None  # the original keeps its derived state
+
+
+def test_fused_8x8_switch_rows_follow_the_measured_cost_model():
+    """hip_kernel.fused_8x8_min_rows: the row count from which an 8x8 g32 layer leaves the look-up-table matvec for the fused MFMA
+    kernel -- the values the round-5 measurements gave (profiles/r05_gemm_8x8_mfma.log), monotone in the layer's work per round,
+    never below 2, pinned by FUSED_8X8_MFMA_MIN_ROWS; and the shared-input group steps aside exactly when a member would switch."""
+    from aqlm_amd.inference_kernels import hip_kernel as hk
+
+    assert hk.fused_8x8_min_rows(4096, 4096) == 3 and hk.fused_8x8_min_rows(11008, 4096) == 5 and hk.fused_8x8_min_rows(4096, 11008) == 5
+    assert hk.fused_8x8_min_rows(1024, 4096) == 3 and hk.fused_8x8_min_rows(16, 2048) >= 2
+    rows = [hk.fused_8x8_min_rows(m, 4096) for m in (4096, 8192, 16384, 32768)]
+    assert rows == sorted(rows)                      # more rounds of tiles -> the per-row table kernel stays ahead for longer
+    old = hk.FUSED_8X8_MFMA_MIN_ROWS
+    try:
+        hk.FUSED_8X8_MFMA_MIN_ROWS = 4
+        assert hk.fused_8x8_min_rows(4096, 4096) == 4 and hk.fused_8x8_min_rows(28672, 8192) == 4
+    finally:
+        hk.FUSED_8X8_MFMA_MIN_ROWS = old
