@@ -58,6 +58,8 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "kx8_mfma_min_rows")) return &t.kx8_mfma_min_rows;
   if (!strcmp(key, "kx8_xres")) return &t.kx8_xres;
   if (!strcmp(key, "kx8_xres_phased")) return &t.kx8_xres_phased;
+  if (!strcmp(key, "kx8_phase_tpb")) return &t.kx8_phase_tpb;
+  if (!strcmp(key, "kx8_phase_quads")) return &t.kx8_phase_quads;
   if (!strcmp(key, "kx8_multi_xres_min_rows")) return &t.kx8_multi_xres_min_rows;
   if (!strcmp(key, "kx8_ksplit")) return &t.kx8_ksplit;
   if (!strcmp(key, "kx8_rt")) return &t.kx8_rt;

@@ -153,6 +153,8 @@ struct Tuning {
   int gemm_variant = 0;          // large-batch 1x16 op: 0 = by batch (16-row no-split kernel <= 64 rows, K-split LDS-DMA pipeline above), 1 = register-staged split-K kernel (round 1), 2 = 16-row kernel wherever it applies, 3 = K-split pipeline only
   int kx8_xres = 1;              // fused K x 8 MFMA op at <= 16 rows: 1 = X resident in LDS (round 5), 0 = the streaming 16-row kernel (A/B runs)
   int kx8_xres_phased = 1;       // ... whose X image does not fit the LDS at once: 1 = the X-resident kernel in phases (round 5; also 17 .. 32 rows), 2 = up to 16 rows only, 0 = the streaming 16-row kernel
+  int kx8_phase_tpb = 0;         // experiments: 1..3 = every <= 32-row call on the phased kernel with this many tiles per workgroup (0 = off)
+  int kx8_phase_quads = 0;       // experiments: cap on the quads per phase (smaller image -> more workgroups per CU)
   int kx8_mfma_min_rows = 2;     // rows from which aqlm_hip_gemv_kx8[_multi] hands 1x8 / 2x8 g8 calls to the fused MFMA kernel (0 = never; 3 in round 4, 2 since the X-resident kernel)
   int kx8_multi_xres_min_rows = 2;  // shared-input launches of 1x8 / 2x8 g8: rows from which all layers run in ONE launch of the X-resident MFMA kernel (0 = never; 1 = batch 1 too)
   int kx8_ksplit = 0;            // fused K x 8 MFMA op with a workspace at >= 49 rows: 0 = K slices by the plan (<= 4), 1 = never split, 2 / 4 = force

@@ -1666,22 +1666,30 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const 
   }
 }
 
-// plan + launch; AQLM_HIP_E_UNSUPPORTED when the layer has more tiles than three per CU, or a phase would hold fewer than 8 quads
-template <class T, int K>
-static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t stream) {
-  static const int cus = [] {
+static int device_cus() {
+  static const int cus = [] {  // (initialised once, thread-safe; every GPU of a node is the same part)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
   }();
-  const int tpb = (p.ntiles + cus - 1) / cus;  // tiles per workgroup: 1 .. 3 (their accumulators live in registers across the phases)
+  return cus;
+}
+
+// plan + launch; AQLM_HIP_E_UNSUPPORTED when the layer has more tiles than four (17+ rows: three) per CU, or a phase would hold fewer than 8 quads
+template <class T, int K>
+static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t stream) {
+  const int cus = device_cus();
+  int tpb = (p.ntiles + cus - 1) / cus;  // tiles per workgroup: 1 .. 4 (their accumulators live in registers across the phases)
   const int nbt = p.B <= 16 ? 1 : 2;
-  if (tpb > 3 || p.B > 32) return AQLM_HIP_E_UNSUPPORTED;
+  const int exp_tpb = tuning().kx8_phase_tpb, exp_q = tuning().kx8_phase_quads;  // experiments: tiles per workgroup, quads per phase
+  if (exp_tpb >= 1 && exp_tpb <= 4) tpb = exp_tpb;
+  if (tpb > (nbt == 1 ? 4 : 3) || p.B > 32) return AQLM_HIP_E_UNSUPPORTED;
   const size_t fixed = (size_t)KpLds<K, 1, 1>::RED + (size_t)KR_NW * tpb * nbt * 1024u;
   const int nquads = in_features / 128;
   const int qmax = (int)((160u * 1024u - fixed) / ((size_t)p.B * 256));  // quads whose image fits
   if (qmax < KR_NW) return AQLM_HIP_E_UNSUPPORTED;
-  p.nphases = (nquads + qmax - 1) / qmax;
+  const int qcap = exp_q >= KR_NW && exp_q < qmax ? exp_q : qmax;
+  p.nphases = (nquads + qcap - 1) / qcap;
   p.qpp = (nquads + p.nphases - 1) / p.nphases;
   const size_t lds = fixed + (((size_t)p.B * p.qpp * 256 + 1023) & ~(size_t)1023);
   const int grid = (p.ntiles + tpb - 1) / tpb;
@@ -1690,8 +1698,13 @@ static int launch_kx8_xres_phased(KpParams p, int in_features, hipStream_t strea
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KR_NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "gemm_kx8_xres_phased launch");
   };
-  if (nbt == 1) return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1, 1>) : (tpb == 2 ? go(gemm_kx8_xres_phased_kernel<T, K, 2, 1>) : go(gemm_kx8_xres_phased_kernel<T, K, 3, 1>));
-  return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1, 2>) : (tpb == 2 ? go(gemm_kx8_xres_phased_kernel<T, K, 2, 2>) : go(gemm_kx8_xres_phased_kernel<T, K, 3, 2>));
+  if (nbt == 2) return tpb == 1 ? go(gemm_kx8_xres_phased_kernel<T, K, 1, 2>) : (tpb == 2 ? go(gemm_kx8_xres_phased_kernel<T, K, 2, 2>) : go(gemm_kx8_xres_phased_kernel<T, K, 3, 2>));
+  switch (tpb) {
+    case 1: return go(gemm_kx8_xres_phased_kernel<T, K, 1, 1>);
+    case 2: return go(gemm_kx8_xres_phased_kernel<T, K, 2, 1>);
+    case 3: return go(gemm_kx8_xres_phased_kernel<T, K, 3, 1>);
+    default: return go(gemm_kx8_xres_phased_kernel<T, K, 4, 1>);
+  }
 }
 
 namespace aqlm {
@@ -1766,6 +1779,35 @@ extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebook
     set_last_error("aqlm_hip_gemm_kx8_mfma: needs in_features %% 128 == 0, >= 384, and 16-B aligned codebooks / X rows");
     return AQLM_HIP_E_UNSUPPORTED;
   }
+  // layers of more tiles than CUs at 7+ rows: the phased form first -- every workgroup holds its 2..4 tiles' accumulators and the K shares
+  // meet once (measured, 2x8 g8 4096 -> 11008: 11.5 / 11.9 / 12.2 us at 8 / 12 / 16 rows on the single-phase kernel, 10.3 / 10.8 / 11.0 phased;
+  // at 4 rows 9.3 vs 10.1, and with one tile per CU the single-phase kernel is ahead: profiles/r05_gemm_kx8_phase_geometry.log)
+  const int ntiles_all = (out_features + 15) / 16;
+  const bool phased_first = (batch >= 7 && ntiles_all > device_cus() && ntiles_all <= 4 * device_cus()) || tuning().kx8_phase_tpb != 0;
+  auto try_phased = [&]() -> int {  // the X-resident kernel in phases: images that do not fit the LDS at once, 17 .. 32 rows, multi-round layers
+    if (!(batch <= (tuning().kx8_xres_phased == 2 ? 16 : 32) && tuning().kx8_xres && tuning().kx8_xres_phased && in_features % 128 == 0 && xs > 0 &&
+          xs < (1l << 21)))
+      return AQLM_HIP_E_UNSUPPORTED;
+    KpParams kp{};
+    kp.codes = (const uint8_t*)codes;
+    kp.codebooks = (const uint8_t*)codebooks;
+    kp.X = (const uint16_t*)X;
+    kp.scales = (const uint16_t*)scales;
+    kp.bias = (const uint16_t*)bias;
+    kp.Y = (uint16_t*)Y;
+    kp.xs = xs;
+    kp.ys = ys;
+    kp.M = out_features;
+    kp.B = batch;
+    kp.in_groups = in_features / 8;
+    kp.ntiles = (out_features + 15) / 16;
+    if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres_phased<F16, 2>(kp, in_features, stream) : launch_kx8_xres_phased<F16, 1>(kp, in_features, stream);
+    return num_codebooks == 2 ? launch_kx8_xres_phased<BF16, 2>(kp, in_features, stream) : launch_kx8_xres_phased<BF16, 1>(kp, in_features, stream);
+  };
+  if (phased_first) {
+    const int e = try_phased();
+    if (e != AQLM_HIP_E_UNSUPPORTED) return e;
+  }
   if (batch <= 16 && tuning().kx8_xres && (num_codebooks == 2 ? xres_fits<2>(batch, in_features, xs) : xres_fits<1>(batch, in_features, xs))) {
     // <= 16 rows: X resident in LDS, no per-step synchronisation (round 5)
     KrParams<1> kr{};
@@ -1786,24 +1828,8 @@ extern "C" int aqlm_hip_gemm_kx8_mfma_ws(const void* codes, const void* codebook
     if (dtype == AQLM_HIP_F16) return num_codebooks == 2 ? launch_kx8_xres<F16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<F16, 1, 1>(kr, in_features, stream);
     return num_codebooks == 2 ? launch_kx8_xres<BF16, 2, 1>(kr, in_features, stream) : launch_kx8_xres<BF16, 1, 1>(kr, in_features, stream);
   }
-  if (batch <= (tuning().kx8_xres_phased == 2 ? 16 : 32) && tuning().kx8_xres && tuning().kx8_xres_phased && in_features % 128 == 0 && xs > 0 && xs < (1l << 21)) {
-    // <= 16 rows whose X image does not fit the LDS at once, and 17 .. 32 rows (two batch tiles): the same kernel in phases (round 5)
-    KpParams kp{};
-    kp.codes = (const uint8_t*)codes;
-    kp.codebooks = (const uint8_t*)codebooks;
-    kp.X = (const uint16_t*)X;
-    kp.scales = (const uint16_t*)scales;
-    kp.bias = (const uint16_t*)bias;
-    kp.Y = (uint16_t*)Y;
-    kp.xs = xs;
-    kp.ys = ys;
-    kp.M = out_features;
-    kp.B = batch;
-    kp.in_groups = in_features / 8;
-    kp.ntiles = (out_features + 15) / 16;
-    int e;
-    if (dtype == AQLM_HIP_F16) e = num_codebooks == 2 ? launch_kx8_xres_phased<F16, 2>(kp, in_features, stream) : launch_kx8_xres_phased<F16, 1>(kp, in_features, stream);
-    else e = num_codebooks == 2 ? launch_kx8_xres_phased<BF16, 2>(kp, in_features, stream) : launch_kx8_xres_phased<BF16, 1>(kp, in_features, stream);
+  if (!phased_first) {
+    const int e = try_phased();
     if (e != AQLM_HIP_E_UNSUPPORTED) return e;
   }
   // fp32 partials of the K-split form: [<= KX_MAX_KSPLIT][rows of the slab][out_features]; a workspace too small for a slab's plan

@@ -450,6 +450,7 @@ def test_matmat_dequant_kx8_fused_mfma(hk, K, fin, fout, B, dt, bias):
     (2, 384, 40, "float16", True),         # 3 quads: five of the eight waves only take part in the barriers
     (2, 14336, 4096, "float16", False),    # Llama-3-8B down projection: 5+ rows in phases (16 rows: 448 KiB in four), one tile per workgroup
     (1, 8192, 6000, "bfloat16", True),     # 375 tiles: two tiles per workgroup in the phased form, the last workgroups hold one; 10+ rows phased
+    (2, 4096, 14336, "float16", True),     # 896 tiles: from 7 rows on the phased form with FOUR tiles per workgroup (2..6 rows: single phase)
 ])
 def test_fused_kx8_x_resident_small_batches(hk, K, fin, fout, dt, bias):
     """The fused K x 8 MFMA op at <= 16 rows (round 5: X resident in LDS, aqlm_hip_gemm_kx8_mfma / the 3+ row route of
