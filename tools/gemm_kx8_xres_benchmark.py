@@ -38,10 +38,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":  # python tools/gemm_kx8_xres_ben
 if len(sys.argv) > 1 and sys.argv[1] == "multi":  # shared-input launches (q / k / v, gate / up): one launch over all layers vs one per layer
     groups = {"llama2-7b q/k/v": (4096, (4096, 4096, 4096)), "llama2-7b gate/up": (4096, (11008, 11008)),
               "llama3-8b q/k/v": (4096, (4096, 1024, 1024)), "llama2-13b gate/up": (5120, (13824, 13824))}
+    rows_list = (1, 2, 4, 8, 16)
+    if len(sys.argv) > 2 and sys.argv[2] == "b1":  # where does the MFMA form win at ONE row?  (small groups)
+        groups = {"gqa 4096 q/k/v": (4096, (4096, 1024, 1024)), "two 4096": (4096, (4096, 4096)), "13b q/k/v": (5120, (5120, 5120, 5120)),
+                  "70b q/k/v": (8192, (8192, 1024, 1024)), "two 2048": (4096, (2048, 2048)), "small trio": (2048, (2048, 512, 512)),
+                  "mistral gate/up": (4096, (14336, 14336)), "k/v only": (4096, (1024, 1024))}
+        rows_list = (1,)
     for name, (fin, fouts) in groups.items():
         sets = [[layers(fin, fo, 2, 1)[0] for fo in fouts] for _ in range(16)]
         scs = [torch.ones((fo, 1, 1, 1), device=dev, dtype=torch.float16) for fo in fouts]
-        for B in (1, 2, 4, 8, 16):
+        for B in rows_list:
             x = torch.randn((B, fin), device=dev).half()
             res = {}
             for rep in range(2):
