@@ -198,7 +198,7 @@ __global__ __launch_bounds__(E8_NW * 64) void gemm_8x8g32_rows16_kernel(const E8
             const float sc = T::to_float(p.scales[mm]), bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
             h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
           }
-          if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+          if ((p.M & 3) == 0 && (p.ys & 3) == 0 && ((uintptr_t)dst & 7u) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
           else
             for (int r = 0; r < 4; ++r)
               if (m + r < p.M) dst[r] = h[r];

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           uint16_t h[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(acc[j][t][r], sc[r], bi[r]));
-          if (vec && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+          if (vec && (p.ys & 3) == 0 && ((uintptr_t)dst & 7u) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
           else
             for (int r = 0; r < 4; ++r)
               if (m + r < p.M) dst[r] = h[r];
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void gemm_glds_finalize_kernel(const GldsFinal
 #pragma unroll
   for (int r = 0; r < 4; ++r) h[r] = T::from_float(__builtin_fmaf(s[r], sc[r], bi[r]));
   uint16_t* dst = p.Y + (size_t)b * p.ys + m;
-  if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+  if ((p.M & 3) == 0 && (p.ys & 3) == 0 && ((uintptr_t)dst & 7u) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
   else
     for (int r = 0; r < 4; ++r)
       if (m + r < p.M) dst[r] = h[r];
@@ -875,7 +875,7 @@ __global__ __launch_bounds__((R16Lds<NBT, CPB>::WAVES * 64)) void gemm_1x16_rows
     sc[r] = T::to_float(p.scales[mm]);
     bi[r] = p.bias ? T::to_float(p.bias[mm]) : 0.f;
   }
-  const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0;
+  const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0 && ((uintptr_t)p.Y & 7u) == 0;  // (Y only 2- / 4-byte aligned: scalar stores)
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
     const int b = (cw * CT + t) * 16 + arow;
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__((KxLds<K, NBT, CPB, RT>::WAVES * 64)) void gemm_kx8
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // wave cw finishes tiles cw, cw + 4, ... of the RT x NBT output tiles: lane (arow, kg) holds rows 4 kg .. 4 kg + 3, batch column arow
-  const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0;
+  const bool vec = (p.M & 3) == 0 && (p.ys & 3) == 0 && ((uintptr_t)p.Y & 7u) == 0;  // (Y only 2- / 4-byte aligned: scalar stores)
   for (int tile = cw; tile < RT * NBT; tile += KX_NC) {
     const int rt = tile / NBT, bt = tile - rt * NBT;
     f32x4 v = *reinterpret_cast<const f32x4*>(glds_smem + LDS::RED + (uint32_t)tile * 1024u + (uint32_t)lane * 16u);
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_kernel(const KrParam
           const float sc = T::to_float(S.scales[mm]), bi = S.bias ? T::to_float(S.bias[mm]) : 0.f;
           h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
         }
-        if ((S.M & 3) == 0 && (S.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        if ((S.M & 3) == 0 && (S.ys & 3) == 0 && ((uintptr_t)dst & 7u) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
         else
           for (int r = 0; r < 4; ++r)
             if (m + r < S.M) dst[r] = h[r];
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(KR_NW * 64) void gemm_kx8_xres_phased_kernel(const 
           const float sc = T::to_float(p.scales[mm]), bi = p.bias ? T::to_float(p.bias[mm]) : 0.f;
           h[r] = T::from_float(__builtin_fmaf(v[r], sc, bi));
         }
-        if ((p.M & 3) == 0 && (p.ys & 3) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        if ((p.M & 3) == 0 && (p.ys & 3) == 0 && ((uintptr_t)dst & 7u) == 0) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
         else
           for (int r = 0; r < 4; ++r)
             if (m + r < p.M) dst[r] = h[r];

@@ -32,7 +32,9 @@ PREPACK_MIN_CODES = 500_000
 # call, cuda_kernel.cpp:148-182).  So every DERIVED_CHECK_EVERY-th forward of a module (never while a hipGraph is being captured
 # or traced) re-takes a 128-bit checksum of the parameters the derived state came from (aqlm_hip_checksum: one small kernel + a
 # 16-byte read-back per parameter, ~40 us) and rebuilds what no longer matches; `invalidate_derived_state()` does it on demand.
-# 0 = never check.
+# 0 = never check.  The check is EAGER-ONLY by construction: it never runs under hipGraph replay (a captured forward does not pass
+# through this Python at all) nor in a torch.compile'd graph -- there, call `invalidate_derived_state()` after such a write and
+# re-capture.  The modules of a model start their counters at different offsets, so the checks do not land on the same step.
 DERIVED_CHECK_EVERY = 256
 
 
@@ -141,7 +143,9 @@ class QuantizedLinear(nn.Module):
     def _record_derived_checks(self) -> None:
         """Checksums of the parameters the derived state was just built from (see DERIVED_CHECK_EVERY)."""
         self._derived_checks = None
-        self._calls_since_check = 0
+        # staggered start: the modules of a model were all built at the same forward; without an offset every 256th decode step would
+        # verify all of them at once (one multi-millisecond spike per 256 tokens instead of one module's ~40 us now and then)
+        self._calls_since_check = (id(self) >> 4) % DERIVED_CHECK_EVERY if DERIVED_CHECK_EVERY else 0
         if not DERIVED_CHECK_EVERY or (self._packed_codes is None and self._cpu_codes_alt is None and self._dense is None):
             return
         if torch.cuda.is_available() and self.codes.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -171,9 +175,11 @@ class QuantizedLinear(nn.Module):
         return ok
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        if self._derived_checks is not None:
+        # (is_compiling() FIRST: Dynamo specialises int attributes of a module, so a counter touched while tracing installs a guard
+        # `_calls_since_check == k` that fails on the next call and recompiles until the limit -- ADVICE r05)
+        if not torch.compiler.is_compiling() and self._derived_checks is not None:
             n = self._calls_since_check + 1
-            if n >= DERIVED_CHECK_EVERY > 0 and not torch.compiler.is_compiling() and not (input.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if n >= DERIVED_CHECK_EVERY > 0 and not (input.is_cuda and torch.cuda.is_current_stream_capturing()):
                 n = 0
                 self.verify_derived_state()
             self._calls_since_check = n

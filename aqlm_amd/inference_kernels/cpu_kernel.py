@@ -66,6 +66,9 @@ def permute_codes_for_lut(codes: torch.Tensor) -> torch.Tensor:
     return codes.permute(1, 0, 2).contiguous().view(torch.uint8)
 
 
+# (torch.compiler.disable: these functions hand raw pointers to libaqlm_cpu.so through ctypes -- Dynamo must call them, not trace them;
+# traced, the resumed frame passed pointers of tensors it no longer owned and the kernel wrote through them)
+@torch.compiler.disable
 def cpu_gemm_lut(input: torch.Tensor, codes_alt: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
                  bias: Optional[torch.Tensor], nthreads: int = 0) -> torch.Tensor:
     """K x 8-bit schemes through per-row look-up tables (reference: ``numba_gemm_lut``, numba_kernel.py:10-65, same
@@ -134,6 +137,7 @@ def _half_table(codebooks: torch.Tensor) -> Optional[torch.Tensor]:
     return half
 
 
+@torch.compiler.disable
 def cpu_gemv_1xn(input: torch.Tensor, codes: torch.Tensor, codebooks: torch.Tensor, scales: torch.Tensor,
                  bias: Optional[torch.Tensor], nthreads: int = 0) -> torch.Tensor:
     """One codebook of up to 65536 entries, g = 8 | 16, canonical codes [out, in_groups, 1] (int8 / int16 containers)."""

@@ -70,8 +70,9 @@ def test_bench_self_launches_under_torch_distributed_run():
     env["AQLM_BENCH_LAUNCH_PROBE"] = "1"
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
                                   cwd=ROOT, env=env, timeout=300, stderr=subprocess.DEVNULL)
-    res = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
-    assert res == {"launch_probe": True, "world": 2, "sum_of_ranks_plus_1": 3.0}
+    lines = out.decode().splitlines()
+    assert len(lines) == 1, lines  # ONE line on stdout for the whole job: rank 1 prints nothing, stray prints go to stderr
+    assert json.loads(lines[-1]) == {"launch_probe": True, "world": 2, "sum_of_ranks_plus_1": 3.0}
 
 
 def test_bench_launcher_command_is_the_drivers_form():
@@ -112,3 +113,31 @@ def test_bench_extras_watchdog_prints_the_line_and_ends_the_process():
              "print('done')\n") % ROOT
     p2 = subprocess.run([sys.executable, "-c", code2], cwd=ROOT, capture_output=True, timeout=120)
     assert p2.returncode == 0 and p2.stdout.strip() == b"done"
+
+
+def test_bench_result_line_is_the_last_and_only_thing_on_stdout(tmp_path):
+    """Round 5 lost its driver record to librccl's banner: a C-level printf sits in the stdio buffer of fd 1 and is flushed at
+    process exit, AFTER Python's print of the JSON line.  bench.py now points fd 1 at stderr for the life of the process and
+    writes the line to the saved descriptor as its last act (benchlib/emit.py).  The probe runs that very path with a pending C
+    printf, Python chatter and an atexit print in the way; the driver's parse -- json.loads of the last stdout line, which must
+    carry `roofline` and `cpu_baseline` -- has to succeed, and nothing else may be on stdout."""
+    side = tmp_path / "bench_result.json"
+    env = dict(os.environ, AQLM_BENCH_EMIT_PROBE="1", AQLM_BENCH_RESULT_FILE=str(side))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=ROOT, env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    lines = p.stdout.decode().splitlines()
+    parsed = json.loads(lines[-1])
+    assert "roofline" in parsed and "cpu_baseline" in parsed and parsed["value"] == 1.0
+    assert len(lines) == 1, lines
+    assert b"pretend banner" in p.stderr and b"python chatter" in p.stderr  # the chatter is not lost, it is on stderr
+    assert b"atexit chatter" not in p.stdout + p.stderr                      # os._exit: nothing runs after the line
+    assert json.loads(side.read_text()) == parsed                            # the same document next to it
+
+
+def test_bench_headline_path_stays_readable():
+    """VERDICT r05 item 8: the headline path of bench.py (arguments, workload, timed region, roofline, emission) stays under 300 lines;
+    the untimed extras live in benchlib/."""
+    n = sum(1 for _ in open(os.path.join(ROOT, "bench.py")))
+    assert n < 300, n
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "emit_final(result, rank" in src and "StdoutGuard.install()" in src and "print(json.dumps" not in src
