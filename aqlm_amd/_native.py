@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQLM_AMD_HIP_LIB: another build of the same library (same-box A/B runs of two commits, tools/gpu/r3_ab*.sh); default: in-tree
 LIB_PATH = os.environ.get("AQLM_AMD_HIP_LIB") or os.path.join(_HERE, "libaqlm_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F16, BF16 = 0, 1
 E_INVALID, E_UNSUPPORTED = -1, -2
@@ -133,6 +133,8 @@ SIGNATURES = {
     "aqlm_hip_dequant_kx8": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_dequant_generic": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
     "aqlm_hip_gemm_1x16_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemm_1x16_scan": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
+    "aqlm_hip_gemm_1x16_scan_workspace_bytes": (_sz, [_ci, _ci, _ci]),
     "aqlm_hip_gemm_kx8_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),
     "aqlm_hip_gemm_kx8_mfma_ws": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp, _sz, _vp]),
     "aqlm_hip_gemm_8x8_mfma": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cl, _cl, _ci, _vp]),

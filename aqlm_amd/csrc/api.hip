@@ -63,6 +63,8 @@ static int* tuning_slot(const char* key) {
   if (!strcmp(key, "kx8_multi_xres_min_rows")) return &t.kx8_multi_xres_min_rows;
   if (!strcmp(key, "kx8_ksplit")) return &t.kx8_ksplit;
   if (!strcmp(key, "kx8_rt")) return &t.kx8_rt;
+  if (!strcmp(key, "scan_max_rows")) return &t.scan_max_rows;
+  if (!strcmp(key, "scan_prefetch")) return &t.scan_prefetch;
   if (!strcmp(key, "gemm_debug")) return &t.gemm_debug;
   if (!strcmp(key, "gemm_store_nt")) return &t.gemm_store_nt;
   if (!strcmp(key, "force_generic")) return &t.force_generic;

@@ -1294,6 +1294,7 @@ extern "C" size_t aqlm_hip_workspace_bytes(int op, int batch, int out_features, 
   GldsPlan q;
   if (plan_glds(std::min(batch, 128), out_features, in_features, q) && q.ksplit > 1)
     need = std::max(need, (size_t)q.ksplit * std::min(batch, 128) * out_features * sizeof(float));
+  need = std::max(need, scan::workspace_bytes(batch, out_features, in_features));  // the slice-scan kernel's planes (gemm_variant 0 / 4)
   return need;
 }
 
@@ -1922,10 +1923,16 @@ extern "C" int aqlm_hip_gemm_1x16_mfma(const void* codes, const void* codebook, 
     set_last_error("aqlm_hip_gemm_1x16_mfma: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return AQLM_HIP_E_INVALID;
   }
+  // gemm_variant: 0 = the slice-scan kernel (gemm_1x16_scan.hip, round 6: codebook slices in LDS, no L2 gathers) up to scan_max_rows
+  // where it applies, else round 5's routing (5): 16-row blocks where they pay, else the K-split pipeline; 1 = register-staged kernel of
+  // round 1, 2 = 16-row blocks wherever they apply, 3 = K-split pipeline only, 4 = slice-scan kernel at any row count
+  int variant = tuning().gemm_variant;
+  if ((variant == 4 || (variant == 0 && batch <= tuning().scan_max_rows)) && in_group_size == 8 &&
+      scan::workspace_bytes(batch, out_features, in_features) != 0 && aligned16(workspace)) {
+    return scan::run(codes, codebook, scales, bias, X, Y, batch, out_features, in_features, xs, ys, dtype, workspace, stream);
+  }
+  if (variant == 4 || variant == 5) variant = 0;
   // batch > 128 is processed in slabs of 128 columns (codes re-gathered per slab)
-  // gemm_variant: 0 = by batch and layer size (16-row blocks where they pay, else the K-split pipeline), 1 = register-staged kernel of
-  // round 1, 2 = 16-row blocks wherever they apply, 3 = K-split pipeline only
-  const int variant = tuning().gemm_variant;
   const bool use_glds = variant != 1;
   for (int b0 = 0; b0 < batch; b0 += 128) {
     const int nb = std::min(128, batch - b0);

@@ -1168,6 +1168,37 @@ def _fused_mfma_ok(x, in_features):
     return in_features % 64 == 0 and x.shape[0] <= FUSED_MFMA_MAX_ROWS
 
 
+def code1x16_matmat_scan(input, codes, codebooks, scales, bias=None):
+    """1x16 g8 at 2+ rows on the slice-scan MFMA kernel (aqlm_hip_gemm_1x16_scan, round 6): codebook slices in LDS, canonical codes,
+    no gathers from L2.  Returns None when the kernel does not take the layer (codebook vectors other than 8, in_features % 256 != 0,
+    misaligned rows) -- callers then use `code1x16_matmat_dequant`, which also routes here by default."""
+    if codebooks.shape[0] != 1 or codebooks.shape[1] != 65536 or codebooks.shape[2] != 1 or codebooks.shape[3] != 8:
+        return None
+    out_features, in_features = codes.shape[0], codes.shape[1] * 8
+    if input.shape[-1] != in_features:
+        raise ValueError(f"input has {input.shape[-1]} features, layer expects {in_features}")
+    x = _flat_rows(input)
+    B = x.shape[0]
+    if B == 0 or in_features % 256 != 0 or x.stride(0) % 8 != 0 or x.data_ptr() % 16 != 0:
+        return None
+    dt = _dtype_id(input)
+    ws_bytes = _lib.aqlm_hip_gemm_1x16_scan_workspace_bytes(B, out_features, in_features)
+    if ws_bytes == 0:
+        return None
+    codes, codebooks, scales = _c(codes), _c(codebooks), _c(scales)
+    if bias is not None:
+        bias = _c(bias)
+    y = torch.empty((B, out_features), dtype=input.dtype, device=input.device)
+    ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=input.device)
+    with _device_guard(input.device):
+        rc = _lib.aqlm_hip_gemm_1x16_scan(codes.data_ptr(), codebooks.data_ptr(), scales.data_ptr(), _ptr(bias), x.data_ptr(), y.data_ptr(),
+                                          B, out_features, in_features, x.stride(0), out_features, dt, ws.data_ptr(), ws.numel() * 4,
+                                          _stream_ptr(input.device))
+    if rc:
+        _native.check(rc, "aqlm gemm_1x16_scan")
+    return y.reshape(input.shape[:-1] + (out_features,))
+
+
 def code1x16_matmat_dequant(input, codes, codebooks, scales, bias=None):
     """aqlm::code1x16_matmat_dequant (cuda_kernel.py:24-35, cuda_kernel.cpp:249-301) -- fused MFMA kernel."""
     dt = _dtype_id(input)

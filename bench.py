@@ -237,25 +237,30 @@ def main():
     # ---- everything below is OUTSIDE the timed region and must never cost the headline line: a watchdog emits what there is and
     # ends the process if the extras are not done within their budget
     extras = ExtrasWatchdog(result, rank, float(os.environ.get("AQLM_BENCH_EXTRAS_TIMEOUT_S", "480")), side_file)
-    if rank == 0 and not args.no_cpu:  # the CPU leg first: the contract's `cpu_baseline` must not depend on the budgeted extras
-        extras.section = "cpu_baseline"
-        result["cpu_baseline"] = CPU.cpu_baseline(float(os.environ.get("AQLM_BENCH_CPU_SAMPLE_S", "12")))
-    if not args.no_detail:
-        from benchlib import detail as DT
-        from benchlib import sharded as SH
+    try:
+        if rank == 0 and not args.no_cpu:  # the CPU leg first: the contract's `cpu_baseline` must not depend on the budgeted extras
+            extras.section = "cpu_baseline"
+            result["cpu_baseline"] = CPU.cpu_baseline(float(os.environ.get("AQLM_BENCH_CPU_SAMPLE_S", "12")))
+        if not args.no_detail:
+            from benchlib import detail as DT
+            from benchlib import sharded as SH
 
-        extras.section = "sharded_70b"
-        try:
-            result["sharded_70b"] = SH.sharded_70b(lib, dev, rank, world, args.steps)
-        except Exception as e:  # noqa: BLE001 - an extra never costs the headline line
-            result["sharded_70b"] = {"error": f"{type(e).__name__}: {e}"}
-        result["detail"] = {}  # filled in place: a timed-out run still reports what it had
-        budget = 0.0 if args.full_detail else float(os.environ.get("AQLM_BENCH_DETAIL_BUDGET_S", "38"))
-        ctx = DT.Ctx(lib, dev, rank, world, max(4, args.steps // 5), layers, NBLOCKS, value)
-        DT.run_detail(ctx, result["detail"], T_PROCESS, budget, args.full_detail, extras)
-    if rank == 0 and not args.no_cpu:
-        extras.section = "gpu_reference_baseline"
-        result["gpu_reference_baseline"] = CPU.gpu_reference_baseline()
+            extras.section = "sharded_70b"
+            try:
+                result["sharded_70b"] = SH.sharded_70b(lib, dev, rank, world, args.steps)
+            except Exception as e:  # noqa: BLE001 - an extra never costs the headline line
+                result["sharded_70b"] = {"error": f"{type(e).__name__}: {e}"}
+            result["detail"] = {}  # filled in place: a timed-out run still reports what it had
+            budget = 0.0 if args.full_detail else float(os.environ.get("AQLM_BENCH_DETAIL_BUDGET_S", "38"))
+            ctx = DT.Ctx(lib, dev, rank, world, max(4, args.steps // 5), layers, NBLOCKS, value)
+            DT.run_detail(ctx, result["detail"], T_PROCESS, budget, args.full_detail, extras)
+        if rank == 0 and not args.no_cpu:
+            extras.section = "gpu_reference_baseline"
+            result["gpu_reference_baseline"] = CPU.gpu_reference_baseline()
+    except Exception as e:  # noqa: BLE001 - whatever an extra does (an import error included), the line goes out
+        import traceback
+
+        result["extras_error"] = {"section": extras.section, "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
     result["bench_wall_s"] = round(time.perf_counter() - T_PROCESS, 1)
 
     if not extras.finish():

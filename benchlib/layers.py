@@ -260,3 +260,62 @@ def _time_calls(fn, budget_s, max_iters, warmup):
         times.append(time.perf_counter() - t1)
     return {"mean": float(np.mean(times)), "median": float(np.median(times)), "min": float(np.min(times))}, len(times)
 
+
+
+class GraphedCalls:
+    """A sequence of callables `fn(stream)` -- kernel launches through the C ABI and torch.distributed collectives alike -- captured
+    into ONE hipGraph on a side stream (after an eager pass on that stream, which also initialises the communicator), timed by
+    replays between HIP events, MAX over the ranks.  An eager RCCL call costs 20-30 us of host time and would swamp a 10-25 us
+    kernel budget; a captured one is a graph node like the kernels around it.  If a collective cannot be captured the same calls
+    are timed eagerly and `timing` says so."""
+
+    def __init__(self, calls, dev):
+        self.calls, self.dev = calls, dev
+        self.stream = torch.cuda.Stream()
+        self.timing = "hipgraph"
+        with torch.cuda.stream(self.stream):
+            for fn in calls:
+                fn(self.stream)
+        self.stream.synchronize()
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of torch.distributed queries events while this thread captures; in the default
+            # ("global") mode such a call from another thread invalidates the capture
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                for fn in calls:
+                    fn(torch.cuda.current_stream())
+            self.graph.replay()
+            self.stream.synchronize()
+        except Exception as e:  # noqa: BLE001 - reported in the bench line
+            self.graph, self.timing = None, f"eager ({type(e).__name__}: {str(e)[:120]})"
+            torch.cuda.synchronize()
+
+    def us_per_pass(self, reps, dist=None):
+        import torch.distributed as td
+
+        def run():
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                for fn in self.calls:
+                    fn(self.stream)
+
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):
+                run()
+        torch.cuda.synchronize()
+        if dist is not None and td.is_initialized() and td.get_world_size() > 1:
+            td.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            e0.record(self.stream)
+            for _ in range(reps):
+                run()
+            e1.record(self.stream)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        if dist is not None and td.is_initialized() and td.get_world_size() > 1:
+            t = torch.tensor([us], device=self.dev, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            us = float(t)
+        return us

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AQLM_HIP_ABI_VERSION 8
+#define AQLM_HIP_ABI_VERSION 9
 
 #define AQLM_HIP_F16 0
 #define AQLM_HIP_BF16 1
@@ -156,9 +156,11 @@ int aqlm_hip_dequant_generic(const void* codes, const void* codebooks, const voi
 /*
  * Large-batch path: Y[B][out] = (X[B][in] @ W^T) * scales + bias with W dequantised tile-by-tile into LDS and
  * contracted on the matrix cores (v_mfma_f32_16x16x32_f16/bf16: a gathered codebook vector IS a fragment lane); W never
- * touches HBM.  Two kernels behind the entry, chosen by batch and layer size (tuning key `gemm_variant` forces one): a K-split
- * pipeline with fp32 partials in `workspace` + a finalize launch, and (<= 16 rows; <= 64 rows on layers of <= 4096 x 4096) a
- * single launch of 16-row blocks over all of K that uses no workspace.
+ * touches HBM.  Three kernels behind the entry, chosen by batch and layer shape (tuning key `gemm_variant` forces one): the slice-scan
+ * kernel of aqlm_hip_gemm_1x16_scan (in_group_size 8, in_features % 256 == 0, up to `scan_max_rows` = 128 rows: codebook slices in
+ * LDS, no gathers from L2), and round 5's L2-gather kernels for everything else: a K-split pipeline with fp32 partials in
+ * `workspace` + a finalize launch, and (<= 16 rows; <= 64 rows on layers of <= 4096 x 4096) a single launch of 16-row blocks over
+ * all of K that uses no workspace.
  * Replaces: code1x16_matmat_dequant = Code1x16Dequant + F::linear(cuBLAS) + epilogue (cuda_kernel.cpp:249-301).
  * X and Y are row-major with the given row strides (elements).  workspace: aqlm_hip_workspace_bytes(...) bytes
  * (may be 0 -> NULL allowed).
@@ -167,6 +169,24 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
                             const void* X, void* Y, int batch, int out_features, int in_features,
                             int in_group_size, long x_row_stride, long y_row_stride, int dtype, void* workspace,
                             size_t workspace_bytes, void* stream);
+
+/*
+ * 1x16, in_group_size 8, at 2 .. any number of rows WITHOUT gathers from L2 (round 6; gemm_1x16_scan.hip): the codebook is cut into 8
+ * slices of 8192 entries (128 KiB); a workgroup keeps one slice in LDS, scans the canonical codes [out][in / 8] of its row group and
+ * feeds v_mfma_f32_16x16x32 with W fragments whose lanes read their entry when it lives in the workgroup's slice and a zero vector
+ * when it does not; x stays in registers (every wave owns a K range), the eight slices' partial sums (x K chunks for long rows) go to
+ * `workspace` as fp32 planes [8 * chunks][batch][out] and a second launch adds them in plane order, applies scales + bias and rounds
+ * once.  Data-oblivious (no prepacked copy, no dependence on the code histogram), deterministic, batch-invariant; rows are processed
+ * in passes of 16 (batch <= 16) or 32.  Needs in_features % 256 == 0, 16-B aligned codes / codebook / X rows / workspace.
+ * aqlm_hip_gemm_1x16_mfma routes to it by default (tuning keys `gemm_variant`, `scan_max_rows`).
+ * Replaces: the per-row relaunch of the matvec for 2 .. 6 rows (cuda_kernel.cpp:165-175) and code1x16_matmat_dequant =
+ * Code1x16Dequant + cuBLAS + epilogue above (cuda_kernel.cpp:249-301; cuda_kernel.cu:98-142).
+ * workspace: aqlm_hip_gemm_1x16_scan_workspace_bytes(batch, out_features, in_features) bytes (0 = the shape has no plan).
+ */
+size_t aqlm_hip_gemm_1x16_scan_workspace_bytes(int batch, int out_features, int in_features);
+int aqlm_hip_gemm_1x16_scan(const void* codes_i16, const void* codebook, const void* scales, const void* bias, const void* X, void* Y,
+                            int batch, int out_features, int in_features, long x_row_stride, long y_row_stride, int dtype,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Load-time repack of 1x16 codes (g 8 or 16) into the slice-bucketed format v7 consumed by aqlm_hip_gemv_1x16_packed (layout:

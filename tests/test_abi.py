@@ -32,7 +32,7 @@ def test_header_and_binding_agree(native):
 
 
 def test_abi_version_and_error_string(native):
-    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 8
+    assert native.lib.aqlm_hip_abi_version() == native.ABI_VERSION == 9
     assert isinstance(native.last_error(), str)
 
 
@@ -146,3 +146,30 @@ def test_tuning_knobs(native):
     native.set_tuning("gemv_rows_per_wave", 0)
     with pytest.raises(ValueError):
         native.set_tuning("no_such_knob", 1)
+
+
+def test_scan_entry_validation_and_plan_without_gpu(native):
+    """aqlm_hip_gemm_1x16_scan (round 6): argument checks and the plan behind the workspace size -- 8 codebook slices x the K chunks
+    the x fragments' registers ask for (<= 3 units of 256 features per wave at <= 16 rows, <= 2 at 17+ rows)."""
+    L = native.lib
+    buf = ctypes.create_string_buffer(4096)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    ws = L.aqlm_hip_gemm_1x16_scan_workspace_bytes
+    assert ws(8, 4096, 4096) == 8 * 1 * 8 * 4096 * 4          # one chunk: 16 units over 8 waves x 2
+    assert ws(16, 11008, 4096) == 8 * 1 * 16 * 11008 * 4
+    assert ws(8, 4096, 11008) == 8 * 3 * 8 * 4096 * 4         # 43 units: 3 chunks of 15 / 14 / 14 units (8 waves x 2 units each)
+    assert ws(32, 4096, 11008) == 8 * 3 * 32 * 4096 * 4       # the K chunking does not depend on the row count (batch invariance)
+    assert ws(8, 4096, 14336) == 8 * 4 * 8 * 4096 * 4
+    assert ws(8, 4096, 4096 + 64) == 0 and ws(0, 4096, 4096) == 0   # in_features % 256 != 0: no plan
+    assert L.aqlm_hip_workspace_bytes(native.OP_GEMM_1X16_MFMA, 16, 11008, 4096) >= ws(16, 11008, 4096)
+    rc = L.aqlm_hip_gemm_1x16_scan(None, p, p, None, p, p, 8, 4096, 4096, 4096, 4096, native.F16, p, 1 << 30, None)
+    assert rc == native.E_INVALID and "null pointer" in native.last_error()
+    rc = L.aqlm_hip_gemm_1x16_scan(p, p, p, None, p, p, 8, 4096, 4160, 4160, 4096, native.F16, p, 1 << 30, None)
+    assert rc == native.E_UNSUPPORTED and "256" in native.last_error()
+    rc = L.aqlm_hip_gemm_1x16_scan(p, p, p, None, p, p, 8, 4096, 4096, 4096, 4096, 7, p, 1 << 30, None)
+    assert rc == native.E_UNSUPPORTED and "float16 and bfloat16" in native.last_error()
+    rc = L.aqlm_hip_gemm_1x16_scan(p, p, p, None, p, p, 8, 4096, 4096, 4096, 4096, native.F16, p, 64, None)
+    assert rc == native.E_INVALID and "workspace" in native.last_error()
+    native.set_tuning("scan_max_rows", 64)
+    assert native.get_tuning("scan_max_rows") == 64
+    native.set_tuning("scan_max_rows", 128)
