@@ -108,6 +108,7 @@ SIGNATURES = {
     "aqlm_hip_prepack_1x16_ex": (_ci, [_vp, _ci, _ci, _ci, _vp, _sz, _descp, _ci, _vp]),
     "aqlm_hip_packed_set_codebook": (_ci, [_descp, _vp, _vp, _vp]),
     "aqlm_hip_packed_plan_relabel": (_ci, [_vp, _ci, _vp]),
+    "aqlm_hip_packed_plan_relabel_ex": (_ci, [_vp, _ci, _ci, _vp]),
     "aqlm_hip_packed_plan_geometry": (_ci, [_vp, _ci, _ci, _ci, _vp]),
     "aqlm_hip_packed_desc_read": (_ci, [_vp, _sz, _descp]),
     "aqlm_hip_unpack_1x16": (_ci, [_descp, _vp, _vp, _vp]),

@@ -125,12 +125,21 @@ def memory_report(model: torch.nn.Module) -> Dict[str, float]:
     return rep
 
 
-def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_canonical: bool = False, compact: bool = False,
+_DEFAULT = object()
+
+
+def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_canonical=_DEFAULT, compact: bool = False,
                   thorough: bool = False) -> Dict[str, float]:
     """Resolve the kernels and run the load-time repack of every eligible QuantizedLinear now (GPU-resident modules
     only) instead of at its first forward; ``min_codes`` overrides ``inference.PREPACK_MIN_CODES`` for this call.
-    ``drop_canonical=True`` (inference-only deployments) frees the checkpoint-layout ``codes`` of every repacked layer:
-    the packed buffer is lossless, ``state_dict()`` / large-batch / backward rebuild them on demand.
+    ``drop_canonical``: free the checkpoint-layout ``codes`` of repacked layers -- the packed buffer is lossless; ``state_dict()``,
+    the > 6-row ops and backward rebuild the codes on demand through ``aqlm_hip_unpack_1x16`` into a transient buffer (one pass
+    over the packed bytes, measured per call in bench.py's ``detail.unpack_1x16_us``: a few per cent of a prefill call, a third of
+    a 7..32-row call).  Default since round 6 (this is the deployment call, and a second copy of the codes is what the format
+    exists to avoid): drop where a second, larger copy exists -- the slice-bucketed 1x16 buffers, 4.8 instead of 6.8 resident bits
+    per weight; planar 8x8 codes are the size of the canonical ones and the fused 8x8 g32 MFMA kernel reads the canonical layout,
+    so those keep both.  ``True``: drop everywhere (planar 8x8 included: 2.0 bits per weight); ``False``: keep everything (training,
+    speculative verification at 7+ rows on every step).  A module that was only packed lazily at its first forward keeps both.
     ``compact=True`` packs 1x16 g8 layers with 24-bit entries (3.5 instead of 4.5 bytes per code: a 70B model holds 30 GB of
     packed codes instead of 39; measured 1-5 % slower matvecs).  ``thorough=True`` runs the local search of the entry order on
     every layer, not only on those of <= 8 Mi codes (1-3 % faster matvecs on the big layers for ~5x their prepack time).
@@ -140,6 +149,9 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_
     from . import _native, inference
     from .inference import QuantizedLinear
 
+    explicit_drop = drop_canonical is not _DEFAULT
+    if not explicit_drop:
+        drop_canonical = True
     old = inference.PREPACK_MIN_CODES
     if min_codes is not None:
         inference.PREPACK_MIN_CODES = int(min_codes)
@@ -157,7 +169,11 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_
                 if not m.codes.is_cuda:
                     raise NotImplementedError("prepack_model needs the model on an MI355X (`model.to('cuda')` first)")
                 m.prepare_matmul_op(m.codebooks)
-                if drop_canonical:
+                # explicit True: every repacked layer (planar 8x8 included); the default drops where a SECOND copy exists -- the
+                # slice-bucketed 1x16 buffers (4.8 bits per weight next to the 2.0 of the codes).  Planar 8x8 codes are the same
+                # size as the canonical ones and the fused 8x8 g32 MFMA kernel (3+ rows) reads the canonical layout: those stay
+                # unless asked for.
+                if drop_canonical is True and (explicit_drop or m.nbits_per_codebook == 16):
                     m.drop_canonical_codes()
     finally:
         inference.PREPACK_MIN_CODES = old

@@ -150,9 +150,9 @@ struct Tuning {
   int gemv1x16_aux = AUX_DEFAULT;  // cache policy of the codebook gathers: 0 default, 1 sc0, 2 nt, 16 sc1
   int gemv1x16_prefetch_cb = 0;  // 1: each block touches a slice of the codebook first (warms its XCD's L2)
   int kx8_replicas = 1;          // K x 8 g8 batch-1: 1 = replicated-LDS kernel for >= 4096 rows, 0 = never, 2 = always
-  int gemm_variant = 0;          // large-batch 1x16 op: 0 = slice-scan kernel (round 6) up to scan_max_rows where it applies (g 8, in_features % 256 == 0), else as 5; 1 = register-staged split-K kernel (round 1), 2 = 16-row L2-gather kernel wherever it applies, 3 = K-split L2-gather pipeline only, 4 = slice-scan kernel at any row count, 5 = round 5's routing (16-row kernel <= 64 rows, pipeline above)
-  int scan_max_rows = 128;       // rows up to which variant 0 takes the slice-scan kernel
-  int scan_prefetch = 4;         // slice-scan kernel: tiles of code words in flight per wave (2 / 4 / 6)
+  int gemm_variant = 0;          // large-batch 1x16 op: 0 = slice-scan kernel (round 6) up to scan_max_rows (default 0: never) where it applies (g 8, in_features % 256 == 0), else as 5; 1 = register-staged split-K kernel (round 1), 2 = 16-row L2-gather kernel wherever it applies, 3 = K-split L2-gather pipeline only, 4 = slice-scan kernel at any row count, 5 = round 5's routing (16-row kernel <= 64 rows, pipeline above)
+  int scan_max_rows = 0;         // rows up to which variant 0 takes the slice-scan kernel (0: never -- measured slower than round 5's routes, gemm_1x16_scan.hip)
+  int scan_prefetch = 4;         // slice-scan kernel: tiles of code words in flight per wave (2 / 4)
   int kx8_xres = 1;              // fused K x 8 MFMA op at <= 16 rows: 1 = X resident in LDS (round 5), 0 = the streaming 16-row kernel (A/B runs)
   int kx8_xres_phased = 1;       // ... whose X image does not fit the LDS at once: 1 = the X-resident kernel in phases (round 5; also 17 .. 32 rows), 2 = up to 16 rows only, 0 = the streaming 16-row kernel
   int kx8_phase_tpb = 0;         // experiments: 1..3 = every <= 32-row call on the phased kernel with this many tiles per workgroup (0 = off)

@@ -1,5 +1,16 @@
 // 1x16 g8 at 2 .. 128+ input rows: codebook SLICES in LDS, canonical codes scanned, one sparse MFMA per 64 codes (round 6).
 //
+// STATUS: parity-green, NOT on any default route (tuning key `gemm_variant` = 4 or `scan_max_rows` > 0 selects it).  Measured
+// (profiles/r06_scan_kernel_vs_routes.log, us, this kernel / round 5's L2-gather MFMA op / dense fp16): 4096 x 4096 at 8 rows 17.8 /
+// 12.8 / 12.8; 4096 -> 11008 30.2 / 31.8 / 20.6; 11008 -> 4096 32.9 / 30.3 / 29.6.  The knock-out runs
+// (profiles/r06_scan_kernel_knockouts.log) say why: 11.5 us are fixed (launch 1.6, the 128 KiB slice 2.3, the x fragments 2.1, the
+// finalize launch 2.8, first codes / drain 2.7) and every 16-row tile costs 0.6 us of VALU + LDS + MFMA work that is 8-fold
+// redundant by construction (each code is looked at by the eight workgroups that own the eight slices) + 0.3 us for the K-range
+// reduction.  Even with all three pipelines perfectly overlapped the 8-fold scan of 4096 -> 11008 is ~9.5 us on top of the fixed
+// part, i.e. the dense GEMM's 20.6 us: the formulation trades the L2-gather floor (2.3 clocks per code and CU) for ~1 clock per
+// code and CU plus 5 us more fixed cost, which does not pay at Llama layer sizes.  Kept as the data-oblivious, prepack-free
+// multi-row kernel and as the record of that measurement.
+//
 // Replaces (behaviour, not code): the reference's handling of more than one row of the 1x16 scheme -- the per-row relaunch of its
 // matvec (cuda_kernel.cpp:165-175) up to 6 rows and code1x16_matmat_dequant = dequantise W to HBM + cuBLAS (cuda_kernel.cpp:249-301)
 // above.  Rounds 1-5 served these calls with (a) the slice-bucketed matvec, whose x operand is an LDS gather of 16 B per row and
@@ -26,7 +37,6 @@
 // Arithmetic: exact fp16 / bf16 products, fp32 sums in a fixed order that depends on the layer shape only -> deterministic and
 // batch-invariant (a row's bits do not depend on the other rows nor on their number); NaN / Inf in x poison their own row only.
 #include <algorithm>
-#include <type_traits>
 
 #include "aqlm_common.h"
 
@@ -75,7 +85,7 @@ struct Params {
 };
 
 // One work item per workgroup.  U = units (8 k-steps = 256 features each) per wave, NBT = 16-row batch tiles per pass, D = tiles of
-// code words in flight.  DBG (timing experiments, results wrong): 4 no K-range reduction, 32 no slice fill, 64 no x loads.
+// code words in flight.
 //
 // What the loop is built around (measured on the first cuts, profiles/r06_scan_knockouts.log):
 //   * NO branch around a VMEM instruction and no compiler-visible store in the loop: hipcc's wait-count insertion answers either
@@ -87,7 +97,7 @@ struct Params {
 //     instructions earlier);
 //   * the tile's reducer does not make the others wait: it requests the seven partial tiles right after the barrier and adds them
 //     one tile later, inside its own gather phase's LDS latency.
-template <class T, int U, int NBT, int D, int DBG = 0>
+template <class T, int U, int NBT, int D>
 __global__ __launch_bounds__(NW * 64) void gemm_1x16_scan_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
   if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)scan_smem != 0u) __builtin_trap();  // LDS map above starts at 0
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_1x16_scan_kernel(const Params p)
   // all pull the same lines at the same moment), the zero entry, and this wave's first code words
   {
     const uint8_t* src = p.codebook + (size_t)slice * (SLICE_ENTRIES * 16u) + (size_t)lane * 16u;
-    for (int i = wave; i < ((DBG & 32) ? 0 : 128); i += NW) {
+    for (int i = wave; i < 128; i += NW) {
       const int piece = (i + rg * 8) & 127;
       __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + (size_t)piece * 1024u), (lds_void_ptr)(size_t)(LDS_CB + (uint32_t)piece * 1024u), 16, 0, 0);
     }
@@ -158,8 +168,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_1x16_scan_kernel(const Params p)
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           u32x4 v = u32x4{0u, 0u, 0u, 0u};
-          if constexpr (DBG & 64) v = u32x4{(uint32_t)(size_t)xr, 1u, 2u, (uint32_t)t};
-          else if (b < p.B && uvalid[u]) v = *reinterpret_cast<const u32x4*>(xr + (uoff[u] * 32 + t) * 8);
+          if (b < p.B && uvalid[u]) v = *reinterpret_cast<const u32x4*>(xr + (uoff[u] * 32 + t) * 8);
           xf[nb][u][t] = v;
         }
     }
@@ -233,13 +242,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_1x16_scan_kernel(const Params p)
       f32x4 mine[NBT];
 #pragma unroll
       for (int nb = 0; nb < NBT; ++nb) mine[nb] = acc[nb][0] + acc[nb][1];
-      if constexpr (DBG & 4) {
-        if (tile + 1 == tile1 && wave == 0 && (p.M & 3) == 0) {
-          float* dst = p.partial + ((size_t)plane * p.B + (b0 + arow < p.B ? b0 + arow : 0)) * p.M + tile * 16 + kg * 4;
-          asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(mine[0]) : "memory");
-        }
-        continue;
-      }
       if (wave != red) {
         const int s = (wave - red - 1) & (NW - 1);
 #pragma unroll
@@ -374,37 +376,8 @@ static int launch(const Params& p, const Plan& pl, hipStream_t stream) {
     return check_hip(hipGetLastError(), "gemm_1x16_scan launch");
   };
   const int depth = tuning().scan_prefetch;
-  if constexpr (std::is_same<T, F16>::value) {  // timing experiments (tuning key gemm_debug; results are wrong)
-    if (pl.nbt == 1 && pl.U == 2 && tuning().gemm_debug) {
-      switch (tuning().gemm_debug) {
-        case 1: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 1>, lds_total<1>());
-        case 2: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 2>, lds_total<1>());
-        case 3: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 3>, lds_total<1>());
-        case 4: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 4>, lds_total<1>());
-        case 7: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 7>, lds_total<1>());
-        case 8: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 8>, lds_total<1>());
-        case 12: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 12>, lds_total<1>());
-        case 15: case 16 + 15: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 15>, lds_total<1>());
-        case 32 + 15: case 16 + 32 + 15: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 32 + 15>, lds_total<1>());
-        case 64 + 15: case 16 + 64 + 15: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 64 + 15>, lds_total<1>());
-        case 96 + 15: case 16 + 96 + 15: return go(gemm_1x16_scan_kernel<T, 2, 1, 4, 96 + 15>, lds_total<1>());
-        default: break;
-      }
-    }
-  }
-#define AQLM_SCAN_CASE(U_, NBT_)                                                                                  \
-  do {                                                                                                            \
-    if (depth == 2) return go(gemm_1x16_scan_kernel<T, U_, NBT_, 2>, lds_total<NBT_>());                          \
-    if (depth == 6) return go(gemm_1x16_scan_kernel<T, U_, NBT_, 6>, lds_total<NBT_>());                          \
-    return go(gemm_1x16_scan_kernel<T, U_, NBT_, 4>, lds_total<NBT_>());                                          \
-  } while (0)
-  if (pl.nbt == 1) {
-    if (pl.U == 1) AQLM_SCAN_CASE(1, 1);
-    AQLM_SCAN_CASE(2, 1);
-  }
-  if (pl.U == 1) AQLM_SCAN_CASE(1, 2);
-  AQLM_SCAN_CASE(2, 2);
-#undef AQLM_SCAN_CASE
+  if (pl.U == 1) return depth == 2 ? go(gemm_1x16_scan_kernel<T, 1, 1, 2>, lds_total<1>()) : go(gemm_1x16_scan_kernel<T, 1, 1, 4>, lds_total<1>());
+  return depth == 2 ? go(gemm_1x16_scan_kernel<T, 2, 1, 2>, lds_total<1>()) : go(gemm_1x16_scan_kernel<T, 2, 1, 4>, lds_total<1>());
 }
 
 // the whole op: scan kernel + finalize.  Callers have validated pointers, dtype and alignment.
@@ -428,7 +401,6 @@ int run(const void* codes, const void* codebook, const void* scales, const void*
   p.upc = pl.upc;
   p.per_xcd = pl.RG * pl.kchunks * NSLICES / 8;
   if (int e = dtype == AQLM_HIP_F16 ? launch<F16>(p, pl, stream) : launch<BF16>(p, pl, stream)) return e;
-  if (tuning().gemm_debug & 16) return 0;  // timing experiments: no finalize launch
   FinalizeParams f{};
   f.partial = (const float*)workspace;
   f.scales = (const uint16_t*)scales;

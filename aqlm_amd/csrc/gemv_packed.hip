@@ -71,6 +71,7 @@
 #define aqlm_hip_prepack_1x16_ex aqlm_hip_g16_prepack_1x16_ex
 #define aqlm_hip_packed_set_codebook aqlm_hip_g16_packed_set_codebook
 #define aqlm_hip_packed_plan_relabel aqlm_hip_g16_packed_plan_relabel
+#define aqlm_hip_packed_plan_relabel_ex aqlm_hip_g16_packed_plan_relabel_ex
 #define aqlm_hip_packed_plan_geometry aqlm_hip_g16_packed_plan_geometry
 #define aqlm_hip_packed_desc_read aqlm_hip_g16_packed_desc_read
 #define aqlm_hip_unpack_1x16 aqlm_hip_g16_unpack_1x16
@@ -2316,6 +2317,7 @@ int aqlm_hip_g16_prepack_1x16(const void*, int, int, int, void*, size_t, aqlm_hi
 int aqlm_hip_g16_prepack_1x16_ex(const void*, int, int, int, void*, size_t, aqlm_hip_packed_desc*, int, void*);
 int aqlm_hip_g16_packed_set_codebook(aqlm_hip_packed_desc*, void*, const void*, void*);
 int aqlm_hip_g16_packed_plan_relabel(const uint32_t*, int, uint16_t*);
+int aqlm_hip_g16_packed_plan_relabel_ex(const uint32_t*, int, int, uint16_t*);
 int aqlm_hip_g16_packed_plan_geometry(const uint64_t*, int, int, int, uint8_t*);
 int aqlm_hip_g16_packed_desc_read(const void*, size_t, aqlm_hip_packed_desc*);
 int aqlm_hip_g16_unpack_1x16(const aqlm_hip_packed_desc*, const void*, void*, void*);
@@ -2351,7 +2353,11 @@ static inline bool pk_is_g16(const aqlm_hip_packed_desc* d) { return d && d->sli
 // single entry outweighs a slice's share.  Deterministic (ties: lower label, lower slice).  Within a slice the heaviest entries
 // take consecutive slots, i.e. distinct LDS bank groups.  Returns 0 (and leaves new_of_old alone) when the checkpoint's labels
 // already load the slices evenly: no permutation, no codebook image, the buffer of format v6.
-static int plan_relabel(const uint32_t* usage, uint16_t* new_of_old) {
+// `force`: deal even when the slices' TOTAL masses are already even -- label use correlated with the ROW (rows of one block of the
+// layer drawing their codes from one slice's labels) leaves every global histogram flat and one stream per row group 14 x the
+// mean; the repack asks for it whenever the 16 x 16 layout is not balanced and keeps the result only if the
+// longest stream got shorter.  Equal counts fall out round-robin over the slices (stable order, lightest slice first).
+static int plan_relabel(const uint32_t* usage, uint16_t* new_of_old, bool force = false) {
   unsigned long long mass0[PK_S] = {}, total = 0;
   for (int c = 0; c < 65536; ++c) mass0[c >> PK_CODE_BITS] += usage[c];
   unsigned long long mx = 0;
@@ -2359,7 +2365,7 @@ static int plan_relabel(const uint32_t* usage, uint16_t* new_of_old) {
     total += mass0[s];
     mx = std::max(mx, mass0[s]);
   }
-  if (total == 0 || (double)mx * PK_S <= 1.02 * (double)total) return 0;
+  if (total == 0 || (!force && (double)mx * PK_S <= 1.02 * (double)total)) return 0;
   std::vector<uint32_t> order(65536);
   for (uint32_t c = 0; c < 65536; ++c) order[c] = c;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return usage[x] > usage[y]; });
@@ -2427,6 +2433,17 @@ extern "C" PK_API int aqlm_hip_packed_plan_relabel(const uint32_t* usage, int sl
     return AQLM_HIP_E_INVALID;
   }
   return plan_relabel(usage, new_of_old);
+}
+
+extern "C" PK_API int aqlm_hip_packed_plan_relabel_ex(const uint32_t* usage, int slices_log2, int force, uint16_t* new_of_old) {
+#if AQLM_PK_G == 8
+  if (slices_log2 == 5) return aqlm_hip_g16_packed_plan_relabel_ex(usage, slices_log2, force, new_of_old);
+#endif
+  if (!usage || !new_of_old || slices_log2 != PK_S_LOG) {
+    set_last_error("aqlm_hip_packed_plan_relabel_ex: null pointer or slices_log2 not 4 / 5");
+    return AQLM_HIP_E_INVALID;
+  }
+  return plan_relabel(usage, new_of_old, force != 0);
 }
 
 extern "C" PK_API int aqlm_hip_packed_plan_geometry(const uint64_t* slice_steps, int slices_log2, int out_features, int in_features,
@@ -2556,12 +2573,19 @@ extern "C" PK_API int aqlm_hip_prepack_1x16_ex(const void* codes, int out_featur
       if (int e = check_hip(hipMemcpyAsync(usage.data(), hist_d, (size_t)65536 * 4, hipMemcpyDeviceToHost, stream), "prepack read-back")) return e;
       if (int e = check_hip(hipStreamSynchronize(stream), "prepack sync")) return e;
       new_of_old.resize(65536);
-      relabel = plan_relabel(usage.data(), new_of_old.data()) == 1;
+      // forced: the layout is not balanced although the global masses may be (label use correlated with the row); kept only when
+      // the longest stream runs fewer wave-steps with the new labels
+      const uint32_t maxL_before = maxL;
+      relabel = plan_relabel(usage.data(), new_of_old.data(), /*force=*/true) == 1;
       if (relabel) {
         old_of_new.resize(65536);
         for (uint32_t c = 0; c < 65536; ++c) old_of_new[new_of_old[c]] = (uint16_t)c;
         if (int e = check_hip(hipMemcpyAsync(relabel_d, new_of_old.data(), (size_t)65536 * 2, hipMemcpyHostToDevice, stream), "prepack relabel table")) return e;
         if (int e = count_and_scan(relabel_d)) return e;
+        if (capacity(maxL) >= capacity(maxL_before)) {  // the deal did not help (e.g. one row that lives in one slice): labels as they are
+          relabel = false;
+          if (int e = count_and_scan(nullptr)) return e;
+        }
       }
     }
     // (3) an entry that outweighs a slice: deal the workgroups to the slices by their work

@@ -211,9 +211,15 @@ class QuantizedLinear(nn.Module):
                                                                     [packed.out_features, packed.in_features, packed.in_group_size],
                                                                     packed.codebook_absmax)
                     return hip_kernel.code8x8_matmat_planar(input, packed, self.codebooks, self.scales, self.bias)
+            elif (packed.desc.relabelled and not self._codes_dropped and not packed.range_is_current(self.codebooks)
+                  and not torch.compiler.is_compiling() and torch.cuda.is_current_stream_capturing()):
+                # a relabelled buffer's kernels read a derived codebook IMAGE; the codebook changed and the image cannot be rewritten
+                # inside a capture (it reads a bound back): this call runs the direct kernel on the canonical codes and the live
+                # codebook instead of raising; the first eager forward rewrites the image
+                return self.gemv_op.apply(input, self.codes, self.codebooks, self.scales, self.bias)
             elif torch.compiler.is_compiling():  # traced: go through the dispatcher op (it has a fake implementation)
                 return torch.ops.aqlm.code1x16_matmat_packed(input, packed.buf, self.codebooks, self.scales, self.bias,
-                                                             packed._ints)
+                                                             packed.op_ints())
             else:
                 return hip_kernel.code1x16_matmat_packed(input, packed, self.codebooks, self.scales, self.bias)
         if (self.prefer_dense_below_rows and input.is_cuda and GEMV_MAX_ROWS < math.prod(input.shape[:-1]) < self.prefer_dense_below_rows

@@ -194,6 +194,14 @@ class PackedCodes:
     def range_is_current(self, codebooks: torch.Tensor) -> bool:
         return self._range_of == (codebooks.data_ptr(), _version(codebooks))
 
+    def op_ints(self):
+        """What the dispatcher op `aqlm::code1x16_matmat_packed` takes: the descriptor + the fingerprint (data pointer, version) of the
+        codebook tensor its range -- and, for a relabelled buffer, its codebook IMAGE -- was taken from.  A traced graph bakes these
+        ints in; the op compares the fingerprint with the codebook it is called with and refreshes on a mismatch (a codebook updated
+        in place between two calls of a compiled model must not be served from the stale image: ADVICE r05)."""
+        fp = self._range_of if self._range_of is not None else (0, -1)
+        return list(self._ints) + [int(fp[0]), int(fp[1])]
+
     def verify_range(self, codebooks: torch.Tensor) -> bool:
         """Was the codebook written behind the version counter's back (``codebooks.data.copy_()``)?  Compares the checksum taken
         with the range; on a mismatch the range (and a relabelled buffer's codebook image) is forgotten and rebuilt at the next
@@ -207,6 +215,16 @@ class PackedCodes:
 
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
+
+    def padding_fraction(self) -> float:
+        """Share of the entry slots that hold no code: every (row, slice) bucket is rounded up to lane-steps of 4 entries and every
+        stream to whole wave-steps.  Short rows pay most (a 1024-wide shard of a row-split layer has 8 codes per row and slice =
+        2 lane-steps, mostly padding: VERDICT r05 weak #2)."""
+        d = self.desc
+        streams = sum(int(v) for v in list(d.slice_groups)[:self.slices])
+        slots = streams * int(d.waves) * int(d.steps) * 64 * 4
+        codes = self.out_features * (self.in_features // self.in_group_size)
+        return 1.0 - codes / slots if slots else 0.0
 
     def unpack(self) -> torch.Tensor:
         return unpack_1x16(self)
@@ -916,6 +934,14 @@ class PlanarCodes:
     def range_is_current(self, codebooks: torch.Tensor) -> bool:
         return self._range_of == (codebooks.data_ptr(), _version(codebooks))
 
+    def op_ints(self):
+        """What the dispatcher op `aqlm::code1x16_matmat_packed` takes: the descriptor + the fingerprint (data pointer, version) of the
+        codebook tensor its range -- and, for a relabelled buffer, its codebook IMAGE -- was taken from.  A traced graph bakes these
+        ints in; the op compares the fingerprint with the codebook it is called with and refreshes on a mismatch (a codebook updated
+        in place between two calls of a compiled model must not be served from the stale image: ADVICE r05)."""
+        fp = self._range_of if self._range_of is not None else (0, -1)
+        return list(self._ints) + [int(fp[0]), int(fp[1])]
+
     def verify_range(self, codebooks: torch.Tensor) -> bool:
         """See PackedCodes.verify_range: the codebook bound against unversioned writes of the codebook."""
         if self._range_of is None or not self.range_is_current(codebooks) or self._range_checksum is None:
@@ -927,6 +953,16 @@ class PlanarCodes:
 
     def numel(self) -> int:  # bytes held
         return self.buf.numel()
+
+    def padding_fraction(self) -> float:
+        """Share of the entry slots that hold no code: every (row, slice) bucket is rounded up to lane-steps of 4 entries and every
+        stream to whole wave-steps.  Short rows pay most (a 1024-wide shard of a row-split layer has 8 codes per row and slice =
+        2 lane-steps, mostly padding: VERDICT r05 weak #2)."""
+        d = self.desc
+        streams = sum(int(v) for v in list(d.slice_groups)[:self.slices])
+        slots = streams * int(d.waves) * int(d.steps) * 64 * 4
+        codes = self.out_features * (self.in_features // self.in_group_size)
+        return 1.0 - codes / slots if slots else 0.0
 
     @property
     def device(self):
@@ -1457,9 +1493,19 @@ for _name, _impl in (("code1x16_matmat_multi", code1x16_matmat_multi), ("codekx8
 
 # the prepacked op as a dispatcher op, so that a QuantizedLinear on the packed path traces under torch.compile
 # (the descriptor travels as a list of ints; eager calls skip the dispatcher and use code1x16_matmat_packed directly)
+_N_DESC_INTS = 17
+
+
 def _packed_op(input, packed, codebooks, scales, bias, desc):
-    pk = PackedCodes(packed, _native.PackedDesc.from_ints(desc))
-    pk._range_of = (codebooks.data_ptr(), _version(codebooks))  # the caller's descriptor is taken at its word (0 = unknown)
+    pk = PackedCodes(packed, _native.PackedDesc.from_ints(desc[:_N_DESC_INTS]))
+    now = (codebooks.data_ptr(), _version(codebooks))
+    if len(desc) >= _N_DESC_INTS + 2:
+        # the descriptor says which codebook its range (and a relabelled buffer's codebook image) came from: anything else is
+        # refreshed by code1x16_matmat_packed -> _refresh_range (outside a capture; inside one the stale range means the two-kernel
+        # form, and a stale image is refused with a message)
+        pk._range_of = now if (int(desc[_N_DESC_INTS]), int(desc[_N_DESC_INTS + 1])) == now else (0, -2)
+    else:
+        pk._range_of = now  # (descriptors without a fingerprint are taken at their word: 0 = unknown range)
     return code1x16_matmat_packed(input, pk, codebooks, scales, bias)
 
 

@@ -54,6 +54,28 @@ def shard_bounds(n: int, world: int, rank: int, multiple: int = 1):
     return min(lo_b * multiple, n), min(hi_b * multiple, n)
 
 
+def packed_matvec_cost_us(out_features: int, in_features: int, in_group_size: int = 8) -> float:
+    """Cost line of the prepacked 1x16 matvec on one MI355X (bs = 1, cold), read off bench.py's figures: ~3.3 us fixed (launch
+    boundary, slice fill, hand-in) + ~1.1 us per million ENTRY SLOTS -- every (row, slice) bucket is padded to lane-steps of 4
+    entries, so short rows pay for slots that hold no code (a 1024-wide shard has 8 codes per bucket = 2-3 lane-steps: 10.1 us for
+    3.7 M codes where the 8192 -> 3584 shard of the same layer takes 8.0 us; 4096 x 4096 6.0, 4096 -> 11008 8.8, 8192 -> 28672 26.9)."""
+    slices = 16 if in_group_size == 8 else 32
+    per_bucket = (in_features // in_group_size) / slices
+    lane_steps = max(1, -(-int(per_bucket + 1.5) // 4))       # expected codes + the Poisson tail, in steps of 4 entries
+    return 3.3 + 1.1e-6 * out_features * slices * 4 * lane_steps
+
+
+def preferred_partition(out_features: int, in_features: int, world: int, in_group_size: int = 8, allreduce_us: float = 12.0,
+                        allgather_us: float = 10.0, gather_output: bool = True) -> str:
+    """"in" (north star: row-sharded codes + all-reduce of out values) or "out" (column shards + all-gather of out / world values per
+    rank, or nothing when the output stays sharded) for ONE layer: shard kernel by `packed_matvec_cost_us` + the collective.  The
+    collective terms are latency-bound on xGMI at these sizes (56-112 KiB); the defaults are placeholders until the 8-GPU tier has
+    measured them -- the decision for the 70B layer (8192 -> 28672 over 8) does not hinge on them: 10.1 + reduce vs 8.0 + gather."""
+    t_in = packed_matvec_cost_us(out_features, max(in_group_size, in_features // world), in_group_size) + allreduce_us
+    t_out = packed_matvec_cost_us(max(1, out_features // world), in_features, in_group_size) + (allgather_us if gather_output else 0.0)
+    return "in" if t_in < t_out else "out"
+
+
 class ShardedQuantizedLinear(nn.Module):
     """One rank's shard of an AQLM layer.  Build it with :meth:`from_full` (every rank passes the full tensors, or
     loads only its slice using :func:`shard_bounds`)."""
@@ -123,6 +145,8 @@ class ShardedQuantizedLinear(nn.Module):
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         out_groups, in_groups, _ = codes.shape
         g = codebooks.shape[3]
+        if mode == "auto":  # one layer on its own: the cheaper of the two partitions by the cost line above
+            mode = preferred_partition(out_groups, in_groups * g, world, g, gather_output=gather_output) if bounds is None else "in"
         if mode == "in":
             # multiples of 8 groups keep each shard on the tuned (16-B code word) kernels
             j0, j1 = bounds if bounds is not None else shard_bounds(in_groups, world, rank, multiple=8)

@@ -211,7 +211,9 @@ def main():
                    # load-time and memory price of the prepacked path for these 64 layers (outside the timed region)
                    "prepack_s_total": prepack["seconds"], "prepack_ms_per_layer": prepack["seconds"] * 1e3 / max(1, prepack["layers"]),
                    "packed_bytes": prepack["packed_bytes"], "canonical_code_bytes": prepack["canonical_code_bytes"],
-                   "bits_per_weight_resident": bits},
+                   "bits_per_weight_resident": bits,
+                   # share of the packed entry slots that hold no code (buckets padded to lane-steps of 4 entries), per shape
+                   "packed_padding_fraction": {f"{L.fin}->{L.fout}": round(L.packed.padding_fraction(), 4) for L in layers[:2] if L.packed is not None}},
         "tokens_per_s_this_stack": world * 1e3 / ms_per_step,
         "roofline": roofline,
         "cpu_baseline": None,
@@ -251,7 +253,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - an extra never costs the headline line
                 result["sharded_70b"] = {"error": f"{type(e).__name__}: {e}"}
             result["detail"] = {}  # filled in place: a timed-out run still reports what it had
-            budget = 0.0 if args.full_detail else float(os.environ.get("AQLM_BENCH_DETAIL_BUDGET_S", "38"))
+            budget = 0.0 if args.full_detail else float(os.environ.get("AQLM_BENCH_DETAIL_BUDGET_S", "42"))
             ctx = DT.Ctx(lib, dev, rank, world, max(4, args.steps // 5), layers, NBLOCKS, value)
             DT.run_detail(ctx, result["detail"], T_PROCESS, budget, args.full_detail, extras)
         if rank == 0 and not args.no_cpu:

@@ -18,9 +18,9 @@ def code_histograms_detail(lib, dev, rank, reps, nblocks, uniform_value, full=Tr
     close to that the slice-bucketed kernel stays."""
     out = {"protocol": "the timed step's layer list (one hipGraph, cold: 564 MB per step), codes ~ Zipf(alpha) over the 65536 entries",
            "uniform_GBps": uniform_value, "cases": {}}
-    # the default (time-budgeted) pass takes three cases: the two Zipf laws that moved most in round 5 and the row-correlated layer
+    # the default (time-budgeted) pass takes two cases: the Zipf law that was worst in round 5 and the row-correlated layer
     # of VERDICT r05 weak #1 (rows of block b draw 90 % of their codes from labels [4096 b, 4096 (b + 1)): global usage uniform)
-    laws = [(a, s_) for a in (0.5, 0.8, 1.0, 1.2) for s_ in (False, True)] if full else [(1.0, False), (1.2, True)]
+    laws = [(a, s_) for a in (0.5, 0.8, 1.0, 1.2) for s_ in (False, True)] if full else [(1.2, True)]
     laws.append(("rowblock", 0.9))
     for alpha, sorted_labels in laws:
         if True:
@@ -416,12 +416,12 @@ def sec_rows_8x8(c, detail):
 
 def sec_rows_1x16(c, detail):
     """1x16 g8 at 1..32 input rows on both headline shapes: the prepacked matvec (1..8 rows: one more LDS read
-    + 4 dots per entry and row), the large-batch op `code1x16_matmat_dequant` as the operator routes it (round 6: the slice-scan
-    MFMA kernel, codebook slices in LDS; `gather_mfma_us` = round 5's L2-gather kernels, forced), and a dense fp16 GEMM on rotating
-    weights.  hipGraph replay over > 600 MB of distinct layers; `operator_us` = what QuantizedLinear.forward runs for that count."""
+    + 4 dots per entry and row), the large-batch op `code1x16_matmat_dequant` (L2-gather MFMA kernels: one cost up to 16 rows), the
+    slice-scan MFMA kernel built in round 6 (`scan_us`; not on a default route) and a dense fp16 GEMM on rotating weights.
+    hipGraph replay over > 600 MB of distinct layers; `operator_us` = what QuantizedLinear.forward runs for that count (gemv rule:
+    <= 6 rows the matvec kernels, above the large-batch op)."""
     if not LY.PACK_MIN_OUT:
         return
-    from aqlm_amd import _native
     from aqlm_amd import inference as inf
     from aqlm_amd.inference_kernels import hip_kernel as hk
 
@@ -438,44 +438,55 @@ def sec_rows_1x16(c, detail):
                 e["prepacked_matvec_us"] = gpb.time_replays(c.reps) * 1e3 / gpb.n
                 del gpb
             if B >= 2:
-                def op(st, l):
-                    hk.code1x16_matmat_dequant(xb, l.codes, l.codebooks, l.scales, None)
-                g = GraphedCalls([(lambda st, l=l: op(st, l)) for l in ls], c.dev)
+                g = GraphedCalls([(lambda st, l=l: hk.code1x16_matmat_dequant(xb, l.codes, l.codebooks, l.scales, None)) for l in ls], c.dev)
                 e["mfma_op_us"] = g.us_per_pass(c.reps) / len(ls)
                 del g
-                if hasattr(hk, "SCAN_KERNEL") or True:
-                    keep = _native.get_tuning("gemm_variant")
-                    try:
-                        _native.set_tuning("gemm_variant", 5)  # round 5's routes: 16-row L2-gather kernel / K-split pipeline
-                        g = GraphedCalls([(lambda st, l=l: op(st, l)) for l in ls], c.dev)
-                        e["gather_mfma_us"] = g.us_per_pass(c.reps) / len(ls)
-                        del g
-                    except Exception:  # noqa: BLE001
-                        pass
-                    finally:
-                        _native.set_tuning("gemm_variant", keep)
-            routes = {k: v for k, v in e.items() if k in ("prepacked_matvec_us", "mfma_op_us") and v is not None}
-            if B == 1:
-                e["operator_us"] = e["prepacked_matvec_us"]
-            else:
-                e["operator_us"] = e["prepacked_matvec_us"] if B <= getattr(inf, "PACKED_MATVEC_MAX_ROWS", inf.GEMV_MAX_ROWS) and "prepacked_matvec_us" in e else e["mfma_op_us"]
+            if B in (8, 16):
+                g = GraphedCalls([(lambda st, l=l: hk.code1x16_matmat_scan(xb, l.codes, l.codebooks, l.scales, None)) for l in ls], c.dev)
+                e["scan_us"] = g.us_per_pass(c.reps) / len(ls)
+                del g
+            e["operator_us"] = e["prepacked_matvec_us"] if B <= inf.GEMV_MAX_ROWS else e["mfma_op_us"]
             e["operator_vs_dense"] = e["dense_fp16_us"] / e["operator_us"]
-            e["best_route"] = min(routes, key=routes.get)
             per[f"B{B}"] = e
         out[f"{fi}->{fo}"] = per
         del ls, Ws
     detail["batch_rows_1x16g8"] = out
 
 
+def sec_unpack(c, detail):
+    """What dropping the canonical codes costs the calls that need them: `aqlm_hip_unpack_1x16` of one layer
+    into a transient buffer (one pass over the packed bytes), hipGraph replay over distinct layers, next to the 16-row large-batch op
+    that would follow it"""
+    if not LY.PACK_MIN_OUT:
+        return
+    from aqlm_amd.inference_kernels import hip_kernel as hk
+
+    out = {}
+    for fi, fo in ((4096, 4096), (4096, 11008)):
+        ls = [Layer(fi, fo, 1, 16, 8, 6100 + c.rank * 10000 + i, c.dev) for i in range(min(48, int(600e6 / algorithmic_bytes(fi, fo)) + 1))]
+        g = GraphedCalls([(lambda st, l=l: hk.unpack_1x16(l.packed)) for l in ls], c.dev)
+        us = g.us_per_pass(c.reps) / len(ls)
+        del g
+        xb = torch.randn((16, fi), device=c.dev, dtype=torch.float16)
+        g = GraphedCalls([(lambda st, l=l: hk.code1x16_matmat_dequant(xb, l.codes, l.codebooks, l.scales, None)) for l in ls], c.dev)
+        op = g.us_per_pass(c.reps) / len(ls)
+        del g
+        out[f"{fi}->{fo}"] = {"unpack_us": us, "packed_bytes": int(ls[0].packed.buf.numel() * ls[0].packed.buf.element_size()),
+                              "large_batch_op_16_rows_us": op, "unpack_over_op": us / op}
+        del ls
+    detail["unpack_1x16_us"] = out
+
+
 # (name, function, runs in the default (budgeted) pass?)  Order = priority under the default time budget.
 SECTIONS = [
     ("per_shape", sec_per_shape),
-    ("batch_rows_1x16", None),       # filled in below (needs the operator's routing: see sec_rows_1x16)
-    ("config4", sec_config4),
-    ("config3", sec_config3),
+    ("batch_rows_1x16", None),       # (forward references: resolved in run_detail)
     ("code_histograms", None),
-    ("rows_2x8", sec_rows_2x8),
+    ("config4", sec_config4),
+    ("unpack", sec_unpack),
     ("rows_8x8", sec_rows_8x8),
+    ("config3", sec_config3),
+    ("rows_2x8", sec_rows_2x8),
     ("llama3_8b", sec_llama3_8b),
     ("llama2_7b", sec_llama2_7b),
     ("qkv", sec_qkv),

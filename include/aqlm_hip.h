@@ -156,11 +156,10 @@ int aqlm_hip_dequant_generic(const void* codes, const void* codebooks, const voi
 /*
  * Large-batch path: Y[B][out] = (X[B][in] @ W^T) * scales + bias with W dequantised tile-by-tile into LDS and
  * contracted on the matrix cores (v_mfma_f32_16x16x32_f16/bf16: a gathered codebook vector IS a fragment lane); W never
- * touches HBM.  Three kernels behind the entry, chosen by batch and layer shape (tuning key `gemm_variant` forces one): the slice-scan
- * kernel of aqlm_hip_gemm_1x16_scan (in_group_size 8, in_features % 256 == 0, up to `scan_max_rows` = 128 rows: codebook slices in
- * LDS, no gathers from L2), and round 5's L2-gather kernels for everything else: a K-split pipeline with fp32 partials in
- * `workspace` + a finalize launch, and (<= 16 rows; <= 64 rows on layers of <= 4096 x 4096) a single launch of 16-row blocks over
- * all of K that uses no workspace.
+ * touches HBM.  Two kernels behind the entry, chosen by batch and layer size (tuning key `gemm_variant` forces one): a K-split
+ * pipeline with fp32 partials in `workspace` + a finalize launch, and (<= 16 rows; <= 64 rows on layers of <= 4096 x 4096) a
+ * single launch of 16-row blocks over all of K that uses no workspace.  (`gemm_variant` = 4 / `scan_max_rows` > 0: the slice-scan
+ * kernel of aqlm_hip_gemm_1x16_scan instead, where it applies.)
  * Replaces: code1x16_matmat_dequant = Code1x16Dequant + F::linear(cuBLAS) + epilogue (cuda_kernel.cpp:249-301).
  * X and Y are row-major with the given row strides (elements).  workspace: aqlm_hip_workspace_bytes(...) bytes
  * (may be 0 -> NULL allowed).
@@ -177,8 +176,10 @@ int aqlm_hip_gemm_1x16_mfma(const void* codes_i16, const void* codebook, const v
  * when it does not; x stays in registers (every wave owns a K range), the eight slices' partial sums (x K chunks for long rows) go to
  * `workspace` as fp32 planes [8 * chunks][batch][out] and a second launch adds them in plane order, applies scales + bias and rounds
  * once.  Data-oblivious (no prepacked copy, no dependence on the code histogram), deterministic, batch-invariant; rows are processed
- * in passes of 16 (batch <= 16) or 32.  Needs in_features % 256 == 0, 16-B aligned codes / codebook / X rows / workspace.
- * aqlm_hip_gemm_1x16_mfma routes to it by default (tuning keys `gemm_variant`, `scan_max_rows`).
+ * in passes of 16.  Needs in_features % 256 == 0, 16-B aligned codes / codebook / X rows / workspace.
+ * NOT on a default route: measured slower than the L2-gather kernels of aqlm_hip_gemm_1x16_mfma at Llama layer sizes (8-fold
+ * redundant scan + 11.5 us fixed: profiles/r06_scan_kernel_*.log); that entry takes it with tuning key `gemm_variant` = 4 or up to
+ * `scan_max_rows` (default 0) rows.
  * Replaces: the per-row relaunch of the matvec for 2 .. 6 rows (cuda_kernel.cpp:165-175) and code1x16_matmat_dequant =
  * Code1x16Dequant + cuBLAS + epilogue above (cuda_kernel.cpp:249-301; cuda_kernel.cu:98-142).
  * workspace: aqlm_hip_gemm_1x16_scan_workspace_bytes(batch, out_features, in_features) bytes (0 = the shape has no plan).
@@ -270,6 +271,9 @@ int aqlm_hip_unpack_1x16(const aqlm_hip_packed_desc* desc, const void* packed, v
  * fills it when the entries should be re-dealt, 0 when the slices are already even within 2 %).  geometry: lane-steps
  * (units of 4 entries) of every slice -> slice_groups[1 << slices_log2] (returns 1 when the result is not uniform). */
 int aqlm_hip_packed_plan_relabel(const uint32_t* usage, int slices_log2, uint16_t* new_of_old);
+/* The same deal with `force` != 0: also when the slices' total masses are already within 2 % of even -- what the repack calls
+ * whenever the 16 x 16 layout is not balanced (label use correlated with the row leaves every global histogram flat; round 6). */
+int aqlm_hip_packed_plan_relabel_ex(const uint32_t* usage, int slices_log2, int force, uint16_t* new_of_old);
 int aqlm_hip_packed_plan_geometry(const uint64_t* slice_steps, int slices_log2, int out_features, int in_features,
                                   uint8_t* slice_groups);
 

@@ -82,13 +82,15 @@ def balanced_enough(codes_unsigned):
     return wave_steps(int(a[:, -1].max())) <= wave_steps(even)
 
 
-def plan_relabel(usage):
+def plan_relabel(usage, force=False):
     """usage [65536] -> new_of_old [65536] (LPT greedy: heaviest entry first, to the lightest slice with room; ties: lower label,
-    lower slice), or None when the checkpoint's labels already load the slices within 2 % of even."""
+    lower slice), or None when the checkpoint's labels already load the slices within 2 % of even -- unless `force`: then the deal
+    is made anyway (equal counts fall out round-robin over the slices), which is what spreads labels whose use is correlated with
+    the ROW: the global masses are even, one stream per row group is not."""
     usage = np.asarray(usage, dtype=np.int64)
     mass0 = usage.reshape(S, SLICE_ENTRIES).sum(axis=1)
     total = int(mass0.sum())
-    if total == 0 or float(mass0.max()) * S <= 1.02 * float(total):
+    if total == 0 or (not force and float(mass0.max()) * S <= 1.02 * float(total)):
         return None
     order = np.argsort(-usage, kind="stable")
     mass, cnt = [0] * S, [0] * S
@@ -102,6 +104,32 @@ def plan_relabel(usage):
         cnt[best] += 1
         mass[best] += int(usage[c])
     return new_of_old
+
+
+def rowblock_codes(M, in_groups, p, seed):
+    """Label use correlated with the ROW: the rows of block b (16 equal blocks of rows) draw a fraction `p` of
+    their codes from the labels [4096 b, 4096 (b + 1)) and the rest uniformly -- every entry is used equally often over the layer,
+    so no global histogram sees it, while one stream per row group carries most of that group's codes."""
+    rng = np.random.default_rng(seed)
+    blk = (np.arange(M) * S // M)[:, None]
+    own = blk * SLICE_ENTRIES + rng.integers(0, SLICE_ENTRIES, size=(M, in_groups))
+    uni = rng.integers(0, 65536, size=(M, in_groups))
+    return np.where(rng.random((M, in_groups)) < p, own, uni).astype(np.int64)
+
+
+def plan_labels(codes_unsigned):
+    """The repack's decision about the labels, as aqlm_hip_prepack_1x16 takes it: balanced layout -> the checkpoint's labels (None);
+    else the forced deal, kept only if the longest stream then runs fewer wave-steps."""
+    if balanced_enough(codes_unsigned):
+        return None
+    new = plan_relabel(np.bincount(codes_unsigned.ravel(), minlength=65536), force=True)
+    if new is None:
+        return None
+    _, a0 = lane_steps(codes_unsigned)
+    _, a1 = lane_steps(new[codes_unsigned])
+    if wave_steps(int(a1[:, -1].max())) >= wave_steps(int(a0[:, -1].max())):
+        return None
+    return new
 
 
 def plan_geometry(slice_steps, M, min_groups=MIN_GROUPS):

@@ -170,6 +170,7 @@ def test_scan_entry_validation_and_plan_without_gpu(native):
     assert rc == native.E_UNSUPPORTED and "float16 and bfloat16" in native.last_error()
     rc = L.aqlm_hip_gemm_1x16_scan(p, p, p, None, p, p, 8, 4096, 4096, 4096, 4096, native.F16, p, 64, None)
     assert rc == native.E_INVALID and "workspace" in native.last_error()
+    assert native.get_tuning("scan_max_rows") == 0              # not on a default route (measured slower: gemm_1x16_scan.hip)
     native.set_tuning("scan_max_rows", 64)
     assert native.get_tuning("scan_max_rows") == 64
-    native.set_tuning("scan_max_rows", 128)
+    native.set_tuning("scan_max_rows", 0)

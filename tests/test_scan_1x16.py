@@ -1,5 +1,5 @@
-"""GPU parity of the slice-scan MFMA kernel (aqlm_hip_gemm_1x16_scan, round 6): the 1x16 g8 scheme at 2+ rows with the codebook
-slices in LDS -- against the fp64 oracle (tolerance AND the correctly-rounded statement), the direct matvec kernel (another order
+"""GPU parity of the slice-scan MFMA kernel (aqlm_hip_gemm_1x16_scan, round 6; an opt-in route: measured slower than the L2-gather
+kernels at Llama layer sizes, see the kernel's header): the 1x16 g8 scheme at 2+ rows with the codebook slices in LDS -- against the fp64 oracle (tolerance AND the correctly-rounded statement), the direct matvec kernel (another order
 of the same exact products), bit-exact repeatability, batch invariance, strided inputs, NaN rows, every K plan (1 .. 3 units per
 wave, 1 .. 4 K chunks, ragged chunks), ragged row counts, and the ops / module that route to it.
 Replaces cuda_kernel.cpp:165-175 (per-row relaunch) and cuda_kernel.cpp:249-301 (dequantise + cuBLAS)."""
@@ -61,12 +61,16 @@ def test_scan_kernel_vs_oracle(hk, fin, fout, rows, dt):
     # the direct matvec kernel on the same rows: same exact products, another summation order
     yd = hk.code1x16_matmat(T["x"][:min(rows, 8)], *args)
     check_close(y[:min(rows, 8)].float().cpu().numpy(), yd.double().cpu().numpy(), dtype, "scan vs direct kernel")
-    # the large-batch op routes here by default (up to `scan_max_rows` = 128 rows; above: round 5's kernels, another summation order)
-    yo = hk.code1x16_matmat_dequant(T["x"], *args)
-    if rows <= 128:
-        assert torch.equal(yo, y)
-    else:
-        check_close(yo.float().cpu().numpy(), y64, dtype, what + " (large-batch op)")
+    # the large-batch op takes this kernel when asked to (gemm_variant 4); its default routes give the same values within the bound
+    from aqlm_amd import _native
+
+    keep = _native.get_tuning("gemm_variant")
+    try:
+        _native.set_tuning("gemm_variant", 4)
+        assert torch.equal(hk.code1x16_matmat_dequant(T["x"], *args), y)
+    finally:
+        _native.set_tuning("gemm_variant", keep)
+    check_close(hk.code1x16_matmat_dequant(T["x"], *args).float().cpu().numpy(), y64, dtype, what + " (large-batch op, default route)")
 
 
 def test_scan_kernel_nan_rows_zero_input_and_edge_codes(hk):
@@ -105,8 +109,8 @@ def test_scan_kernel_declines_what_it_does_not_take(hk):
 
 
 def test_scan_kernel_under_hipgraph_and_variants(hk):
-    """hipGraph capture (no allocation / synchronisation inside the entry) and the `gemm_variant` knob: 5 = round 5's routing must give
-    the same values within the tolerance (other kernels, other order), 4 = the scan kernel at any row count."""
+    """hipGraph capture (no allocation / synchronisation inside the entry); the default routing of the large-batch op (other kernels,
+    another summation order) gives the same values within the tolerance."""
     from aqlm_amd import _native
 
     L = orc.make_layer(91, 4096, 4096, 1, 16, 8, batch=8, bias=True, float_dtype=np.float16)
@@ -116,17 +120,13 @@ def test_scan_kernel_under_hipgraph_and_variants(hk):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        hk.code1x16_matmat_dequant(T["x"], *args)
+        hk.code1x16_matmat_scan(T["x"], *args)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            yg = hk.code1x16_matmat_dequant(T["x"], *args)
+            yg = hk.code1x16_matmat_scan(T["x"], *args)
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg, y)
-    keep = _native.get_tuning("gemm_variant")
-    try:
-        _native.set_tuning("gemm_variant", 5)
-        y5 = hk.code1x16_matmat_dequant(T["x"], *args)
-    finally:
-        _native.set_tuning("gemm_variant", keep)
-    check_close(y.float().cpu().numpy(), y5.double().cpu().numpy(), torch.float16, "scan vs round-5 routing")
+    assert _native.get_tuning("scan_max_rows") == 0   # not on a default route
+    y5 = hk.code1x16_matmat_dequant(T["x"], *args)
+    check_close(y.float().cpu().numpy(), y5.double().cpu().numpy(), torch.float16, "scan vs the default routing")

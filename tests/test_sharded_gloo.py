@@ -44,6 +44,11 @@ def _worker(rank, world, port, mode, cfg, q):
                                             kernel=_torch_kernel)
         y = m(t(L["x"]))
         # shard bookkeeping
+        if mode == "auto":
+            from aqlm_amd.sharded import preferred_partition
+
+            mode = preferred_partition(fout, fin, world, g)
+            assert m.mode == mode
         if mode == "in":
             assert m.codes.shape[0] == fout and (m.bias is not None) == (rank == 0)
             widths = torch.tensor([m.codes.shape[1]])
@@ -59,9 +64,11 @@ def _worker(rank, world, port, mode, cfg, q):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["in", "out"])
+@pytest.mark.parametrize("mode", ["in", "out", "auto"])
 @pytest.mark.parametrize("cfg", [(1, 16, 8, 1024, 48, 2), (2, 8, 8, 704, 50, 1)])
 def test_sharded_linear_gloo(world, mode, cfg):
+    if mode == "auto" and (world, cfg[0]) != (2, 1):
+        pytest.skip("the cost line's choice is covered once per scheme")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -75,6 +82,21 @@ def test_sharded_linear_gloo(world, mode, cfg):
     for rank, shape, err in res:
         assert shape == (cfg[5], cfg[4])
         assert err < 1e-5, f"rank {rank}: sharded result differs from the unsharded oracle by {err}"
+
+
+def test_partition_cost_line():
+    """SURVEY.md 8(e) both partitions, chosen per layer: the north star's 70B layer over 8 ranks takes the
+    out-split -- its 1024-wide in-split shards hold 8 codes per (row, slice) bucket, 2-3 lane-steps of mostly padding (10.1 us per
+    shard measured against 8.0 us for the 8192 -> 3584 shard) --, a down-projection whose output would otherwise be all-gathered
+    from short shards stays in-split when its input arrives sharded anyway."""
+    from aqlm_amd.sharded import packed_matvec_cost_us, preferred_partition
+
+    assert abs(packed_matvec_cost_us(4096, 4096) - 6.0) < 0.8 and abs(packed_matvec_cost_us(11008, 4096) - 8.8) < 1.5
+    assert abs(packed_matvec_cost_us(28672, 1024) - 10.1) < 1.5 and abs(packed_matvec_cost_us(3584, 8192) - 8.0) < 1.0
+    assert preferred_partition(28672, 8192, 8) == "out"
+    assert preferred_partition(28672, 8192, 8, allreduce_us=5.0, allgather_us=10.0) == "in"     # the collective decides close calls
+    assert preferred_partition(8192, 28672, 8, gather_output=True) in ("in", "out")
+    assert preferred_partition(4096, 4096, 1) in ("in", "out")
 
 
 def test_shard_bounds_cover_and_align():
