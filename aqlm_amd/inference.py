@@ -211,8 +211,8 @@ class QuantizedLinear(nn.Module):
                                                                     [packed.out_features, packed.in_features, packed.in_group_size],
                                                                     packed.codebook_absmax)
                     return hip_kernel.code8x8_matmat_planar(input, packed, self.codebooks, self.scales, self.bias)
-            elif (packed.desc.relabelled and not self._codes_dropped and not packed.range_is_current(self.codebooks)
-                  and not torch.compiler.is_compiling() and torch.cuda.is_current_stream_capturing()):
+            elif (not torch.compiler.is_compiling() and torch.cuda.is_current_stream_capturing() and packed.desc.relabelled
+                  and not self._codes_dropped and not packed.range_is_current(self.codebooks)):
                 # a relabelled buffer's kernels read a derived codebook IMAGE; the codebook changed and the image cannot be rewritten
                 # inside a capture (it reads a bound back): this call runs the direct kernel on the canonical codes and the live
                 # codebook instead of raising; the first eager forward rewrites the image

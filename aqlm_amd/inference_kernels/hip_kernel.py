@@ -756,10 +756,17 @@ def _raw_packed_for(codes, codebooks, input):
         if ok and entry[2] is not None and RAW_OP_CHECK_EVERY and not torch.cuda.is_current_stream_capturing() and not torch.compiler.is_compiling():
             # unversioned writes (`codes.data.copy_()`): re-check the checksum taken at pack time -- every RAW_OP_CHECK_EVERY hits
             # here, and on every call the compiled op hands back (it does so once per RAW_OP_CHECK_EVERY of ITS hits)
+            # (with the compiled front end loaded this path sees the calls the compiled op hands back -- its one-in-RAW_OP_CHECK_EVERY
+            # verification call, but also every call it declines: strided x, grad mode, a re-created view.  Those must not pay a
+            # checksum + host sync each: the check is due when the hits since the last one -- here plus the compiled op's own,
+            # read from its counter -- reach the period.  ADVICE r05)
             chk = entry[3]
             chk[1] += 1
-            if _RAW_FAST is not None or chk[1] >= RAW_OP_CHECK_EVERY:
-                chk[1] = 0
+            fast_hits = _RAW_FAST.raw_hits() if _RAW_FAST is not None else 0
+            if len(chk) < 3:
+                chk.append(fast_hits)
+            if chk[1] + (fast_hits - chk[2]) >= RAW_OP_CHECK_EVERY:
+                chk[1], chk[2] = 0, fast_hits
                 ok = chk[0] is None or tensor_checksum(codes) == chk[0]
                 entry[2].verify_range(codebooks)  # ... and the codebook image / range against the codebook's
         if ok:

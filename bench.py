@@ -15,7 +15,7 @@ replicas of the step (one process per GPU, no data-path collective), "scaling": 
 all-reduce is an extra ("sharded_70b"), never the headline value.
 
 Output protocol (benchlib/emit.py): the process prints ONE line to stdout -- the JSON result, written by rank 0 as the last
-bytes of the process (fd 1 is pointed at stderr for everything else, C libraries included; exit through os._exit).  The same
+thing it ever writes there (fd 1 is pointed at stderr for everything else, C libraries and exit handlers included).  The same
 document is written to bench_result.json.  This file is the headline path; the untimed extras live in benchlib/ (`detail`:
 benchlib/detail.py, budgeted so the default run stays near a minute -- `--full-detail` runs every section; `sharded_70b`:
 benchlib/sharded.py; `cpu_baseline` / `gpu_reference_baseline`: benchlib/cpu.py, the only importers of oracle/).

@@ -7,8 +7,12 @@ nothing after it (benchmark/matmul_benchmark.py:99-125); this module makes that 
   * `StdoutGuard.install()` (first thing in main, every rank) duplicates fd 1 to a private descriptor and points fd 1 at
     stderr.  From then on everything any library, C or Python, writes to "stdout" lands on stderr;
   * `emit_final(line)` flushes the C and Python buffers (they drain to stderr), writes the line to the private descriptor with
-    `os.write` and leaves through `os._exit(0)`: no atexit handler, destructor or buffered banner can follow it.  Ranks other
-    than 0 never touch the private descriptor.
+    `os.write` and ends the process through `sys.exit(0)`: whatever atexit handlers, destructors or buffered banners still print
+    goes to stderr -- the private descriptor is written exactly once.  (A normal exit, not `os._exit`: a profiler wrapped around
+    the process -- rocprofv3 for the committed kernel stats and counter passes -- writes its results in exit handlers.)  A daemon
+    timer ends the process with `os._exit(0)` if the interpreter has not finished 30 s later (a library teardown that hangs must
+    not hold the driver); from the watchdog's thread, where `sys.exit` would only end the thread, `os._exit` is used directly.
+    Ranks other than 0 never touch the private descriptor.
 
 `ExtrasWatchdog` guards the untimed sections after the timed region the same way: if they hang, rank 0 emits what it has.
 """
@@ -77,9 +81,9 @@ def dumps(result):
         return json.dumps({k: v for k, v in result.items() if k not in ("detail", "sharded_70b")}, default=lambda o: None)
 
 
-def emit_final(result, rank, side_file=None):
-    """Rank 0: write the full result to `side_file` (best effort), then the line as the LAST bytes of stdout.  Every rank: leave
-    through os._exit(0) -- nothing after this call runs, so nothing can print."""
+def emit_final(result, rank, side_file=None, hard=False):
+    """Rank 0: write the full result to `side_file` (best effort), then the line as the last (and only) bytes of stdout.  Every rank
+    then exits: normally (`sys.exit(0)` + a 30 s hard stop) from the main thread, `os._exit(0)` when `hard` (watchdog thread)."""
     if rank == 0:
         line = dumps(result)
         if side_file:
@@ -91,7 +95,15 @@ def emit_final(result, rank, side_file=None):
         flush_all()
         StdoutGuard.write_line(line)
     flush_all()
-    os._exit(0)
+    if hard or threading.current_thread() is not threading.main_thread():
+        os._exit(0)
+
+    def _hard_stop():
+        time.sleep(30.0)
+        os._exit(0)
+
+    threading.Thread(target=_hard_stop, daemon=True).start()
+    sys.exit(0)
 
 
 class ExtrasWatchdog:
@@ -118,7 +130,7 @@ class ExtrasWatchdog:
             self.result["extras_timed_out"] = {"after_s": self.budget_s, "section": self.section}
         else:
             time.sleep(5.0)  # rank 0 writes first
-        emit_final(self.result, self.rank, self.side_file)
+        emit_final(self.result, self.rank, self.side_file, hard=True)
 
     def finish(self):
         with self.lock:

@@ -7,7 +7,7 @@
 # Outputs land under gpurun_out/<tag>/; copy what is to be judged into profiles/ (tools/gpu/README.md).
 set +e
 TAG=${1:-final}
-RND=${2:-r05}   # prefix of the counter files copied to profiles/
+RND=${2:-r06}   # prefix of the counter files copied to profiles/
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -30,13 +30,25 @@ cd "$R"; python tools/make_pmc_traffic.py $OUT > $OUT/pmc_traffic.json; cp $OUT/
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o bench -- python "$R/bench.py" --steps 200 --warmup 5 --no-detail --no-cpu > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/rocprof.log"; echo "rocprof rc=$?"
 cd "$R"
 find $OUT -name "*kernel_trace*" -delete; find $OUT -name "*counter_collection*" -delete; find $OUT -name "*.db" -delete
-timeout 1200 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 1200 python bench.py --steps 50 --warmup 10 --full-detail > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+# what the DRIVER runs, and the assertion it makes on it: the last stdout line parses and carries roofline + cpu_baseline (round 5
+# lost its record to a library banner behind the line)
+bash tools/gpu/r6_bench_check.sh $TAG/driver_form
 timeout 600 python bench.py --steps 50 --warmup 10 --no-packed --no-detail --no-cpu > $OUT/bench_nopacked.json 2> $OUT/bench_nopacked.err; echo "bench(no-packed) rc=$?"
 head -8 $OUT/prof/*kernel_stats.csv | cut -c1-200; head -c 700 $OUT/bench.json; echo
+python3 - $OUT/bench.json <<'PY'
+import json, sys
+lines = open(sys.argv[1]).read().splitlines()
+assert len(lines) == 1, f"bench.json: {len(lines)} lines on stdout"
+d = json.loads(lines[-1])
+assert d.get("roofline") and d.get("cpu_baseline"), "bench.json: roofline / cpu_baseline missing"
+print("bench.json parses: value %.1f GB/s, frac %.4f, wall %s s, skipped %s" % (d["value"], d["roofline"]["frac"], d.get("bench_wall_s"), d.get("detail", {}).get("skipped")))
+PY
 timeout 900 $MB gemv quick > $OUT/mb_gemv_quick.log 2>&1; echo "mb gemv rc=$?"
 timeout 300 $MB gemm > $OUT/mb_gemm.log 2>&1; echo "mb gemm rc=$?"
 timeout 300 $MB multi > $OUT/mb_multi.log 2>&1; echo "mb multi rc=$?"
 grep -c MISMATCH $OUT/mb_gemv_quick.log $OUT/mb_multi.log
+timeout 900 python tools/scan_benchmark.py --json $OUT/scan_benchmark.json > $OUT/scan_benchmark.log 2>&1; echo "scan benchmark rc=$?"
 timeout 600 python tools/reference_triton.py --out $OUT/reference_triton.json > $OUT/reference_triton.log 2>&1; echo "reference triton rc=$?"
 bm() { name=$1; shift; timeout 600 python tools/matmul_benchmark.py --module "$@" --json $OUT/matmul_benchmark_$name.json 2>&1 | grep -i "speedup" | tr '\n' ' '; echo " [$name]"; }
 bm 1x16_eager; bm 1x16_graph --graph
