@@ -133,13 +133,17 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_
     """Resolve the kernels and run the load-time repack of every eligible QuantizedLinear now (GPU-resident modules
     only) instead of at its first forward; ``min_codes`` overrides ``inference.PREPACK_MIN_CODES`` for this call.
     ``drop_canonical``: free the checkpoint-layout ``codes`` of repacked layers -- the packed buffer is lossless; ``state_dict()``,
-    the > 6-row ops and backward rebuild the codes on demand through ``aqlm_hip_unpack_1x16`` into a transient buffer (one pass
-    over the packed bytes, measured per call in bench.py's ``detail.unpack_1x16_us``: a few per cent of a prefill call, a third of
-    a 7..32-row call).  Default since round 6 (this is the deployment call, and a second copy of the codes is what the format
-    exists to avoid): drop where a second, larger copy exists -- the slice-bucketed 1x16 buffers, 4.8 instead of 6.8 resident bits
-    per weight; planar 8x8 codes are the size of the canonical ones and the fused 8x8 g32 MFMA kernel reads the canonical layout,
-    so those keep both.  ``True``: drop everywhere (planar 8x8 included: 2.0 bits per weight); ``False``: keep everything (training,
-    speculative verification at 7+ rows on every step).  A module that was only packed lazily at its first forward keeps both.
+    the > 6-row ops and backward rebuild the codes through ``aqlm_hip_unpack_1x16``.  That unpack is not cheap (bench.py
+    ``detail.unpack_1x16_us``: 32 us for a 4096 x 4096 layer, 94 us for 4096 -> 11008 -- 2.4-2.9 x the 16-row op it would precede), so:
+      * default (round 6: this is the deployment call, and a second copy of the codes is what the format exists to avoid): the
+        1x16 layers -- whose packed buffer is a second, larger copy -- drop their codes NOW (4.8 instead of 6.8 resident bits per
+        weight) and a layer that is later called with 7+ rows / backward takes them back for good at that call (one unpack, not one
+        per call): decode-only deployments stay at one copy, everything else converges to round 5's behaviour.  Planar 8x8 layers
+        keep both (same size as the canonical codes, and the fused 8x8 g32 MFMA kernel reads the canonical layout);
+      * ``True``: drop everywhere, planar 8x8 included, and never restore (every call that needs the codes unpacks transiently):
+        the smallest footprint, 2.0 / 4.8 bits per weight;
+      * ``False``: keep everything (training, speculative verification at 7+ rows on every step).
+    A module that was only packed lazily at its first forward keeps both copies.
     ``compact=True`` packs 1x16 g8 layers with 24-bit entries (3.5 instead of 4.5 bytes per code: a 70B model holds 30 GB of
     packed codes instead of 39; measured 1-5 % slower matvecs).  ``thorough=True`` runs the local search of the entry order on
     every layer, not only on those of <= 8 Mi codes (1-3 % faster matvecs on the big layers for ~5x their prepack time).
@@ -174,7 +178,7 @@ def prepack_model(model: torch.nn.Module, min_codes: Optional[int] = None, drop_
                 # size as the canonical ones and the fused 8x8 g32 MFMA kernel (3+ rows) reads the canonical layout: those stay
                 # unless asked for.
                 if drop_canonical is True and (explicit_drop or m.nbits_per_codebook == 16):
-                    m.drop_canonical_codes()
+                    m.drop_canonical_codes(strict=explicit_drop)
     finally:
         inference.PREPACK_MIN_CODES = old
         _native.set_tuning("packed_entry_bytes", old_eb)

@@ -80,6 +80,7 @@ class QuantizedLinear(nn.Module):
         self._packed_codes = None  # derived, never saved: rebuilt from `codes` at first use
         self._packed_fingerprint = None
         self._codes_dropped = False
+        self._codes_drop_strict = True  # False: the first call that needs the canonical codes restores them for good (prepack_model's default)
         self._codes_shape = None
         self._cpu_codes_alt = None  # host modules with 8-bit codebooks: codes permuted for the LUT kernel (derived)
         self._prepack_deferred = False
@@ -227,7 +228,7 @@ class QuantizedLinear(nn.Module):
                 and not torch.compiler.is_compiling()):
             return torch.nn.functional.linear(input, self._dense_weight(), self.bias)
         op = self.gemv_op if self.use_gemv_rule(input) else self.gemm_op
-        return op.apply(input, self._canonical_codes(), self.codebooks, self.scales, self.bias)
+        return op.apply(input, self._codes_for_ops(), self.codebooks, self.scales, self.bias)
 
     def _rows_take_the_fused_8x8_op(self, input: torch.Tensor) -> bool:
         from .inference_kernels import hip_kernel
@@ -284,12 +285,25 @@ class QuantizedLinear(nn.Module):
             return self.codes
         return self._packed_codes.unpack()  # lossless inverse of the load-time re-layout (1x16 slices / 8x8 planes)
 
-    def drop_canonical_codes(self) -> bool:
+    def _codes_for_ops(self) -> torch.Tensor:
+        """The canonical codes for an op that reads them (> 6 rows, backward, a call the packed kernel does not take).  Dropped and not
+        `strict`: this module turns out to be used that way -- the codes come back for good (one unpack, 32 us for a 4096 x 4096
+        layer, instead of one per call: `detail.unpack_1x16_us` puts a transient unpack at 2.4-2.9 x the 16-row op it would precede).
+        Never inside a hipGraph capture or a trace (the restored parameter would belong to the capture): those calls unpack
+        transiently."""
+        if (self._codes_dropped and not self._codes_drop_strict and not torch.compiler.is_compiling()
+                and not (self.codebooks.is_cuda and torch.cuda.is_current_stream_capturing())):
+            self.restore_canonical_codes()
+        return self._canonical_codes()
+
+    def drop_canonical_codes(self, strict: bool = True) -> bool:
         """Inference-only memory saver: free ``codes`` of a prepacked layer (the packed buffer holds the same
-        information; ``state_dict()`` and the large-batch / backward ops rebuild them on demand).  Returns whether
-        anything was freed."""
+        information; ``state_dict()`` and the large-batch / backward ops rebuild them on demand).  ``strict=False``: the first
+        forward that needs them restores them for good (decode-only deployments keep one copy, a model that is also called with 7+
+        rows pays one unpack per layer and ends up with both).  Returns whether anything was freed."""
         if self._packed_codes is None or self._codes_dropped:
             return False
+        self._codes_drop_strict = bool(strict)
         self._codes_shape = tuple(self.codes.shape)
         self.codes = nn.Parameter(torch.empty((0,), dtype=self.codes.dtype, device=self.codes.device), requires_grad=False)
         self._codes_dropped = True

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--full-detail", action="store_true", help="run every section of the breakdown (minutes) instead of the time-budgeted default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and gpu_reference_baseline legs")
     ap.add_argument("--no-packed", action="store_true", help="direct L2-gather kernel for every layer (no prepacked path)")
+    ap.add_argument("--soft-exit", action="store_true", help="exit through the interpreter after the line (profilers write in exit handlers)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -99,6 +100,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched by torch.distributed.run with another --nproc-per-node?)")
+    if args.soft_exit:
+        os.environ["AQLM_BENCH_SOFT_EXIT"] = "1"
     StdoutGuard.install()  # from here on fd 1 is stderr for everybody; the result line goes out through emit_final
     os.environ.setdefault("NCCL_DEBUG", "WARN")  # (the librccl banner is harmless now; this only keeps stderr short)
     if os.environ.get("AQLM_BENCH_EMIT_PROBE") == "1":

@@ -7,11 +7,10 @@ nothing after it (benchmark/matmul_benchmark.py:99-125); this module makes that 
   * `StdoutGuard.install()` (first thing in main, every rank) duplicates fd 1 to a private descriptor and points fd 1 at
     stderr.  From then on everything any library, C or Python, writes to "stdout" lands on stderr;
   * `emit_final(line)` flushes the C and Python buffers (they drain to stderr), writes the line to the private descriptor with
-    `os.write` and ends the process through `sys.exit(0)`: whatever atexit handlers, destructors or buffered banners still print
-    goes to stderr -- the private descriptor is written exactly once.  (A normal exit, not `os._exit`: a profiler wrapped around
-    the process -- rocprofv3 for the committed kernel stats and counter passes -- writes its results in exit handlers.)  A daemon
-    timer ends the process with `os._exit(0)` if the interpreter has not finished 30 s later (a library teardown that hangs must
-    not hold the driver); from the watchdog's thread, where `sys.exit` would only end the thread, `os._exit` is used directly.
+    `os.write` -- exactly once per process -- and ends the process with `os._exit(0)`: no teardown of a library (RCCL communicators,
+    captured graphs) can hang or crash the run after its result is out.  Under a profiler (rocprofv3 writes its kernel stats and
+    counter files in exit handlers: `AQLM_BENCH_SOFT_EXIT=1`, `--soft-exit`, or a ROCPROF* variable in the environment) the exit is
+    a normal `sys.exit(0)` with a 30 s hard stop behind it; whatever the handlers print goes to stderr.
     Ranks other than 0 never touch the private descriptor.
 
 `ExtrasWatchdog` guards the untimed sections after the timed region the same way: if they hang, rank 0 emits what it has.
@@ -81,9 +80,16 @@ def dumps(result):
         return json.dumps({k: v for k, v in result.items() if k not in ("detail", "sharded_70b")}, default=lambda o: None)
 
 
+def soft_exit_wanted():
+    """A profiler around the process needs the exit handlers to run."""
+    if os.environ.get("AQLM_BENCH_SOFT_EXIT") == "1":
+        return True
+    return any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def emit_final(result, rank, side_file=None, hard=False):
-    """Rank 0: write the full result to `side_file` (best effort), then the line as the last (and only) bytes of stdout.  Every rank
-    then exits: normally (`sys.exit(0)` + a 30 s hard stop) from the main thread, `os._exit(0)` when `hard` (watchdog thread)."""
+    """Rank 0: write the full result to `side_file` (best effort), then the line as the only bytes of stdout.  Every rank then
+    exits: `os._exit(0)` (also always from the watchdog's thread: `hard`), or normally when a profiler needs the exit handlers."""
     if rank == 0:
         line = dumps(result)
         if side_file:
@@ -95,7 +101,7 @@ def emit_final(result, rank, side_file=None, hard=False):
         flush_all()
         StdoutGuard.write_line(line)
     flush_all()
-    if hard or threading.current_thread() is not threading.main_thread():
+    if hard or threading.current_thread() is not threading.main_thread() or not soft_exit_wanted():
         os._exit(0)
 
     def _hard_stop():

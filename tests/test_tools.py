@@ -130,7 +130,11 @@ def test_bench_result_line_is_the_last_and_only_thing_on_stdout(tmp_path):
     assert "roofline" in parsed and "cpu_baseline" in parsed and parsed["value"] == 1.0
     assert len(lines) == 1, lines
     assert b"pretend banner" in p.stderr and b"python chatter" in p.stderr  # the chatter is not lost, it is on stderr
-    assert b"atexit chatter" in p.stderr and b"atexit chatter" not in p.stdout  # exit handlers still run (a profiler needs them): on stderr
+    assert b"atexit chatter" not in p.stdout + p.stderr                      # os._exit: nothing runs after the line
+    # under a profiler the exit handlers must run (rocprofv3 writes its files there): still one line on stdout, the rest on stderr
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--soft-exit"], cwd=ROOT, env=env, capture_output=True, timeout=300)
+    assert p2.returncode == 0 and p2.stdout.decode().splitlines() == lines
+    assert b"atexit chatter" in p2.stderr
     assert json.loads(side.read_text()) == parsed                            # the same document next to it
 
 

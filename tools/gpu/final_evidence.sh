@@ -24,10 +24,10 @@ for spec in "2x8g8 4096 kx8 gemv_kx8_rep_kernel ${RND}_2x8_rep_kernel_pmc.json" 
   cp $OUT/$5 profiles/$5
   rm -rf gpurun_out/pmc_${TAG}_$3
 done
-cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/$OUT/pmc_fetch" -o bench -- python "$R/bench.py" --steps 4 --warmup 1 --no-detail --no-cpu > "$R/$OUT/pmc_fetch.log" 2>&1; echo "pmc fetch rc=$?"
-cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/$OUT/pmc_write" -o bench -- python "$R/bench.py" --steps 4 --warmup 1 --no-detail --no-cpu > "$R/$OUT/pmc_write.log" 2>&1; echo "pmc write rc=$?"
+cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/$OUT/pmc_fetch" -o bench -- python "$R/bench.py" --steps 4 --warmup 1 --no-detail --no-cpu --soft-exit > "$R/$OUT/pmc_fetch.log" 2>&1; echo "pmc fetch rc=$?"
+cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/$OUT/pmc_write" -o bench -- python "$R/bench.py" --steps 4 --warmup 1 --no-detail --no-cpu --soft-exit > "$R/$OUT/pmc_write.log" 2>&1; echo "pmc write rc=$?"
 cd "$R"; python tools/make_pmc_traffic.py $OUT > $OUT/pmc_traffic.json; cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o bench -- python "$R/bench.py" --steps 200 --warmup 5 --no-detail --no-cpu > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/rocprof.log"; echo "rocprof rc=$?"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o bench -- python "$R/bench.py" --steps 200 --warmup 5 --no-detail --no-cpu --soft-exit > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/rocprof.log"; echo "rocprof rc=$?"
 cd "$R"
 find $OUT -name "*kernel_trace*" -delete; find $OUT -name "*counter_collection*" -delete; find $OUT -name "*.db" -delete
 timeout 1200 python bench.py --steps 50 --warmup 10 --full-detail > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
