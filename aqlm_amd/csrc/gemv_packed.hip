@@ -868,8 +868,9 @@ __global__ __launch_bounds__(64) void pk_unpack3_kernel(const uint8_t* ent3, con
 
 // inverse of the repack: canonical codes [M][in_groups] from a packed buffer (lossless; used to drop / restore the
 // canonical codes of inference-only models and by the tests).  One wave per (stream, wave range).
-__global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, const uint32_t* winfo, const uint16_t* old_of_new,
-                                                       uint16_t* codes, const PkGeom G, int in_groups, int NW, int T) {
+__global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ winfo,
+                                                       const uint16_t* __restrict__ old_of_new, uint16_t* __restrict__ codes, const PkGeom G,
+                                                       int in_groups, int NW, int T) {
   const int xstride = pk_x_stride(in_groups);
   const size_t st = blockIdx.x;
   const int w = blockIdx.y, l = threadIdx.x;
@@ -877,22 +878,35 @@ __global__ __launch_bounds__(64) void pk_unpack_kernel(const uint32_t* ent, cons
   pk_stream_rows(G, (int)st, s, row0, nrows);
   const uint32_t* wi = winfo + (st * NW + w) * 4;
   const int steps = (int)wi[2];
-  const uint32_t* col = ent + (((size_t)st * NW + w) * T * 64 + l) * 4;
+  const u32x4* col = reinterpret_cast<const u32x4*>(ent + (((size_t)st * NW + w) * T * 64 + l) * 4);
   int local = 0;
-  for (int t = 0; t < steps; ++t) {
-    const uint32_t* e = col + (size_t)t * 256;
-    const uint32_t e0 = e[0];
-    if (t == 0) local = (int)pk_get_start_row(e0, e[1], e[2], e[3]);
+  // A column's lane-steps are independent loads; only the row counter is sequential.  UB of them are requested before the first is
+  // decoded (round 6: the first cut loaded, decoded and stored one lane-step at a time -- with ~10 steps per column and 14 waves per
+  // CU the kernel was a chain of HBM round trips: 32 us for the 10 MB of a 4096 x 4096 layer, bench.py detail.unpack_1x16_us).
+  constexpr int UB = 8;
+  for (int t0 = 0; t0 < steps; t0 += UB) {
+    u32x4 ev[UB];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t v = e[k];
-      const int j = (int)(v >> (16 + PK_VSH)) - (int)((v >> 16) & 3u) * xstride;
-      if (j < in_groups && local < nrows) {
-        const uint32_t c = ((uint32_t)s << PK_CODE_BITS) | ((v >> PK_VSH) & (uint32_t)(PK_SLICE_ENTRIES - 1));
-        codes[(size_t)(row0 + local) * in_groups + j] = old_of_new ? old_of_new[c] : (uint16_t)c;
-      }
+    for (int u = 0; u < UB; ++u) {
+      const int t = t0 + u < steps ? t0 + u : steps - 1;
+      ev[u] = col[(size_t)t * 64];
     }
-    local += (int)(e0 & 1u);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (t0 + u >= steps) break;
+      const uint32_t e[4] = {ev[u].x, ev[u].y, ev[u].z, ev[u].w};
+      if (t0 + u == 0) local = (int)pk_get_start_row(e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t v = e[k];
+        const int j = (int)(v >> (16 + PK_VSH)) - (int)((v >> 16) & 3u) * xstride;
+        if (j < in_groups && local < nrows) {
+          const uint32_t c = ((uint32_t)s << PK_CODE_BITS) | ((v >> PK_VSH) & (uint32_t)(PK_SLICE_ENTRIES - 1));
+          codes[(size_t)(row0 + local) * in_groups + j] = old_of_new ? old_of_new[c] : (uint16_t)c;
+        }
+      }
+      local += (int)(e[0] & 1u);
+    }
   }
 }
 

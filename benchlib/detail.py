@@ -513,8 +513,9 @@ def run_detail(c, detail, t_start, budget_s, full, watchdog=None):
             fn(c, detail)
         except Exception as e:  # noqa: BLE001 - an extra never costs the headline line
             detail[f"{name}_error"] = f"{type(e).__name__}: {e}"
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
         detail["section_seconds"][name] = round(time.perf_counter() - t0, 2)
     if detail["skipped"]:
         detail["skipped_note"] = f"sections not started after {budget_s:.0f} s of process time (default budget); `python bench.py --full-detail` runs all"

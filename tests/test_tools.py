@@ -145,3 +145,35 @@ def test_bench_headline_path_stays_readable():
     assert n < 300, n
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "emit_final(result, rank" in src and "StdoutGuard.install()" in src and "print(json.dumps" not in src
+
+
+def test_bench_detail_sections_respect_the_time_budget(monkeypatch):
+    """benchlib.detail.run_detail: sections run in priority order, one is only STARTED while the process is younger than the budget
+    (the default run stays near a minute; `--full-detail` = budget 0 runs all), an exception in a section is recorded and does not
+    stop the others, and what did not run is listed."""
+    import time
+
+    sys.path.insert(0, ROOT)
+    from benchlib import detail as DT
+
+    ran = []
+
+    def quick(name, secs=0.0, fail=False):
+        def fn(c, d):
+            ran.append(name)
+            time.sleep(secs)
+            if fail:
+                raise RuntimeError("boom")
+            d[name] = True
+        return fn
+
+    monkeypatch.setattr(DT, "SECTIONS", [("a", quick("a", 0.3)), ("b", quick("b", fail=True)), ("c", quick("c", 0.3)), ("d", quick("d"))])
+    det = {}
+    t0 = time.perf_counter()
+    DT.run_detail(None, det, t0, 0.5, False)
+    assert ran == ["a", "b", "c"] and det["skipped"] == ["d"] and "skipped_note" in det
+    assert det["a"] and det["c"] and det["b_error"].startswith("RuntimeError") and set(det["section_seconds"]) == {"a", "b", "c"}
+    ran.clear()
+    det = {}
+    DT.run_detail(None, det, t0 - 100.0, 0.0, True)          # no budget: everything runs however old the process is
+    assert ran == ["a", "b", "c", "d"] and det["skipped"] == []
