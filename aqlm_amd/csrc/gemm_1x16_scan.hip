@@ -87,7 +87,7 @@ struct Params {
 // One work item per workgroup.  U = units (8 k-steps = 256 features each) per wave, NBT = 16-row batch tiles per pass, D = tiles of
 // code words in flight.
 //
-// What the loop is built around (measured on the first cuts, profiles/r06_scan_knockouts.log):
+// What the loop is built around (measured on the first cuts, profiles/r06_scan_kernel_knockouts.log):
 //   * NO branch around a VMEM instruction and no compiler-visible store in the loop: hipcc's wait-count insertion answers either
 //     with vmcnt(0), which serialised the code prefetch on memory latency (1.5 us per tile).  Code loads are unconditional (clamped
 //     addresses); the one store per tile is inline asm (loads return in order among themselves, so a store the compiler does not

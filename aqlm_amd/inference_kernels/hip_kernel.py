@@ -1347,7 +1347,13 @@ def fused_8x8_min_rows(out_features: int, in_features: int) -> int:
     """Rows from which the fused MFMA kernel beats the look-up-table matvec on an 8x8 g32 layer.  Both times are affine in what
     they scale with (profiles/r05_gemm_8x8_mfma.log, r05_mb_lutrows.log; us, MI355X): the fused kernel costs 3.6 + 2.15 per round
     of 256 sixteen-row tiles and 1024 input features, whatever the rows (<= 16); the table kernel 1.3 + rows x (3.7 + 0.05 per
-    million weights).  4096 x 4096: 3 rows; 4096 -> 11008 and 8192 x 8192: 5; 11008 -> 4096: 4."""
+    million weights).  4096 x 4096: 3 rows; 4096 -> 11008 and 8192 x 8192: 5; 11008 -> 4096: 4.
+    The comparison is with what the operator can run INSTEAD -- the table kernel -- not with not quantising: on the MLP shapes the fused
+    kernel is faster than the table kernel from these row counts on and still slower than a dense fp16 GEMM (4096 -> 11008: 28.4 us for
+    5..16 rows against 19.8-20.1 dense, 8192 x 8192 35 against 29-30; at 4096 x 4096 12.2 against 12.8; bench.py
+    `detail.small_batch_rows_8x8g32` prints `dense_fp16_us` beside every count, profiles/r05_gemm_8x8_mfma_pmc.json has the reason: 54 %
+    of the kernel's LDS cycles are bank conflicts of the codebook gathers).  A deployment that prefers speed to memory at those batch
+    sizes has `prefer_dense_below_rows`."""
     if FUSED_8X8_MFMA_MIN_ROWS > 0:
         return FUSED_8X8_MFMA_MIN_ROWS
     tiles = (out_features + 15) // 16

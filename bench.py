@@ -245,7 +245,10 @@ def main():
     try:
         if rank == 0 and not args.no_cpu:  # the CPU leg first: the contract's `cpu_baseline` must not depend on the budgeted extras
             extras.section = "cpu_baseline"
-            result["cpu_baseline"] = CPU.cpu_baseline(float(os.environ.get("AQLM_BENCH_CPU_SAMPLE_S", "12")))
+            try:  # (guarded on its own: rank 0 must reach the collectives of `sharded_70b` like every other rank)
+                result["cpu_baseline"] = CPU.cpu_baseline(float(os.environ.get("AQLM_BENCH_CPU_SAMPLE_S", "12")))
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline_error"] = f"{type(e).__name__}: {e}"
         if not args.no_detail:
             from benchlib import detail as DT
             from benchlib import sharded as SH
@@ -270,14 +273,13 @@ def main():
 
     if not extras.finish():
         return  # the watchdog is emitting the line and ending the process
-    if dist:
-        dist.barrier()
 
-    def teardown():  # process groups go BEFORE the line (librccl may talk on the way out) -- but may never cost the line
+    def teardown():  # ranks meet and the process groups go BEFORE the line (librccl may talk on the way out) -- but never cost it
         try:
             import torch.distributed as td
 
             if td.is_initialized():
+                td.barrier()
                 td.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
@@ -286,7 +288,7 @@ def main():
 
     th = threading.Thread(target=teardown, daemon=True)
     th.start()
-    th.join(timeout=20.0)
+    th.join(timeout=120.0 if dist else 20.0)
     emit_final(result, rank, side_file)
 
 
