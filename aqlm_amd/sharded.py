@@ -55,10 +55,12 @@ def shard_bounds(n: int, world: int, rank: int, multiple: int = 1):
 
 
 def packed_matvec_cost_us(out_features: int, in_features: int, in_group_size: int = 8) -> float:
-    """Cost line of the prepacked 1x16 matvec on one MI355X (bs = 1, cold), read off bench.py's figures: ~3.3 us fixed (launch
-    boundary, slice fill, hand-in) + ~1.1 us per million ENTRY SLOTS -- every (row, slice) bucket is padded to lane-steps of 4
-    entries, so short rows pay for slots that hold no code (a 1024-wide shard has 8 codes per bucket = 2-3 lane-steps: 10.1 us for
-    3.7 M codes where the 8192 -> 3584 shard of the same layer takes 8.0 us; 4096 x 4096 6.0, 4096 -> 11008 8.8, 8192 -> 28672 26.9)."""
+    """Empirical cost line of the prepacked 1x16 matvec on one MI355X (bs = 1, cold), fitted to bench.py's five shapes: ~3.3 us fixed
+    (launch boundary, slice fill, hand-in) + ~1.1 us per million entry slots, where a (row, slice) bucket counts as its lane-steps of
+    4 entries.  What the slot count stands in for: short rows cost more per code than long ones -- a 1024-wide shard has 8 codes per
+    bucket, i.e. a row end (flush of the lane's sums, and one returning atomic per row and slice in the epilogue: 459 k of them for
+    28672 rows) every 2-3 lane-steps --: 10.1 us for the 3.7 M codes of 1024 -> 28672 where the 8192 -> 3584 shard of the same layer
+    takes 8.0 us (4096 x 4096 6.0, 4096 -> 11008 8.8, 8192 -> 28672 26.9).  Good to ~15 % on those; not a model of anything else."""
     slices = 16 if in_group_size == 8 else 32
     per_bucket = (in_features // in_group_size) / slices
     lane_steps = max(1, -(-int(per_bucket + 1.5) // 4))       # expected codes + the Poisson tail, in steps of 4 entries
